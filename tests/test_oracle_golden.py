@@ -1,0 +1,130 @@
+"""Pins oracle/torch_ref.py (the torch-CPU restatement) to the golden vectors produced from the real
+reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, grad_tol, rel_err
+from detinit import det_state, sample_index
+from oracle import torch_ref as R
+
+TOL = 1e-4
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def det_sd(net):
+    lay = R.state_layout(net, 1, 4)
+    vals = det_state({k: s for k, s in lay}, 2022)
+    return {k: t(v).clone() for k, v in vals.items()}
+
+
+def test_state_layout_matches_reference_keys():
+    g = golden("g0_init")
+    for net in ("unet", "unet_cct"):
+        lay = R.state_layout(net, 1, 4)
+        assert [k for k, _ in lay] == list(g[f"{net}_keys"])
+        assert [str(tuple(s)) for _, s in lay] == list(g[f"{net}_shapes"])
+    assert sum(int(np.prod(s)) for k, s in R.state_layout("unet_cct") if R.is_param(k)) == 2447064
+    assert sum(int(np.prod(s)) for k, s in R.state_layout("unet") if R.is_param(k)) == 1813764
+
+
+@pytest.mark.parametrize("tag,net", [("cct32", "unet_cct"), ("unet32", "unet"), ("cct48x80", "unet_cct")])
+def test_net_forward_backward(tag, net):
+    g = golden(f"g2_{tag}")
+    sd = det_sd(net)
+    pk = [k for k in sd if R.is_param(k)]
+    for k in pk:
+        sd[k].requires_grad_(True)
+    x, lab = t(g["x"]), t(g["label"])
+    em = [t(g[f"emask{i}"]) for i in range(5)]
+    cm = [t(g[f"cmask{i}"]) for i in range(5)] if net == "unet_cct" else None
+    out = R.net_forward(sd, x, net, em, cm, True)
+    if net == "unet_cct":
+        assert rel_err(out[0].detach(), g["logits_main"]) < TOL
+        assert rel_err(out[1].detach(), g["logits_aux"]) < TOL
+        loss, lce, lpse, pseudo = R.ours_proposed_loss(out[0], out[1], lab, float(g["beta"]))
+        assert np.array_equal(pseudo.numpy(), g["pseudo"])
+        assert rel_err([loss.item(), lce.item(), lpse.item()], g["loss_parts"]) < TOL
+    else:
+        assert rel_err(out.detach(), g["logits_main"]) < TOL
+        loss = R.ce_ignore(out, lab)
+        assert rel_err([loss.item()], g["loss_parts"]) < TOL
+    loss.backward()
+    for k in pk:
+        gr = sd[k].grad.numpy().ravel()
+        ref = g[f"g.{k}"]
+        assert np.max(np.abs(gr[sample_index(gr.size)] - ref)) <= grad_tol(k, ref), k
+    for k in sd:
+        if k.endswith(("running_mean", "running_var")):
+            assert rel_err(sd[k].detach(), g[f"b.{k}"]) < TOL, k
+    with torch.no_grad():
+        ev = R.net_forward(sd, x, net, None, [torch.zeros_like(c) for c in cm] if cm else None, False)
+    assert rel_err((ev[0] if net == "unet_cct" else ev), g["logits_eval"]) < TOL
+
+
+def test_losses_against_reference():
+    g = golden("g3_head")
+    for tag in "ab":
+        z1, z2 = t(g[f"{tag}_z1"]).requires_grad_(), t(g[f"{tag}_z2"]).requires_grad_()
+        loss, lce, lpse, pseudo = R.ours_proposed_loss(z1, z2, t(g[f"{tag}_label"]), float(g[f"{tag}_beta"]))
+        loss.backward()
+        assert np.array_equal(pseudo.numpy(), g[f"{tag}_pseudo"])
+        assert rel_err(loss.item(), g[f"{tag}_loss"]) < 1e-5
+        assert rel_err(z1.grad, g[f"{tag}_dz1"]) < TOL and rel_err(z2.grad, g[f"{tag}_dz2"]) < TOL
+    for i, b in enumerate(g["mix_betas"]):
+        assert np.array_equal(R.mix_argmax(t(g["mix_s1"]), t(g["mix_s2"]), float(b)).numpy(), g["mix_pseudo"][i])
+    s = t(g["pd_s"]).requires_grad_()
+    l = R.pdice(s, t(g["pd_target"]))
+    l.backward()
+    assert rel_err(l.item(), g["pd_loss"]) < 1e-5 and rel_err(s.grad, g["pd_ds"]) < TOL
+    s = t(g["dl_s"]).requires_grad_()
+    l = R.dice(s, t(g["dl_target"]))
+    l.backward()
+    assert rel_err(l.item(), g["dl_loss"]) < 1e-5 and rel_err(s.grad, g["dl_ds"]) < TOL
+    assert np.isnan(g["ce_allignored"]) and torch.isnan(R.ce_ignore(t(g["ce_z"]), torch.full((2, 16, 16), 4)))
+    a = t(g["mse_a"]).requires_grad_()
+    l = R.softmax_mse(a, t(g["mse_b"])).mean()
+    l.backward()
+    assert rel_err(l.item(), g["mse_loss"]) < 1e-5 and rel_err(a.grad, g["mse_da"]) < TOL
+
+
+def test_gatedcrf_tv_ms_against_reference():
+    g = golden("g4_gatedcrf")
+    for tag in ("r5", "r2", "ns5", "ns2", "r1"):
+        y = t(g[f"{tag}_y"]).requires_grad_()
+        loss, msg = R.gatedcrf(y, t(g[f"{tag}_img"]), int(g[f"{tag}_r"]))
+        loss.backward()
+        assert rel_err(loss.item(), g[f"{tag}_loss"]) < TOL, tag
+        assert rel_err(y.grad, g[f"{tag}_dy"]) < TOL, tag
+        N, C, H, W = y.shape
+        assert rel_err((-2.0 * msg / (N * H * W)).detach(), g[f"{tag}_dy"]) < TOL   # analytic backward
+    w, sxy, srgb = g["alt_desc"]
+    y = t(g["alt_y"]).requires_grad_()
+    loss, _ = R.gatedcrf(y, t(g["alt_img"]), int(g["alt_r"]), sxy, srgb, w)
+    loss.backward()
+    assert rel_err(loss.item(), g["alt_loss"]) < TOL and rel_err(y.grad, g["alt_dy"]) < TOL
+    g = golden("g5_tv_ms")
+    for pre in ("tv", "tvt"):
+        p = t(g[f"{pre}_p"]).requires_grad_()
+        l = R.tv_loss(p[1:] if pre == "tv" else p)
+        l.backward()
+        assert rel_err(l.item(), g[f"{pre}_loss"]) < 1e-5 and rel_err(p.grad, g[f"{pre}_dp"]) < TOL
+    p = t(g["ms_p"]).requires_grad_()
+    l = R.mumford_shah(t(g["ms_img"]), p)
+    l.backward()
+    assert rel_err(l.item(), g["ms_loss"]) < 1e-5 and rel_err(p.grad, g["ms_dp"]) < TOL
+
+
+def test_sgd_ema_against_reference():
+    g = golden("g6_sgd_ema")
+    p, e = t(g["p0"]).clone(), t(g["ema0"]).clone()
+    buf = torch.zeros_like(p)
+    for it in range(5):
+        lr = 0.01 if it == 0 else R.poly_lr(0.01, it - 1, 60000)
+        assert abs(lr - g["lrs"][it]) < 1e-15
+        R.sgd_step([p], [t(g["grads"][it])], [buf], lr, first=(it == 0))
+        R.ema_update([e], [p], 0.99, it)
+        assert rel_err(p, g["params"][it]) < 1e-6 and rel_err(e, g["emas"][it]) < 1e-6
