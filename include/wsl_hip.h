@@ -1,0 +1,205 @@
+/* wsl_hip.h -- C ABI of libwslhip.so: the MI355X (gfx950) hot path of WSL4MIS' 2-D weakly-supervised
+ * training step (dual-branch UNet + scribble losses), as hand-written HIP kernels.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors on the Python side); the library
+ *     borrows it for the duration of the enqueue, never allocates, never frees, never synchronises;
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns 0 (WSL_OK) or a negative
+ *     WSL_E* code; wsl_last_error() returns a thread-local description of the last failure;
+ *   - tensors are fp32 NCHW, contiguous unless a *_bs ("batch stride", in elements) argument says otherwise:
+ *     a batch stride lets a channel-slice of a wider tensor be passed without a copy;
+ *   - scalar results (losses) are written to device memory; reading them is the caller's (only) sync;
+ *   - reductions are two-stage and order-fixed (no float atomics): results are run-to-run reproducible.
+ *
+ * Citations "ref:" are file:line under the reference checkout's code/ directory.
+ */
+#ifndef WSL_HIP_H
+#define WSL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSL_OK 0
+#define WSL_EINVAL (-1)       /* bad shape / null pointer / inconsistent arguments */
+#define WSL_EUNSUPPORTED (-2) /* valid in the reference but not built (reported, never ignored) */
+#define WSL_EHIP (-3)         /* a HIP runtime error was reported at launch */
+#define WSL_EWORKSPACE (-4)   /* workspace smaller than the matching *_ws_bytes() query */
+
+#define WSL_LEAKY_SLOPE 0.01f /* nn.LeakyReLU() default, ref: networks/unet.py:21,25 */
+
+int wsl_version(void);              /* 100*major + minor */
+const char* wsl_last_error(void);   /* thread-local, valid until the next failing call on this thread */
+const char* wsl_build_info(void);   /* "gfx950 hipcc ..." or "HOST-EMULATION (tests only)" */
+
+/* ------------------------------------------------------------------------------------------------ conv stack
+ * One channel-range of a convolution's *virtual* input.  The loader applies, per element,
+ *     v = x[n, c, y, x]
+ *     if (scale)  v = leaky_relu(v * scale[c] + shift[c])      (BatchNorm apply + LeakyReLU of the producer)
+ *     if (emask)  v = emask[n, c, y, x] ? v * emask_scale : 0  (nn.Dropout(p): keep mask, scale 1/(1-p))
+ *     if (cmask)  v = v * cmask[n, c]                          (F.dropout2d channel multiplier, 0 or 1/(1-p))
+ * and then zero-pads.  Two sources concatenated along C reproduce torch.cat([skip, up], 1) without a copy
+ * (ref: networks/unet.py:18-26 ConvBlock, :63-68 UpBlock.forward, :254-256 Dropout). */
+typedef struct WslSrc {
+  const float* x;        /* [N, C, H, W] with batch stride `bs` */
+  int64_t bs;            /* elements between consecutive samples (>= C*H*W) */
+  int32_t C;             /* 0 = source absent */
+  int32_t _pad0;
+  const float* scale;    /* [C] or NULL */
+  const float* shift;    /* [C] (required iff scale) */
+  const uint8_t* emask;  /* [N, C, H, W] dense, or NULL */
+  float emask_scale;
+  float _pad1;
+  const float* cmask;    /* [N, C] or NULL */
+} WslSrc;
+
+/* y = conv2d(cat(a, b), w) + bias, stride 1, zero padding ks/2, ks in {1,3} (nn.Conv2d, ref: unet.py:19,23,55,120).
+ * wmode 0: w is [Co][Ci][ks][ks] (forward).  wmode 1: data-gradient mode, w is the FORWARD weight
+ * [Ci][Co][ks][ks] and the kernel uses w[ci][co][ks-1-ky][ks-1-kx] (what autograd's conv backward computes).
+ * If stat_part != NULL the epilogue also emits per-block (sum, M2) of y per channel for BatchNorm
+ * (layout [nblk][Co][2], nblk = wsl_conv2d_stat_blocks(); stat_cnt [nblk] = valid pixels per block). */
+int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y, int64_t y_bs,
+                   int N, int H, int W, int Co, int ks, int wmode, float* stat_part, float* stat_cnt, void* stream);
+int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int ks);
+
+/* dw[Co][Ci][ks][ks] = sum_{n,y,x} dy[n,co,y,x] * in[n,ci,y+ky-p,x+kx-p];  db[Co] = sum dy  (db may be NULL).
+ * Split over pixels into partials in `ws`, then an order-fixed second stage. */
+int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db,
+                     int N, int H, int W, int Co, int ks, void* ws, size_t ws_bytes, void* stream);
+size_t wsl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co, int ks);
+
+/* BatchNorm2d, training mode (ref: unet.py:20,24; eps 1e-5, momentum 0.1): merge the conv epilogue's partials
+ * (Chan's parallel variance), write mean/invstd (saved for backward) and the fused apply coefficients
+ * scale = gamma*invstd, shift = beta - mean*scale; update running_mean / running_var (unbiased) /
+ * num_batches_tracked in place (any of the three may be NULL). */
+int wsl_bn_stats_finalize(const float* stat_part, const float* stat_cnt, int nblk, int C, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                          int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                          void* stream);
+/* eval mode: scale/shift from the running statistics. */
+int wsl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int C, float* scale, float* shift, void* stream);
+/* out = the loader's transform of one source, materialised (used for returning features / tests). */
+int wsl_src_materialize(const WslSrc* s, float* out, int64_t out_bs, int N, int H, int W, void* stream);
+/* out[n,c,i,j] = max over the 2x2 window of transform(src) (nn.MaxPool2d(2), ref: unet.py:38). H, W even or odd
+ * (floor), window scan row-major, strict '>' (first maximum wins). */
+int wsl_pool2_fwd(const WslSrc* s, float* out, int N, int H, int W, void* stream);
+
+/* Gradient that reaches one encoder feature map f = transform(y) from its three consumers:
+ *   g[n,c,y,x] = ga[n,c,y,x] + gb[n,c,y,x]*gb_cmask[n,c] + (gp[n,c,y/2,x/2] if (y,x) is the arg-max of its window)
+ * ga/gb/gp may each be NULL.  The arg-max is recomputed from `f` (same transform as the forward pool). */
+int wsl_feat_grad_combine(const WslSrc* f, const float* ga, int64_t ga_bs, const float* gb, int64_t gb_bs,
+                          const float* gb_cmask, const float* gp, float* g, int N, int H, int W, void* stream);
+
+/* Backward of  out = dropout(leaky(bn(y)))  for one conv output y, given g = dL/d(out):
+ *   stage 1: per-channel sums  S1 = sum dz, S2 = sum dz*xhat   (dz = g*emask*emask_scale*leaky'(z))
+ *   stage 2: dgamma = S2, dbeta = S1, dy = gamma*invstd*(dz - S1/n - xhat*S2/n)
+ * ws: wsl_bnact_bwd_ws_bytes().  (autograd of ref: unet.py:18-26) */
+int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                  float* dgamma, float* dbeta, int N, int C, int H, int W, void* ws, size_t ws_bytes, void* stream);
+size_t wsl_bnact_bwd_ws_bytes(int N, int C, int H, int W);
+
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (ref: unet.py:56-57) and its transpose. */
+int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream);
+int wsl_bilinear_up2_bwd(const float* dout, int64_t dout_bs, float* du, int N, int C, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ losses
+ * Labels: uint8 (label_i64 == 0) or int64 (label_i64 == 1), values 0..C-1 or `ignore`. C <= 8. */
+int wsl_softmax_fwd(const float* z, float* s, int N, int C, int HW, void* stream);
+int wsl_softmax_bwd(const float* s, const float* ds, float* dz, int N, int C, int HW, void* stream);
+
+/* torch.nn.CrossEntropyLoss(ignore_index) (ref: train_weakly_supervised_pCE_2D.py:81,100): loss[0] = mean NLL over
+ * non-ignored pixels (NaN if none), dz = gscale*(softmax - onehot)/n_valid on valid pixels, 0 elsewhere. */
+int wsl_ce_fwd_bwd(const float* z, const void* label, int label_i64, int ignore, float* loss, float* dz, float gscale,
+                   int N, int C, int HW, void* ws, size_t ws_bytes, void* stream);
+/* pseudo = argmax_c(beta*s1 + (1-beta)*s2), two fp32 multiplies + one add, no FMA contraction, first index on
+ * ties -- bit-exact with torch (ref: ...pCE_ours_proposed.py:117-120).  beta is the python double. */
+int wsl_mix_argmax(const float* s1, const float* s2, double beta, int64_t* pseudo, int N, int C, int HW, void* stream);
+/* utils.losses.pDLoss(n_classes, ignore_index).forward (ref: utils/losses.py:195-232) including its
+ * [N,H,W]x[N,1,H,W] broadcast (sums weighted by the batch-summed ignore mask), and DiceLoss (ignore < 0:
+ * ref: utils/losses.py:156-192).  sums[3*C] = {I, Z, Y} per class kept for the backward. */
+int wsl_pdice_fwd(const float* s, const void* target, int target_i64, int ignore, float* loss, float* sums, int N,
+                  int C, int HW, void* ws, size_t ws_bytes, void* stream);
+int wsl_pdice_bwd(const float* s, const void* target, int target_i64, int ignore, const float* sums,
+                  const float* gout /* device scalar or NULL (=1) */, float* ds, int N, int C, int HW, void* stream);
+
+/* Fused loss head of `ours_proposed` on logits (ref: ...pCE_ours_proposed.py:110-125):
+ *   s_k = softmax(z_k); ce = 0.5*(CE(z1,l)+CE(z2,l)); pseudo = argmax(beta*s1+(1-beta)*s2);
+ *   pse = 0.5*(pDice(s1,pseudo)+pDice(s2,pseudo)); loss = ce + w_pse*pse.
+ * out[0..3] = {loss, ce, pse, n_valid}.  dz1/dz2 = dloss/dz (times gscale).  pseudo may be NULL.
+ * z2 == NULL runs the single-branch pCE form (unet): loss = CE(z1, l). */
+int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int ignore, double beta, float w_pse,
+                     float gscale, float* out, int64_t* pseudo, float* dz1, float* dz2, int N, int C, int HW,
+                     void* ws, size_t ws_bytes, void* stream);
+size_t wsl_loss_ws_bytes(int N, int C, int HW);
+
+/* ModelLossSemsegGatedCRF.forward, one {'weight','xy','rgb'} descriptor, Potts model, no masks, prediction at input
+ * resolution (ref: utils/gate_crf_loss.py:20-124,135-188).  loss[0] = (sum K - sum y*msg)/(N*H*W);
+ * msg [N,C,H,W] is kept: dL/dy = -2*msg/(N*H*W) (wsl_gatedcrf_bwd scales it by gout). radius 1..8, C <= 8. */
+int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, float* loss, int N, int C, int H, int W, int radius,
+                     float sigma_xy, float sigma_rgb, float weight, void* ws, size_t ws_bytes, void* stream);
+int wsl_gatedcrf_bwd(const float* msg, const float* gout, float gscale, float* dy, int N, int C, int H, int W,
+                     void* stream);
+/* tv_loss(p) (ref: train_weakly_supervised_pCE_TV_2D.py:58-65) on p[n0:] (n0 = 1 reproduces outputs_soft[1:]). */
+int wsl_tv_fwd_bwd(const float* p, int n0, float* loss, float* dp, float gscale, int N, int C, int H, int W, void* ws,
+                   size_t ws_bytes, void* stream);
+/* MumfordShah_Loss().forward(image, prediction) (ref: utils/losses.py:275-309). */
+int wsl_mumford_shah_fwd_bwd(const float* img, const float* p, float* loss, float* dp, float gscale, int N, int C, int H,
+                             int W, void* ws, size_t ws_bytes, void* stream);
+/* mean((softmax(a)-softmax(b))^2) and its gradient wrt a (ref: utils/losses.py:65-82, train_mean_teacher_2D.py:164). */
+int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* loss, float* da, float gscale, int N, int C, int HW,
+                            void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ optimiser
+ * torch.optim.SGD(momentum, weight_decay) over a flat arena (ref: ...pCE_ours_proposed.py:89-90,126-132):
+ *   g = grad*grad_scale + wd*p; buf = first ? g : mu*buf + g; p -= lr*buf;
+ *   if (ema) ema = ema_alpha*ema + (1-ema_alpha)*p      (update_ema_variables, ref: ..._ustm_2D.py:61-65) */
+int wsl_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float wd, int first,
+                 float grad_scale, float* ema, float ema_alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ network
+ * UNet / UNet_CCT (ref: networks/unet.py:286-303, 327-346; factory: networks/net_factory.py:6-22) over a flat fp32
+ * parameter arena whose entry order is the reference module's parameters() order and whose names are its
+ * state_dict keys.  Buffers (running_mean/var) live in a second arena, num_batches_tracked in an int64 array. */
+typedef struct WslNetDesc {
+  int32_t in_chns, n_class;
+  int32_t n_dec;       /* 1 = 'unet', 2 = 'unet_cct' (main + aux decoder) */
+  int32_t N, H, W;     /* H, W multiples of 16 */
+} WslNetDesc;
+
+typedef struct WslNetEntry {
+  char name[96];       /* state_dict key */
+  int32_t kind;        /* 0 parameter (fp32, param arena), 1 buffer (fp32, buffer arena), 2 num_batches_tracked */
+  int32_t ndim;
+  int64_t shape[4];
+  int64_t offset;      /* element offset in its arena */
+} WslNetEntry;
+
+int wsl_net_num_entries(const WslNetDesc* d);
+int wsl_net_entry(const WslNetDesc* d, int i, WslNetEntry* out);
+int64_t wsl_net_param_count(const WslNetDesc* d);    /* 2,447,064 for unet_cct(1,4); 1,813,764 for unet(1,4) */
+int64_t wsl_net_encoder_param_count(const WslNetDesc* d);
+int64_t wsl_net_buffer_count(const WslNetDesc* d);
+size_t wsl_net_ws_bytes(const WslNetDesc* d);
+
+/* Forward.  emasks[5]: uint8 keep masks of the encoder's nn.Dropout sites ([N,C_l,H_l,W_l]; training only);
+ * cmasks[5]: [N,C_l] multipliers of the aux branch's F.dropout2d (required iff n_dec == 2 -- the reference applies
+ * it in eval mode too).  Writes logits [N,n_class,H,W] (aux may be NULL iff n_dec == 1); keeps what the backward
+ * needs inside `ws`. */
+int wsl_net_forward(const WslNetDesc* d, const float* params, float* buffers, int64_t* nbt, const float* x,
+                    const uint8_t* const* emasks, const float* const* cmasks, int training, float* logits_main,
+                    float* logits_aux, void* ws, size_t ws_bytes, void* stream);
+/* Backward of the last training forward held in `ws`.  grads: flat arena, same layout as params (overwritten).
+ * phase: 0 = everything, 1 = decoders only (their grads are final when it returns), 2 = encoder only (after 1) --
+ * the split lets the caller start the decoder bucket's all-reduce while the encoder backward runs. */
+int wsl_net_backward(const WslNetDesc* d, const float* params, const float* x, const uint8_t* const* emasks,
+                     const float* const* cmasks, const float* dlogits_main, const float* dlogits_aux, float* grads,
+                     void* ws, size_t ws_bytes, int phase, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSL_HIP_H */

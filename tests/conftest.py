@@ -40,3 +40,41 @@ def grad_tol(key, ref, tol=1e-4):
     ref = np.asarray(ref)
     bn_fed_bias = key.endswith(("conv_conv.0.bias", "conv_conv.4.bias"))
     return tol * float(np.max(np.abs(ref))) + (1e-5 if bn_fed_bias else 1e-7)
+
+
+# ---------------------------------------------------------------------------------------------- backends
+import subprocess
+
+
+def _emul_stale():
+    so = os.path.join(ROOT, "tests", "emul", "libwslhip_emul.so")
+    if not os.path.exists(so):
+        return True
+    t = os.path.getmtime(so)
+    srcs = [os.path.join(ROOT, "include", "wsl_hip.h"), os.path.join(ROOT, "tests", "emul", "hip_emul.h"),
+            os.path.join(ROOT, "tests", "emul", "hip_emul.cpp")]
+    cs = os.path.join(ROOT, "wsl4mis_amd", "csrc")
+    srcs += [os.path.join(cs, f) for f in os.listdir(cs) if f.endswith((".hip", ".h"))]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+_BACKENDS = {}
+
+
+def get_backend(name):
+    if name not in _BACKENDS:
+        import backends
+        if name == "emul":
+            if _emul_stale():
+                subprocess.run([os.path.join(ROOT, "wsl4mis_amd", "csrc", "build.sh"), "emul"], check=True,
+                               stdout=subprocess.DEVNULL)
+            _BACKENDS[name] = backends.EmulBackend()
+        else:
+            _BACKENDS[name] = backends.HipBackend()
+    return _BACKENDS[name]
+
+
+@pytest.fixture(params=[pytest.param("emul"), pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    """The C ABI behind either the host emulator (kernel-logic check, CPU) or the real library on cuda:0."""
+    return get_backend(request.param)

@@ -1,0 +1,126 @@
+"""Per-kernel parity of the conv stack through the C ABI: conv2d forward / data-gradient mode / weight gradient,
+BatchNorm statistics, with the loader transforms.  Checker: stock torch fp32 ops on the CPU (autograd for the
+gradients).  `be` runs every case on the host emulator (CPU) and, with -m gpu, on the MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+TOL = 1e-4
+
+
+def virt_input(x, scale, shift, emask, es, cmask):
+    v = torch.from_numpy(x)
+    if scale is not None:
+        v = F.leaky_relu(v * torch.from_numpy(scale)[None, :, None, None] + torch.from_numpy(shift)[None, :, None, None], 0.01)
+    if emask is not None:
+        v = v * torch.from_numpy(emask).float() * es
+    if cmask is not None:
+        v = v * torch.from_numpy(cmask)[:, :, None, None]
+    return v
+
+
+CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
+    (2, 9, 11, 5, 0, 7, 3, False),
+    (2, 16, 16, 3, 6, 20, 3, True),
+    (1, 8, 8, 12, 0, 6, 1, False),
+    (1, 12, 40, 4, 4, 16, 3, True),
+    (1, 10, 70, 2, 0, 33, 3, False),
+    (1, 20, 32, 9, 0, 40, 3, False),
+    (2, 16, 16, 17, 0, 48, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad_stats(be, case):
+    N, H, W, Ca, Cb, Co, ks, tr = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    xa = rng.standard_normal((N, Ca, H, W)).astype(np.float32)
+    xb = rng.standard_normal((N, Cb, H, W)).astype(np.float32) if Cb else None
+    Ci = Ca + Cb
+    w = (rng.standard_normal((Co, Ci, ks, ks)) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(Co).astype(np.float32)
+    scale = shift = emask = cmask = None
+    es = 1.0
+    if tr:
+        scale = (rng.standard_normal(Ca) * 0.5 + 1).astype(np.float32)
+        shift = (rng.standard_normal(Ca) * 0.3).astype(np.float32)
+        emask = (rng.random((N, Ca, H, W)) > 0.3).astype(np.uint8)
+        es = float(np.float32(1 / 0.7))
+        cmask = ((rng.random((N, Ca)) > 0.5) * 2.0).astype(np.float32)
+    # ---- checker
+    va = virt_input(xa, scale, shift, emask, es, cmask)
+    vin = (torch.cat([va, torch.from_numpy(xb)], 1) if Cb else va).requires_grad_()
+    wt = torch.from_numpy(w).requires_grad_()
+    bt = torch.from_numpy(bias).requires_grad_()
+    y_ref = F.conv2d(vin, wt, bt, padding=ks // 2)
+    r = torch.from_numpy(rng.standard_normal((N, Co, H, W)).astype(np.float32))
+    (y_ref * r).sum().backward()
+    # ---- device
+    d = {k: (be.arr(v) if v is not None else None) for k, v in
+         dict(xa=xa, xb=xb, w=w, bias=bias, scale=scale, shift=shift, emask=emask, cmask=cmask, r=r.numpy()).items()}
+    sa = be.src(d["xa"], Ca, scale=d["scale"], shift=d["shift"], emask=d["emask"], es=es, cmask=d["cmask"])
+    sb = be.src(d["xb"], Cb) if Cb else be.src()
+    y = be.zeros((N, Co, H, W))
+    nblk = be.lib.wsl_conv2d_stat_blocks(N, H, W, Ci, Co, ks)
+    part, cnt = be.zeros((nblk, Co, 2)), be.zeros((nblk,))
+    be.call("wsl_conv2d_fwd", sa, sb, be.ptr(d["w"]), be.ptr(d["bias"]), be.ptr(y), Co * H * W, N, H, W, Co, ks, 0,
+            be.ptr(part), be.ptr(cnt), be.stream)
+    assert rel_err(be.np(y), y_ref.detach().numpy()) < TOL
+    # BatchNorm statistics from the epilogue partials
+    gamma, beta = be.arr(np.linspace(0.5, 1.5, Co, dtype=np.float32)), be.arr(np.linspace(-0.2, 0.2, Co, dtype=np.float32))
+    rm, rv = be.arr(np.full(Co, 0.1, np.float32)), be.arr(np.full(Co, 0.9, np.float32))
+    nbt = be.arr(np.array([3], dtype=np.int64))
+    mean, invstd, sc, sh = (be.zeros((Co,)) for _ in range(4))
+    be.call("wsl_bn_stats_finalize", be.ptr(part), be.ptr(cnt), nblk, Co, be.ptr(gamma), be.ptr(beta), 1e-5, 0.1,
+            be.ptr(rm), be.ptr(rv), be.ptr(nbt), be.ptr(mean), be.ptr(invstd), be.ptr(sc), be.ptr(sh), be.stream)
+    yr = y_ref.detach()
+    m_ref, v_ref = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
+    n = N * H * W
+    assert rel_err(be.np(mean), m_ref.numpy()) < 1e-5
+    assert rel_err(be.np(invstd), (1 / torch.sqrt(v_ref + 1e-5)).numpy()) < 1e-5
+    assert rel_err(be.np(rm), (0.9 * 0.1 + 0.1 * m_ref).numpy()) < 1e-5
+    assert rel_err(be.np(rv), (0.9 * 0.9 + 0.1 * v_ref * n / (n - 1)).numpy()) < 1e-5
+    assert int(be.np(nbt)[0]) == 4
+    # ---- data-gradient mode: d(vin) = conv(r, W^T flipped)
+    dx = be.zeros((N, Ci, H, W))
+    sr = be.src(d["r"], Co)
+    be.call("wsl_conv2d_fwd", sr, be.src(), be.ptr(d["w"]), None, be.ptr(dx), Ci * H * W, N, H, W, Ci, ks, 1, None, None,
+            be.stream)
+    assert rel_err(be.np(dx), vin.grad.numpy()) < TOL
+    # ---- weight / bias gradient
+    nws = be.lib.wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks)
+    ws, dw, db = be.ws(nws), be.zeros((Co, Ci, ks, ks)), be.zeros((Co,))
+    be.call("wsl_conv2d_wgrad", sa, sb, be.ptr(d["r"]), Co * H * W, be.ptr(dw), be.ptr(db), N, H, W, Co, ks, be.ptr(ws),
+            nws, be.stream)
+    assert rel_err(be.np(dw), wt.grad.numpy()) < TOL
+    assert rel_err(be.np(db), bt.grad.numpy()) < TOL
+
+
+def test_conv_channel_slice_views(be):
+    """batch strides: read a channel slice of a wider tensor, write into a channel slice (no copies for cat/split)."""
+    rng = np.random.default_rng(3)
+    N, H, W = 2, 8, 16
+    big = rng.standard_normal((N, 10, H, W)).astype(np.float32)
+    w = (rng.standard_normal((6, 4, 3, 3)) * 0.2).astype(np.float32)
+    y_ref = F.conv2d(torch.from_numpy(big[:, 3:7]), torch.from_numpy(w), padding=1).numpy()
+    dbig, dw_ = be.arr(big), be.arr(w)
+    out = be.zeros((N, 9, H, W))
+    s = be.src(dbig, 4, bs=10 * H * W)
+    s.x = be.ptr(dbig) + 3 * H * W * 4
+    be.call("wsl_conv2d_fwd", s, be.src(), be.ptr(dw_), None, be.ptr(out) + 2 * H * W * 4, 9 * H * W, N, H, W, 6, 3, 0,
+            None, None, be.stream)
+    o = be.np(out)
+    assert rel_err(o[:, 2:8], y_ref) < TOL
+    assert np.all(o[:, :2] == 0) and np.all(o[:, 8:] == 0)
+
+
+def test_conv_argument_errors(be):
+    x = be.zeros((1, 1, 4, 4))
+    s = be.src(x, 1)
+    with pytest.raises(Exception, match="kernel size 5"):
+        be.call("wsl_conv2d_fwd", s, be.src(), be.ptr(x), None, be.ptr(x), 16, 1, 4, 4, 1, 5, 0, None, None, be.stream)
+    with pytest.raises(Exception, match="null"):
+        be.call("wsl_conv2d_fwd", s, be.src(), None, None, be.ptr(x), 16, 1, 4, 4, 1, 3, 0, None, None, be.stream)

@@ -1,0 +1,123 @@
+"""ctypes binding of libwslhip.so (include/wsl_hip.h).
+
+The product path has NO fallback: if the hipcc-built library is missing this module raises, and every op raises if
+the library reports an error.  (tests/emul builds the same sources for a host emulator; that library is loaded by the
+tests themselves through `bind()`, never by this loader.)"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwslhip.so")
+
+c_fp = C.c_void_p  # device pointers travel as integers
+
+
+class WslSrc(C.Structure):
+    _fields_ = [("x", c_fp), ("bs", C.c_int64), ("C", C.c_int32), ("_pad0", C.c_int32), ("scale", c_fp),
+                ("shift", c_fp), ("emask", c_fp), ("emask_scale", C.c_float), ("_pad1", C.c_float), ("cmask", c_fp)]
+
+
+class WslNetDesc(C.Structure):
+    _fields_ = [("in_chns", C.c_int32), ("n_class", C.c_int32), ("n_dec", C.c_int32), ("N", C.c_int32),
+                ("H", C.c_int32), ("W", C.c_int32)]
+
+
+class WslNetEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("kind", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("offset", C.c_int64)]
+
+
+i32, i64, f32, f64, sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+PS, PD, PE = C.POINTER(WslSrc), C.POINTER(WslNetDesc), C.POINTER(WslNetEntry)
+PP = C.POINTER(c_fp)
+
+_PROTOS = {
+    "wsl_version": (i32, []),
+    "wsl_last_error": (C.c_char_p, []),
+    "wsl_build_info": (C.c_char_p, []),
+    "wsl_conv2d_fwd": (i32, [PS, PS, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
+    "wsl_conv2d_stat_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
+    "wsl_conv2d_wgrad": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),
+    "wsl_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "wsl_bn_stats_finalize": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, f32, f32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                    c_fp, c_fp]),
+    "wsl_bn_eval_affine": (i32, [c_fp, c_fp, c_fp, c_fp, f32, i32, c_fp, c_fp, c_fp]),
+    "wsl_src_materialize": (i32, [PS, c_fp, i64, i32, i32, i32, c_fp]),
+    "wsl_pool2_fwd": (i32, [PS, c_fp, i32, i32, i32, c_fp]),
+    "wsl_feat_grad_combine": (i32, [PS, c_fp, i64, c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wsl_bnact_bwd": (i32, [c_fp, i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32,
+                            c_fp, sz, c_fp]),
+    "wsl_bnact_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),
+    "wsl_bilinear_up2_fwd": (i32, [c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),
+    "wsl_bilinear_up2_bwd": (i32, [c_fp, i64, c_fp, i32, i32, i32, i32, c_fp]),
+    "wsl_softmax_fwd": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wsl_softmax_bwd": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wsl_ce_fwd_bwd": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, f32, i32, i32, i32, c_fp, sz, c_fp]),
+    "wsl_mix_argmax": (i32, [c_fp, c_fp, f64, c_fp, i32, i32, i32, c_fp]),
+    "wsl_pdice_fwd": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, i32, i32, i32, c_fp, sz, c_fp]),
+    "wsl_pdice_bwd": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wsl_head_fwd_bwd": (i32, [c_fp, c_fp, c_fp, i32, f64, f32, f32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, sz,
+                               c_fp]),
+    "wsl_loss_ws_bytes": (sz, [i32, i32, i32]),
+    "wsl_gatedcrf_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, f32, f32, c_fp, sz, c_fp]),
+    "wsl_gatedcrf_bwd": (i32, [c_fp, c_fp, f32, c_fp, i32, i32, i32, i32, c_fp]),
+    "wsl_tv_fwd_bwd": (i32, [c_fp, i32, c_fp, c_fp, f32, i32, i32, i32, i32, c_fp, sz, c_fp]),
+    "wsl_mumford_shah_fwd_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, f32, i32, i32, i32, i32, c_fp, sz, c_fp]),
+    "wsl_softmax_mse_fwd_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, f32, i32, i32, i32, c_fp, sz, c_fp]),
+    "wsl_sgd_step": (i32, [c_fp, c_fp, c_fp, i64, f32, f32, f32, i32, f32, c_fp, f32, c_fp]),
+    "wsl_net_num_entries": (i32, [PD]),
+    "wsl_net_entry": (i32, [PD, i32, PE]),
+    "wsl_net_param_count": (i64, [PD]),
+    "wsl_net_encoder_param_count": (i64, [PD]),
+    "wsl_net_buffer_count": (i64, [PD]),
+    "wsl_net_ws_bytes": (sz, [PD]),
+    "wsl_net_forward": (i32, [PD, c_fp, c_fp, c_fp, c_fp, PP, PP, i32, c_fp, c_fp, c_fp, sz, c_fp]),
+    "wsl_net_backward": (i32, [PD, c_fp, c_fp, PP, PP, c_fp, c_fp, c_fp, c_fp, sz, i32, c_fp]),
+}
+
+
+class WslError(RuntimeError):
+    pass
+
+
+def bind(cdll, strict=True):
+    """Attach prototypes of include/wsl_hip.h to a loaded library; returns the list of missing symbols."""
+    missing = []
+    for name, (res, args) in _PROTOS.items():
+        try:
+            fn = getattr(cdll, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype, fn.argtypes = res, args
+    if missing and strict:
+        raise WslError(f"library lacks symbols declared in include/wsl_hip.h: {missing}")
+    return missing
+
+
+_lib = None
+
+
+def lib():
+    """The product library.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WslError(f"{LIB_PATH} not found: run wsl4mis_amd/csrc/build.sh (hipcc, gfx950). "
+                           "There is no CPU fallback.")
+        cdll = C.CDLL(LIB_PATH)
+        bind(cdll)
+        if b"HOST-EMULATION" in cdll.wsl_build_info():
+            raise WslError("refusing to use a host-emulation build as the product library")
+        _lib = cdll
+    return _lib
+
+
+def check(rc, cdll=None):
+    if rc != 0:
+        l = cdll or lib()
+        raise WslError(f"wsl error {rc}: {l.wsl_last_error().decode()}")
+
+
+def declared_symbols():
+    return list(_PROTOS)

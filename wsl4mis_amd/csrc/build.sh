@@ -1,0 +1,47 @@
+#!/usr/bin/env bash
+# Builds libwslhip.so (the product: hand-written HIP for gfx950) in-tree next to the sources.
+#   ./build.sh          product library only
+#   ./build.sh emul     ALSO the test-only host emulation build (tests/emul/libwslhip_emul.so)
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+root="$(cd "$here/../.." && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+srcs=(wsl_api wsl_conv wsl_bn wsl_loss wsl_optim wsl_net)
+mkdir -p "$here/build"
+objs=()
+pids=()
+for s in "${srcs[@]}"; do
+  [ -f "$here/$s.hip" ] || continue
+  o="$here/build/$s.o"
+  objs+=("$o")
+  if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "$here/$s.hip" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$here/libwslhip.so"
+echo "built $here/libwslhip.so"
+
+if [ "${1:-}" = "emul" ]; then
+  CXX="${EMUL_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
+  em="$root/tests/emul"
+  mkdir -p "$em/build"
+  eobjs=()
+  pids=()
+  for s in "${srcs[@]}"; do
+    [ -f "$here/$s.hip" ] || continue
+    o="$em/build/$s.o"
+    eobjs+=("$o")
+    if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$em/hip_emul.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
+      "$CXX" -x c++ -std=c++17 -O2 -g -fPIC -ffp-contract=off -DWSL_HOST_EMUL -I"$em" -Wall -Wno-unused-function \
+        -Wno-unknown-pragmas -Wno-pass-failed -c "$here/$s.hip" -o "$o" &
+      pids+=($!)
+    fi
+  done
+  "$CXX" -std=c++17 -O2 -g -fPIC -c "$em/hip_emul.cpp" -o "$em/build/hip_emul.o" &
+  pids+=($!)
+  for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+  "$CXX" -shared -fPIC "${eobjs[@]}" "$em/build/hip_emul.o" -o "$em/libwslhip_emul.so"
+  echo "built $em/libwslhip_emul.so"
+fi

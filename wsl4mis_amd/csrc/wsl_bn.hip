@@ -1,0 +1,373 @@
+// BatchNorm statistics / backward, 2x2 max-pool, bilinear x2 and the gradient fan-in of an encoder feature map
+// (ref: networks/unet.py:20-25 BatchNorm2d+LeakyReLU+Dropout, :38 MaxPool2d(2), :56-57 Upsample, :63-68 cat).
+// All of these are HBM-bound scans; reductions are two-stage with a fixed merge order (no atomics).
+#include "wsl_rt.h"
+
+namespace wsl {
+
+constexpr int kChunk = 4096;  // elements of one (n, c) plane handled by one workgroup
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// ------------------------------------------------------------------------------------------------ BN forward stats
+// One workgroup per channel: Chan-merge the conv epilogue's per-block (sum, M2, count) partials in fp64.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, const float* cnt, int nblk, int C,
+                                                          const float* gamma, const float* beta, float eps,
+                                                          float momentum, float* rmean, float* rvar, int64_t* nbt,
+                                                          float* mean_o, float* invstd_o, float* scale_o,
+                                                          float* shift_o) {
+  __shared__ double red[kThreads];
+  const int c = blockIdx.x;
+  double n = 0, s = 0;
+  for (int b = threadIdx.x; b < nblk; b += kThreads) {
+    n += cnt[b];
+    s += part[((int64_t)b * C + c) * 2];
+  }
+  n = block_sum_d(n, red);
+  s = block_sum_d(s, red);
+  const double mean = s / n;
+  double m2 = 0;
+  for (int b = threadIdx.x; b < nblk; b += kThreads) {
+    const double nb = cnt[b];
+    if (nb > 0) {
+      const double d = part[((int64_t)b * C + c) * 2] / nb - mean;
+      m2 += part[((int64_t)b * C + c) * 2 + 1] + nb * d * d;
+    }
+  }
+  m2 = block_sum_d(m2, red);
+  if (threadIdx.x == 0) {
+    const double var = m2 / n;  // biased (normalisation)
+    const float meanf = (float)mean;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_o[c] = meanf;
+    invstd_o[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale_o[c] = sc;
+    shift_o[c] = fmaf(-meanf, sc, beta[c]);
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * meanf;
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(n > 1 ? m2 / (n - 1) : var);
+    if (nbt && c == 0) nbt[0] += 1;
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float invstd = 1.f / sqrtf(rvar[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = fmaf(-rmean[c], sc, beta[c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ materialise / pool
+__global__ __launch_bounds__(256) void src_materialize_kernel(WslSrc s, float* out, int64_t out_bs, int HW) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int base = blockIdx.x * kChunk;
+  for (int i = base + threadIdx.x; i < base + kChunk && i < HW; i += kThreads)
+    out[n * out_bs + (int64_t)c * HW + i] = src_value(s, n, c, n * s.bs + (int64_t)c * HW + i, ((int64_t)n * s.C + c) * HW + i);
+}
+
+__global__ __launch_bounds__(256) void pool2_fwd_kernel(WslSrc s, float* out, int H, int W) {
+  const int c = blockIdx.y, n = blockIdx.z, Ho = H / 2, Wo = W / 2;
+  const int64_t HW = (int64_t)H * W;
+  const int base = blockIdx.x * kChunk;
+  for (int o = base + threadIdx.x; o < base + kChunk && o < Ho * Wo; o += kThreads) {
+    const int oy = o / Wo, ox = o - oy * Wo;
+    float best = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t off = (int64_t)(2 * oy + (k >> 1)) * W + 2 * ox + (k & 1);
+      const float v = src_value(s, n, c, n * s.bs + c * HW + off, ((int64_t)n * s.C + c) * HW + off);
+      if (k == 0 || v > best) best = v;
+    }
+    out[((int64_t)n * s.C + c) * Ho * Wo + o] = best;
+  }
+}
+
+// One thread per 2x2 cell of the full-resolution map (cells on an odd border are partial and carry no pool term).
+__global__ __launch_bounds__(256) void feat_grad_combine_kernel(WslSrc f, const float* ga, int64_t ga_bs,
+                                                                const float* gb, int64_t gb_bs, const float* gb_cmask,
+                                                                const float* gp, float* g, int H, int W) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
+  const int64_t HW = (int64_t)H * W;
+  const float cm = gb_cmask ? gb_cmask[(int64_t)n * f.C + c] : 1.f;
+  const int base = blockIdx.x * kChunk;
+  for (int o = base + threadIdx.x; o < base + kChunk && o < Hc * Wc; o += kThreads) {
+    const int cy = o / Wc, cx = o - cy * Wc;
+    int arg = -1;
+    float gpool = 0.f;
+    if (gp && cy < Ho && cx < Wo) {
+      float best = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t off = (int64_t)(2 * cy + (k >> 1)) * W + 2 * cx + (k & 1);
+        const float v = src_value(f, n, c, n * f.bs + c * HW + off, ((int64_t)n * f.C + c) * HW + off);
+        if (k == 0 || v > best) best = v, arg = k;
+      }
+      gpool = gp[((int64_t)n * f.C + c) * Ho * Wo + (int64_t)cy * Wo + cx];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 2 * cy + (k >> 1), x = 2 * cx + (k & 1);
+      if (y < H && x < W) {
+        const int64_t off = (int64_t)y * W + x;
+        float v = 0.f;
+        if (ga) v = ga[n * ga_bs + c * HW + off];
+        if (gb) v = fmaf(gb[n * gb_bs + c * HW + off], cm, v);
+        if (k == arg) v += gpool;
+        g[((int64_t)n * f.C + c) * HW + off] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BN + act backward
+struct BnBwdP {
+  const float* g;
+  int64_t g_bs;
+  const float* y;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  const uint8_t* emask;
+  float es;
+  int C, HW, chunks;
+};
+
+__device__ __forceinline__ float bn_dz(const BnBwdP& p, int n, int c, int i, float sc, float sh, float mean, float invstd,
+                                       float* xhat) {
+  const int64_t idx = ((int64_t)n * p.C + c) * p.HW + i;
+  const float yv = p.y[idx];
+  float d = p.g[n * p.g_bs + (int64_t)c * p.HW + i];
+  if (p.emask) d = p.emask[idx] ? d * p.es : 0.f;
+  const float z = fmaf(yv, sc, sh);           // same expression as the forward loader: identical sign decisions
+  *xhat = (yv - mean) * invstd;
+  return z > 0.f ? d : WSL_LEAKY_SLOPE * d;
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(BnBwdP p, float* part) {
+  __shared__ float red[8];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float mean = p.mean[c], invstd = p.invstd[c];
+  const float sc = p.gamma[c] * invstd, sh = fmaf(-mean, sc, p.beta[c]);
+  float s1 = 0.f, s2 = 0.f;
+  const int base = blockIdx.x * kChunk;
+  for (int i = base + threadIdx.x; i < base + kChunk && i < p.HW; i += kThreads) {
+    float xh;
+    const float d = bn_dz(p, n, c, i, sc, sh, mean, invstd, &xh);
+    s1 += d;
+    s2 = fmaf(d, xh, s2);
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red + 4);
+  if (threadIdx.x == 0) {
+    float* dst = part + (((int64_t)n * p.chunks + blockIdx.x) * p.C + c) * 2;
+    dst[0] = s1;
+    dst[1] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_finalize_kernel(const float* part, int nblk, int C, double count,
+                                                                 float* dgamma, float* dbeta, float* coef) {
+  __shared__ double red[kThreads];
+  const int c = blockIdx.x;
+  double s1 = 0, s2 = 0;
+  for (int b = threadIdx.x; b < nblk; b += kThreads) {
+    s1 += part[((int64_t)b * C + c) * 2];
+    s2 += part[((int64_t)b * C + c) * 2 + 1];
+  }
+  s1 = block_sum_d(s1, red);
+  s2 = block_sum_d(s2, red);
+  if (threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    coef[2 * c] = (float)(s1 / count);
+    coef[2 * c + 1] = (float)(s2 / count);
+  }
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(BnBwdP p, const float* coef, float* dy) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float mean = p.mean[c], invstd = p.invstd[c];
+  const float sc = p.gamma[c] * invstd, sh = fmaf(-mean, sc, p.beta[c]);
+  const float c1 = coef[2 * c], c2 = coef[2 * c + 1];
+  const int base = blockIdx.x * kChunk;
+  for (int i = base + threadIdx.x; i < base + kChunk && i < p.HW; i += kThreads) {
+    float xh;
+    const float d = bn_dz(p, n, c, i, sc, sh, mean, invstd, &xh);
+    dy[((int64_t)n * p.C + c) * p.HW + i] = sc * (d - c1 - xh * c2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear x2
+// src = dst * (in-1)/(out-1) (align_corners=True), i0 = floor, i1 = min(i0+1, in-1), lambda = src - i0.
+__device__ __forceinline__ void lerp_coord(int dst, float scale, int in, int* i0, int* i1, float* l) {
+  const float src = scale * (float)dst;
+  int a = (int)src;
+  if (a > in - 1) a = in - 1;
+  *i0 = a;
+  *i1 = a + (a < in - 1 ? 1 : 0);
+  *l = src - (float)a;
+}
+
+__global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const float* u, float* out, int64_t out_bs, int C, int h,
+                                                               int w) {
+  const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
+  const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+  const float* src = u + ((int64_t)n * C + c) * h * w;
+  const int base = blockIdx.x * kChunk;
+  for (int o = base + threadIdx.x; o < base + kChunk && o < Ho * Wo; o += kThreads) {
+    const int oy = o / Wo, ox = o - oy * Wo;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    lerp_coord(oy, sy, h, &y0, &y1, &ly);
+    lerp_coord(ox, sx, w, &x0, &x1, &lx);
+    const float top = (1.f - lx) * src[y0 * w + x0] + lx * src[y0 * w + x1];
+    const float bot = (1.f - lx) * src[y1 * w + x0] + lx * src[y1 * w + x1];
+    out[n * out_bs + (int64_t)c * Ho * Wo + o] = (1.f - ly) * top + ly * bot;
+  }
+}
+
+// Transposed gather: input pixel (i, j) collects from the <= 5x5 output pixels whose stencil touches it.
+__global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const float* dout, int64_t dout_bs, float* du, int C,
+                                                               int h, int w) {
+  const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
+  const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+  const float* g = dout + n * dout_bs + (int64_t)c * Ho * Wo;
+  const int base = blockIdx.x * kChunk;
+  for (int e = base + threadIdx.x; e < base + kChunk && e < h * w; e += kThreads) {
+    const int i = e / w, j = e - i * w;
+    float wy[5], wx[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int Y = 2 * i - 2 + k, X = 2 * j - 2 + k;
+      wy[k] = 0.f, wx[k] = 0.f;
+      if (Y >= 0 && Y < Ho) {
+        int a, b;
+        float l;
+        lerp_coord(Y, sy, h, &a, &b, &l);
+        wy[k] = (a == i ? 1.f - l : 0.f) + (b == i ? l : 0.f);
+      }
+      if (X >= 0 && X < Wo) {
+        int a, b;
+        float l;
+        lerp_coord(X, sx, w, &a, &b, &l);
+        wx[k] = (a == j ? 1.f - l : 0.f) + (b == j ? l : 0.f);
+      }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      if (wy[ky] != 0.f) {
+        const int Y = 2 * i - 2 + ky;
+        float row = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx)
+          if (wx[kx] != 0.f) row = fmaf(wx[kx], g[(int64_t)Y * Wo + 2 * j - 2 + kx], row);
+        acc = fmaf(wy[ky], row, acc);
+      }
+    }
+    du[((int64_t)n * C + c) * h * w + e] = acc;
+  }
+}
+
+}  // namespace wsl
+
+using namespace wsl;
+
+extern "C" int wsl_bn_stats_finalize(const float* stat_part, const float* stat_cnt, int nblk, int C, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* running_mean,
+                                     float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
+                                     float* shift, void* stream) {
+  WSL_REQUIRE(stat_part && stat_cnt && gamma && beta && mean && invstd && scale && shift, "bn_stats_finalize: null");
+  WSL_REQUIRE(nblk > 0 && C > 0, "bn_stats_finalize: bad sizes");
+  WSL_LAUNCH(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, stat_part, stat_cnt, nblk, C, gamma, beta, eps,
+             momentum, running_mean, running_var, nbt, mean, invstd, scale, shift);
+  return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int wsl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
+  WSL_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_eval_affine: bad args");
+  WSL_LAUNCH(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, running_mean, running_var,
+             eps, C, scale, shift);
+  return check_launch("bn_eval_affine_kernel");
+}
+
+extern "C" int wsl_src_materialize(const WslSrc* s, float* out, int64_t out_bs, int N, int H, int W, void* stream) {
+  WSL_REQUIRE(s && s->x && out && N > 0 && H > 0 && W > 0 && s->C > 0, "src_materialize: bad args");
+  WSL_LAUNCH(src_materialize_kernel, dim3(cdiv(H * W, kChunk), s->C, N), dim3(kThreads), 0, stream, *s, out, out_bs,
+             H * W);
+  return check_launch("src_materialize_kernel");
+}
+
+extern "C" int wsl_pool2_fwd(const WslSrc* s, float* out, int N, int H, int W, void* stream) {
+  WSL_REQUIRE(s && s->x && out && N > 0 && H > 1 && W > 1 && s->C > 0, "pool2_fwd: bad args");
+  WSL_LAUNCH(pool2_fwd_kernel, dim3(cdiv((H / 2) * (W / 2), kChunk), s->C, N), dim3(kThreads), 0, stream, *s, out, H, W);
+  return check_launch("pool2_fwd_kernel");
+}
+
+extern "C" int wsl_feat_grad_combine(const WslSrc* f, const float* ga, int64_t ga_bs, const float* gb, int64_t gb_bs,
+                                     const float* gb_cmask, const float* gp, float* g, int N, int H, int W, void* stream) {
+  WSL_REQUIRE(f && g && N > 0 && H > 0 && W > 0 && f->C > 0, "feat_grad_combine: bad args");
+  WSL_REQUIRE(!gp || f->x, "feat_grad_combine: pool routing needs the feature map");
+  WSL_LAUNCH(feat_grad_combine_kernel, dim3(cdiv(((H + 1) / 2) * ((W + 1) / 2), kChunk), f->C, N), dim3(kThreads), 0,
+             stream, *f, ga, ga_bs, gb, gb_bs, gb_cmask, gp, g, H, W);
+  return check_launch("feat_grad_combine_kernel");
+}
+
+extern "C" size_t wsl_bnact_bwd_ws_bytes(int N, int C, int H, int W) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return sizeof(float) * ((size_t)N * cdiv(H * W, kChunk) * C * 2 + 2 * (size_t)C);
+}
+
+extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                             float* dgamma, float* dbeta, int N, int C, int H, int W, void* ws, size_t ws_bytes,
+                             void* stream) {
+  WSL_REQUIRE(g && y && mean && invstd && gamma && beta && dy && ws, "bnact_bwd: null argument");
+  WSL_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "bnact_bwd: bad shape");
+  if (ws_bytes < wsl_bnact_bwd_ws_bytes(N, C, H, W)) {
+    set_error("bnact_bwd: workspace %zu < %zu", ws_bytes, wsl_bnact_bwd_ws_bytes(N, C, H, W));
+    return WSL_EWORKSPACE;
+  }
+  BnBwdP p{g, g_bs, y, mean, invstd, gamma, beta, emask, emask_scale, C, H * W, cdiv(H * W, kChunk)};
+  float* part = static_cast<float*>(ws);
+  float* coef = part + (size_t)N * p.chunks * C * 2;
+  dim3 grid(p.chunks, C, N);
+  WSL_LAUNCH(bnact_bwd_reduce_kernel, grid, dim3(kThreads), 0, stream, p, part);
+  WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, N * p.chunks, C,
+             (double)N * H * W, dgamma, dbeta, coef);
+  WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
+  return check_launch("bnact_bwd");
+}
+
+extern "C" int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream) {
+  WSL_REQUIRE(u && out && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_fwd: bad args");
+  WSL_REQUIRE(out_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_fwd: out batch stride too small");
+  WSL_LAUNCH(bilinear_up2_fwd_kernel, dim3(cdiv(4 * h * w, kChunk), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C,
+             h, w);
+  return check_launch("bilinear_up2_fwd_kernel");
+}
+
+extern "C" int wsl_bilinear_up2_bwd(const float* dout, int64_t dout_bs, float* du, int N, int C, int h, int w,
+                                    void* stream) {
+  WSL_REQUIRE(dout && du && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_bwd: bad args");
+  WSL_REQUIRE(dout_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_bwd: dout batch stride too small");
+  WSL_LAUNCH(bilinear_up2_bwd_kernel, dim3(cdiv(h * w, kChunk), C, N), dim3(kThreads), 0, stream, dout, dout_bs, du, C,
+             h, w);
+  return check_launch("bilinear_up2_bwd_kernel");
+}

@@ -1,0 +1,575 @@
+// Convolution stack of the UNet (ref: networks/unet.py:19,23 Conv2d 3x3 p1; :55 Conv2d 1x1; :120 out_conv) as
+// fp32-MFMA implicit GEMMs for gfx950.
+//
+//   forward / data-gradient:  M = 16 consecutive pixels of a row, N = 16 output channels, K = 4 input channels of
+//       one filter tap per v_mfma_f32_16x16x4_f32.  A workgroup (4 waves) owns a TH x TW pixel tile x CO_T output
+//       channels; the input tile (with halo) of KC channels and the matching weights are staged through LDS, the
+//       producer's BatchNorm-apply + LeakyReLU + dropout being applied while staging (nothing normalised is ever
+//       written to HBM).  LDS planes are padded to 16 (mod 32) words so the four k-groups of an A-operand read hit
+//       disjoint banks.  The epilogue adds the bias, stores float4 rows and emits per-block (sum, M2) per channel
+//       for the following BatchNorm (Chan merge in wsl_bn.hip) -- no atomics.
+//   weight-gradient:  M = 16 output channels, N = 16 input channels, K = 4 pixels; nine accumulators (one per
+//       tap) per 16x16 channel pair; split over pixels into partials, second stage order-fixed.
+//       db comes from one extra MFMA against a ones operand.
+#include "wsl_rt.h"
+
+namespace wsl {
+
+// ------------------------------------------------------------------------------------------------ staging
+struct TileSrc {
+  WslSrc a, b;
+  int H, W, Ci;
+};
+
+// value of virtual-input channel `c` (over cat(a,b)) at (n, gy, gx); zero outside the image / channel range.
+__device__ __forceinline__ float tile_value(const TileSrc& t, int n, int c, int gy, int gx) {
+  if (c >= t.Ci || gy < 0 || gy >= t.H || gx < 0 || gx >= t.W) return 0.f;
+  const int64_t hw = (int64_t)t.H * t.W;
+  const int64_t off = (int64_t)gy * t.W + gx;
+  if (c < t.a.C) return src_value(t.a, n, c, n * t.a.bs + c * hw + off, ((int64_t)n * t.a.C + c) * hw + off);
+  c -= t.a.C;
+  return src_value(t.b, n, c, n * t.b.bs + c * hw + off, ((int64_t)n * t.b.C + c) * hw + off);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct ConvP {
+  TileSrc in;
+  const float* w;
+  const float* bias;
+  float* y;
+  int64_t y_bs;
+  int N, Co, wmode, tiles_x, tiles_y, vec_ok;
+  float* stat_part;
+  float* stat_cnt;
+};
+
+template <int KS, int TH, int TW, int CO_T, int KC>
+struct ConvCfg {
+  static constexpr int P = KS / 2, KK = KS * KS;
+  static constexpr int ROWP = TW + 2 * P, ROWS = TH + 2 * P, TILE = ROWS * ROWP;
+  static constexpr int PLANE = ((TILE - 16 + 31) / 32) * 32 + 16;  // >= TILE, == 16 (mod 32)
+  static constexpr int CSTR = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;  // == 16 (mod 32)
+  static constexpr int SEGS = TW / 16, MT_TOTAL = TH * SEGS, MT = MT_TOTAL / 4, NT = CO_T / 16;
+  static constexpr int IN_FLOATS = KC * PLANE, W_FLOATS = KK * KC * CSTR;
+  static constexpr int RED_FLOATS = 8 * CO_T;
+  static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + W_FLOATS > RED_FLOATS ? IN_FLOATS + W_FLOATS : RED_FLOATS);
+  static_assert(MT_TOTAL % 4 == 0 && TW % 16 == 0 && CO_T % 16 == 0 && KC % 4 == 0, "tile shape");
+};
+
+template <int KS, int TH, int TW, int CO_T, int KC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
+  using C = ConvCfg<KS, TH, TW, CO_T, KC>;
+  WSL_DYN_SMEM(smem);
+  float* in_t = reinterpret_cast<float*>(smem);
+  float* w_t = in_t + C::IN_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = blockIdx.y * CO_T;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = p.in.H, W = p.in.W, Ci = p.in.Ci;
+
+  v4f acc[C::MT][C::NT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  int abase[C::MT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i) {
+    const int mt = wave * C::MT + i;
+    abase[i] = (lane >> 4) * C::PLANE + (mt / C::SEGS) * C::ROWP + (mt % C::SEGS) * 16 + (lane & 15);
+  }
+  const int bbase = (lane >> 4) * C::CSTR + (lane & 15);
+
+  for (int c0 = 0; c0 < Ci; c0 += KC) {
+    // ---- stage the input tile (+halo) of channels [c0, c0+KC), transformed, zero padded
+    for (int e = tid; e < KC * C::TILE; e += kThreads) {
+      const int c = e / C::TILE, rem = e - c * C::TILE;
+      const int ty = rem / C::ROWP, tx = rem - ty * C::ROWP;
+      in_t[c * C::PLANE + rem] = tile_value(p.in, n, c0 + c, y0 + ty - C::P, x0 + tx - C::P);
+    }
+    // ---- stage the weights of this channel chunk as w_t[tap][c][co]
+    for (int e = tid; e < CO_T * KC * C::KK; e += kThreads) {
+      const int co = e / (KC * C::KK), rem = e - co * (KC * C::KK);
+      const int c = rem / C::KK, tap = rem - c * C::KK;
+      const int cog = co0 + co, cg = c0 + c;
+      float v = 0.f;
+      if (cog < p.Co && cg < Ci)
+        v = p.wmode == 0 ? p.w[((int64_t)cog * Ci + cg) * C::KK + tap]
+                         : p.w[((int64_t)cg * p.Co + cog) * C::KK + (C::KK - 1 - tap)];
+      w_t[(tap * KC + c) * C::CSTR + co] = v;
+    }
+    __syncthreads();
+    const int ngroups = (Ci - c0 >= KC) ? KC / 4 : (Ci - c0 + 3) / 4;
+#pragma unroll
+    for (int tap = 0; tap < C::KK; ++tap) {
+      const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+      for (int cg = 0; cg < KC / 4; ++cg) {
+        if (cg < ngroups) {
+          float bv[C::NT];
+#pragma unroll
+          for (int j = 0; j < C::NT; ++j) bv[j] = w_t[(tap * KC + cg * 4) * C::CSTR + j * 16 + bbase];
+#pragma unroll
+          for (int i = 0; i < C::MT; ++i) {
+            const float av = in_t[cg * 4 * C::PLANE + ky * C::ROWP + kx + abase[i]];
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) acc[i][j] = WSL_MFMA16(av, bv[j], acc[i][j]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, store, BatchNorm partial statistics
+  const int64_t HW = (int64_t)H * W;
+  float bsum[C::NT];
+#pragma unroll
+  for (int j = 0; j < C::NT; ++j) {
+    const int co = co0 + j * 16 + (lane & 15);
+    const float bias = (p.bias && co < p.Co) ? p.bias[co] : 0.f;
+    bsum[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i) {
+      const int mt = wave * C::MT + i;
+      const int gy = y0 + mt / C::SEGS, gx = x0 + (mt % C::SEGS) * 16 + (lane >> 4) * 4;
+      v4f v = acc[i][j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += bias;
+      acc[i][j] = v;
+      if (co < p.Co && gy < H) {
+        float* dst = p.y + n * p.y_bs + co * HW + (int64_t)gy * W + gx;
+        if (p.vec_ok && gx + 3 < W) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (gx + r < W) dst[r] = v[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (gx + r < W) bsum[j] += v[r];
+      }
+    }
+  }
+  if (p.stat_part) {  // uniform branch
+    float* red1 = in_t;
+    float* red2 = in_t + 4 * CO_T;
+    const int vh = (H - y0 < TH) ? H - y0 : TH, vw = (W - x0 < TW) ? W - x0 : TW;
+    const float cnt = (float)(vh * vw);
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+    }
+    __syncthreads();
+    float m2[C::NT];
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int col = j * 16 + (lane & 15);
+      const int co = co0 + col;
+      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i) {
+        const int mt = wave * C::MT + i;
+        const int gy = y0 + mt / C::SEGS, gx = x0 + (mt % C::SEGS) * 16 + (lane >> 4) * 4;
+        if (co < p.Co && gy < H) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (gx + r < W) {
+              const float d = acc[i][j][r] - mean_b;
+              q = fmaf(d, d, q);
+            }
+        }
+      }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      m2[j] = q;
+      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) {
+        const int col = j * 16 + lane, co = co0 + col;
+        if (co < p.Co) {
+          float* dst = p.stat_part + ((int64_t)blockIdx.x * p.Co + co) * 2;
+          dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+          dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+        }
+      }
+      if (lane == 0 && blockIdx.y == 0) p.stat_cnt[blockIdx.x] = cnt;
+    }
+    (void)m2;
+  }
+}
+
+struct FwdPlan {
+  int th, tw, co_t;
+};
+static FwdPlan fwd_plan(int W, int Co) {
+  FwdPlan f;
+  if (W >= 64) {
+    f.th = 8, f.tw = 64, f.co_t = Co <= 16 ? 16 : 32;
+  } else if (W >= 32) {
+    f.th = 8, f.tw = 32, f.co_t = Co <= 16 ? 16 : (Co <= 32 ? 32 : 64);
+  } else {
+    f.th = 16, f.tw = 16, f.co_t = Co <= 16 ? 16 : (Co <= 32 ? 32 : 64);
+  }
+  return f;
+}
+
+template <int KS, int TH, int TW, int CO_T>
+static int launch_conv(ConvP& p, void* stream) {
+  using C = ConvCfg<KS, TH, TW, CO_T, 8>;
+  auto kern = conv_mfma_kernel<KS, TH, TW, CO_T, 8>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Co, CO_T));
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  return check_launch("conv_mfma_kernel");
+}
+
+template <int KS>
+static int dispatch_conv(ConvP& p, const FwdPlan& f, void* stream) {
+#define WSL_CASE(TH_, TW_, CO_) \
+  if (f.th == TH_ && f.tw == TW_ && f.co_t == CO_) return launch_conv<KS, TH_, TW_, CO_>(p, stream);
+  WSL_CASE(8, 64, 16)
+  WSL_CASE(8, 64, 32)
+  WSL_CASE(8, 32, 16)
+  WSL_CASE(8, 32, 32)
+  WSL_CASE(8, 32, 64)
+  WSL_CASE(16, 16, 16)
+  WSL_CASE(16, 16, 32)
+  WSL_CASE(16, 16, 64)
+#undef WSL_CASE
+  set_error("conv: no kernel for tile %dx%d co_t %d", f.th, f.tw, f.co_t);
+  return WSL_EUNSUPPORTED;
+}
+
+static int check_src(const WslSrc* s, int HW, const char* who) {
+  WSL_REQUIRE(s->x != nullptr && s->C > 0, "%s: source has no data", who);
+  WSL_REQUIRE(s->bs >= (int64_t)s->C * HW, "%s: batch stride %lld < C*H*W", who, (long long)s->bs);
+  WSL_REQUIRE((s->scale == nullptr) == (s->shift == nullptr), "%s: scale and shift must come together", who);
+  return WSL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct WgradP {
+  TileSrc in;
+  const float* dy;
+  int64_t dy_bs;
+  float* part_dw;  // [nsplit][KK][Co][Ci]
+  float* part_db;  // [nsplit][Co]
+  int N, Co, tiles_x, tiles_y, items, nsplit, co_blocks;
+};
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+struct WgradCfg {
+  static constexpr int P = KS / 2, KK = KS * KS;
+  static constexpr int ROWP = TW + 2 * P, ROWS = TH + 2 * P, S = TH * TW;
+  static constexpr int PLD = ((S - 2 + 31) / 32) * 32 + 2;             // == 2 (mod 32)
+  static constexpr int PLA = ((ROWS * ROWP - 2 + 31) / 32) * 32 + 2;   // == 2 (mod 32)
+  static constexpr int CBT = CB / 16, IBT = IB / 16, PAIRS = CBT * IBT, WP = 4 / WK, PP = PAIRS / WP;
+  static constexpr int DY_FLOATS = CB * PLD, A_FLOATS = IB * PLA;
+  static constexpr int RED_FLOATS = (WK > 1) ? 4 * 64 * (PP * (KK + 1) * 4) : 0;
+  static constexpr size_t SMEM =
+      sizeof(float) * (DY_FLOATS + A_FLOATS > RED_FLOATS ? DY_FLOATS + A_FLOATS : RED_FLOATS);
+  static_assert(PAIRS % WP == 0 && TH % WK == 0 && TW % 4 == 0, "wgrad tile shape");
+};
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p) {
+  using C = WgradCfg<KS, TH, TW, CB, IB, WK>;
+  WSL_DYN_SMEM(smem);
+  float* dy_t = reinterpret_cast<float*>(smem);
+  float* a_t = dy_t + C::DY_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = blockIdx.x % p.co_blocks, ib = blockIdx.x / p.co_blocks, split = blockIdx.y;
+  const int co0 = cb * CB, ci0 = ib * IB;
+  const int wp = wave % C::WP, wk = wave / C::WP;
+  const int H = p.in.H, W = p.in.W, Ci = p.in.Ci;
+  const int64_t HW = (int64_t)H * W;
+
+  v4f acc[C::PP][C::KK];
+  v4f accb[C::PP];
+#pragma unroll
+  for (int j = 0; j < C::PP; ++j) {
+    accb[j] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C::KK; ++t) acc[j][t] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_db = (ib == 0) && (p.part_db != nullptr);
+  const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
+  for (int item = it0; item < it1; ++item) {
+    int q = item;
+    const int tx_i = q % p.tiles_x;
+    q /= p.tiles_x;
+    const int ty_i = q % p.tiles_y;
+    const int n = q / p.tiles_y;
+    const int y0 = ty_i * TH, x0 = tx_i * TW;
+    // ---- stage dy tile [CB][S] (zero outside image / channel range)
+    for (int e = tid; e < CB * C::S; e += kThreads) {
+      const int c = e / C::S, rem = e - c * C::S;
+      const int ty = rem / TW, tx = rem - ty * TW;
+      const int gy = y0 + ty, gx = x0 + tx, co = co0 + c;
+      float v = 0.f;
+      if (co < p.Co && gy < H && gx < W) v = p.dy[n * p.dy_bs + co * HW + (int64_t)gy * W + gx];
+      dy_t[c * C::PLD + rem] = v;
+    }
+    // ---- stage input tile [IB][ROWS*ROWP] with halo, transformed
+    for (int e = tid; e < IB * C::ROWS * C::ROWP; e += kThreads) {
+      const int c = e / (C::ROWS * C::ROWP), rem = e - c * (C::ROWS * C::ROWP);
+      const int ty = rem / C::ROWP, tx = rem - ty * C::ROWP;
+      a_t[c * C::PLA + rem] = tile_value(p.in, n, ci0 + c, y0 + ty - C::P, x0 + tx - C::P);
+    }
+    __syncthreads();
+    constexpr int RW = TH / WK;
+#pragma unroll 1
+    for (int r = wk * RW; r < wk * RW + RW; ++r) {
+#pragma unroll 2
+      for (int x4 = 0; x4 < TW / 4; ++x4) {
+        const int pix = r * TW + x4 * 4 + (lane >> 4);
+        const int apix = r * C::ROWP + x4 * 4 + (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < C::PP; ++j) {
+          const int pr = wp * C::PP + j, cot = pr / C::IBT, cit = pr % C::IBT;
+          const float av = dy_t[(cot * 16 + (lane & 15)) * C::PLD + pix];
+          if (want_db && cit == 0) accb[j] = WSL_MFMA16(av, 1.0f, accb[j]);
+#pragma unroll
+          for (int t = 0; t < C::KK; ++t) {
+            const float bv = a_t[(cit * 16 + (lane & 15)) * C::PLA + apix + (t / KS) * C::ROWP + (t % KS)];
+            acc[j][t] = WSL_MFMA16(av, bv, acc[j][t]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- merge the WK row-groups (fixed order) and store partials
+  if (WK > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int PER = C::PP * (C::KK + 1) * 4;
+    float* mine = red + (wave * 64 + lane) * PER;
+#pragma unroll
+    for (int j = 0; j < C::PP; ++j) {
+#pragma unroll
+      for (int t = 0; t < C::KK; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(j * (C::KK + 1) + t) * 4 + r] = acc[j][t][r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(j * (C::KK + 1) + C::KK) * 4 + r] = accb[j][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int j = 0; j < C::PP; ++j) {
+#pragma unroll
+        for (int t = 0; t <= C::KK; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float s = 0.f;
+            for (int k = 0; k < WK; ++k) s += red[((k * C::WP + wp) * 64 + lane) * PER + (j * (C::KK + 1) + t) * 4 + r];
+            if (t < C::KK) acc[j][t][r] = s; else accb[j][r] = s;
+          }
+      }
+    }
+  }
+  if (wk == 0) {
+#pragma unroll
+    for (int j = 0; j < C::PP; ++j) {
+      const int pr = wp * C::PP + j, cot = pr / C::IBT, cit = pr % C::IBT;
+      const int ci = ci0 + cit * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + cot * 16 + (lane >> 4) * 4 + r;
+        if (co < p.Co && ci < Ci) {
+#pragma unroll
+          for (int t = 0; t < C::KK; ++t)
+            p.part_dw[(((int64_t)split * C::KK + t) * p.Co + co) * Ci + ci] = acc[j][t][r];
+        }
+        if (want_db && cit == 0 && (lane & 15) == 0 && co < p.Co) p.part_db[(int64_t)split * p.Co + co] = accb[j][r];
+      }
+    }
+  }
+}
+
+// second stage: dw[co][ci][tap] = sum_s part[s][tap][co][ci]; db[co] = sum_s part_db[s][co].  One thread per
+// (element, s-group); s-groups merged through LDS in fixed order.
+template <int SG>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_dw, const float* part_db, float* dw,
+                                                           float* db, int Co, int Ci, int KK, int nsplit) {
+  __shared__ float red[kThreads];
+  constexpr int EPB = kThreads / SG;  // elements per block
+  const int64_t E = (int64_t)KK * Co * Ci;
+  const int64_t total = E + (db ? Co : 0);
+  const int el = threadIdx.x % EPB, sg = threadIdx.x / EPB;
+  const int64_t e = (int64_t)blockIdx.x * EPB + el;
+  float s = 0.f;
+  if (e < total) {
+    const float* src = e < E ? part_dw + e : part_db + (e - E);
+    const int64_t stride = e < E ? E : Co;
+    for (int k = sg; k < nsplit; k += SG) s += src[k * stride];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sg == 0 && e < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < SG; ++k) t += red[k * EPB + el];
+    if (e < E) {
+      const int tap = (int)(e / ((int64_t)Co * Ci));
+      const int64_t rem = e - (int64_t)tap * Co * Ci;  // co*Ci + ci
+      dw[rem * KK + tap] = t;
+    } else {
+      db[e - E] = t;
+    }
+  }
+}
+
+struct WgPlan {
+  int th, tw, cb, ib, wk, nsplit, items, tiles_x, tiles_y, co_blocks, ci_blocks;
+};
+static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co) {
+  WgPlan g;
+  const bool small = (Co <= 16 || Ci <= 16);
+  if (small) {
+    g.cb = g.ib = 16, g.wk = 4;
+    if (W >= 64) g.th = 8, g.tw = 64; else if (W >= 32) g.th = 8, g.tw = 32; else g.th = 16, g.tw = 16;
+  } else {
+    g.cb = g.ib = 32, g.wk = 1;
+    if (W >= 32) g.th = 8, g.tw = 32; else g.th = 16, g.tw = 16;
+  }
+  g.tiles_x = cdiv(W, g.tw), g.tiles_y = cdiv(H, g.th);
+  g.items = N * g.tiles_x * g.tiles_y;
+  g.co_blocks = cdiv(Co, g.cb), g.ci_blocks = cdiv(Ci, g.ib);
+  int want = 1024 / (g.co_blocks * g.ci_blocks);
+  if (want < 1) want = 1;
+  g.nsplit = g.items < want ? g.items : want;
+  return g;
+}
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+static int launch_wgrad(WgradP& p, const WgPlan& g, void* stream) {
+  using C = WgradCfg<KS, TH, TW, CB, IB, WK>;
+  auto kern = wgrad_mfma_kernel<KS, TH, TW, CB, IB, WK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(g.co_blocks * g.ci_blocks, g.nsplit);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  return check_launch("wgrad_mfma_kernel");
+}
+
+template <int KS>
+static int dispatch_wgrad(WgradP& p, const WgPlan& g, void* stream) {
+#define WSL_CASE(TH_, TW_, CB_, WK_) \
+  if (g.th == TH_ && g.tw == TW_ && g.cb == CB_) return launch_wgrad<KS, TH_, TW_, CB_, CB_, WK_>(p, g, stream);
+  WSL_CASE(8, 64, 16, 4)
+  WSL_CASE(8, 32, 16, 4)
+  WSL_CASE(16, 16, 16, 4)
+  WSL_CASE(8, 32, 32, 1)
+  WSL_CASE(16, 16, 32, 1)
+#undef WSL_CASE
+  set_error("wgrad: no kernel for tile %dx%d cb %d", g.th, g.tw, g.cb);
+  return WSL_EUNSUPPORTED;
+}
+
+}  // namespace wsl
+
+using namespace wsl;
+
+extern "C" int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int ks) {
+  (void)Ci;
+  (void)ks;
+  if (N <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
+  const FwdPlan f = fwd_plan(W, Co);
+  return N * cdiv(H, f.th) * cdiv(W, f.tw);
+}
+
+extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y,
+                              int64_t y_bs, int N, int H, int W, int Co, int ks, int wmode, float* stat_part,
+                              float* stat_cnt, void* stream) {
+  WSL_REQUIRE(a && w && y, "conv2d_fwd: null argument");
+  WSL_REQUIRE(N > 0 && H > 0 && W > 0 && Co > 0, "conv2d_fwd: bad shape N=%d H=%d W=%d Co=%d", N, H, W, Co);
+  WSL_REQUIRE(ks == 1 || ks == 3, "conv2d_fwd: kernel size %d not built (1 and 3 are)", ks);
+  WSL_REQUIRE(wmode == 0 || wmode == 1, "conv2d_fwd: wmode %d", wmode);
+  WSL_REQUIRE((stat_part == nullptr) == (stat_cnt == nullptr), "conv2d_fwd: stat_part and stat_cnt come together");
+  if (int rc = check_src(a, H * W, "conv2d_fwd(a)")) return rc;
+  ConvP p;
+  p.in.a = *a;
+  if (b && b->C > 0) {
+    if (int rc = check_src(b, H * W, "conv2d_fwd(b)")) return rc;
+    p.in.b = *b;
+  } else {
+    p.in.b = WslSrc{};
+  }
+  p.in.H = H, p.in.W = W, p.in.Ci = a->C + p.in.b.C;
+  WSL_REQUIRE(y_bs >= (int64_t)Co * H * W, "conv2d_fwd: y batch stride too small");
+  p.w = w, p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.Co = Co, p.wmode = wmode;
+  p.stat_part = stat_part, p.stat_cnt = stat_cnt;
+  const FwdPlan f = fwd_plan(W, Co);
+  p.tiles_x = cdiv(W, f.tw), p.tiles_y = cdiv(H, f.th);
+  p.vec_ok = (W % 4 == 0) && (y_bs % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  return ks == 3 ? dispatch_conv<3>(p, f, stream) : dispatch_conv<1>(p, f, stream);
+}
+
+extern "C" size_t wsl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co, int ks) {
+  if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+  const WgPlan g = wgrad_plan(N, H, W, Ci, Co);
+  return sizeof(float) * (size_t)g.nsplit * ((size_t)ks * ks * Co * Ci + Co);
+}
+
+extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db,
+                                int N, int H, int W, int Co, int ks, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(a && dy && dw && ws, "conv2d_wgrad: null argument");
+  WSL_REQUIRE(N > 0 && H > 0 && W > 0 && Co > 0, "conv2d_wgrad: bad shape");
+  WSL_REQUIRE(ks == 1 || ks == 3, "conv2d_wgrad: kernel size %d not built (1 and 3 are)", ks);
+  if (int rc = check_src(a, H * W, "conv2d_wgrad(a)")) return rc;
+  WgradP p;
+  p.in.a = *a;
+  if (b && b->C > 0) {
+    if (int rc = check_src(b, H * W, "conv2d_wgrad(b)")) return rc;
+    p.in.b = *b;
+  } else {
+    p.in.b = WslSrc{};
+  }
+  p.in.H = H, p.in.W = W, p.in.Ci = a->C + p.in.b.C;
+  const int Ci = p.in.Ci;
+  WSL_REQUIRE(dy_bs >= (int64_t)Co * H * W, "conv2d_wgrad: dy batch stride too small");
+  const WgPlan g = wgrad_plan(N, H, W, Ci, Co);
+  const size_t need = wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks);
+  if (ws_bytes < need) {
+    set_error("conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+    return WSL_EWORKSPACE;
+  }
+  const int KK = ks * ks;
+  p.dy = dy, p.dy_bs = dy_bs, p.N = N, p.Co = Co;
+  p.part_dw = static_cast<float*>(ws);
+  p.part_db = p.part_dw + (size_t)g.nsplit * KK * Co * Ci;
+  p.tiles_x = g.tiles_x, p.tiles_y = g.tiles_y, p.items = g.items, p.nsplit = g.nsplit, p.co_blocks = g.co_blocks;
+  // a ci-block beyond the first never writes db and a (co,ci) element outside the tensor is never written: no memset
+  if (int rc = (ks == 3 ? dispatch_wgrad<3>(p, g, stream) : dispatch_wgrad<1>(p, g, stream))) return rc;
+  const int64_t total = (int64_t)KK * Co * Ci + (db ? Co : 0);
+  if (g.nsplit >= 64) {
+    WSL_LAUNCH((wgrad_reduce_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(kThreads), 0, stream, p.part_dw,
+               p.part_db, dw, db, Co, Ci, KK, g.nsplit);
+  } else {
+    WSL_LAUNCH((wgrad_reduce_kernel<4>), dim3((unsigned)((total + 63) / 64)), dim3(kThreads), 0, stream, p.part_dw,
+               p.part_db, dw, db, Co, Ci, KK, g.nsplit);
+  }
+  return check_launch("wgrad_reduce_kernel");
+}

@@ -1,0 +1,76 @@
+// Internal runtime shim shared by all kernel translation units.
+// Product build: hipcc --offload-arch=gfx950.  Test-only build: tests/emul (lock-step host emulator,
+// -DWSL_HOST_EMUL) compiles the very same sources to check kernel logic on a machine without a GPU.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/wsl_hip.h"
+
+#ifdef WSL_HOST_EMUL
+#include "hip_emul.h"
+#define WSL_LAUNCH(kern, grid, block, smem, stream, ...) \
+  wsl_emu::launch(grid, block, smem, [&]() { kern(__VA_ARGS__); })
+#define WSL_DYN_SMEM(name) unsigned char* name = wsl_emu::dyn_smem()
+#define WSL_SET_MAX_DYN_SMEM(kern, bytes) 0
+typedef wsl_v4f v4f;
+#define WSL_MFMA16(a, b, c) wsl_emu_mfma16(a, b, c)
+#else
+#include <hip/hip_runtime.h>
+#define WSL_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#define WSL_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define WSL_SET_MAX_DYN_SMEM(kern, bytes) \
+  hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+typedef float v4f __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4] (1 VGPR), B[k=l>>4][j=l&15] (1 VGPR), D col=l&15,row=(l>>4)*4+r.
+#define WSL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif
+
+namespace wsl {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define WSL_REQUIRE(cond, ...)     \
+  do {                             \
+    if (!(cond)) {                 \
+      wsl::set_error(__VA_ARGS__); \
+      return WSL_EINVAL;           \
+    }                              \
+  } while (0)
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;  // every kernel in this library uses 4-wave workgroups
+
+__device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : WSL_LEAKY_SLOPE * z; }
+
+// Sum over the 64 lanes of a wave; every lane gets the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// Sum over the workgroup (256 threads); result valid in every thread. `red` is >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// The loader transform of WslSrc (see wsl_hip.h).  `idx` = element index inside the dense [N,C,H,W] view
+// (used for emask), `xi` = element index in the (possibly batch-strided) x.
+__device__ __forceinline__ float src_value(const WslSrc& s, int n, int c, int64_t xi, int64_t idx) {
+  float v = s.x[xi];
+  if (s.scale) v = leaky(fmaf(v, s.scale[c], s.shift[c]));
+  if (s.emask) v = s.emask[idx] ? v * s.emask_scale : 0.f;
+  if (s.cmask) v *= s.cmask[(int64_t)n * s.C + c];
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace wsl
