@@ -1,0 +1,159 @@
+"""Loss kernels and the optimiser through the C ABI against the reference's golden vectors (tests/golden)."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+
+TOL = 1e-4
+
+
+def lws(be, N, C, HW):
+    n = be.lib.wsl_loss_ws_bytes(N, C, HW)
+    return be.ws(n), n
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fused_head_golden(be, tag):
+    g = golden("g3_head")
+    z1, z2, lab = g[f"{tag}_z1"], g[f"{tag}_z2"], g[f"{tag}_label"]
+    N, C, H, W = z1.shape
+    d = [be.arr(a) for a in (z1, z2, lab)]
+    out, pseudo = be.zeros((4,)), be.zeros((N, H, W), np.int64)
+    dz1, dz2 = be.zeros(z1.shape), be.zeros(z1.shape)
+    ws, n = lws(be, N, C, H * W)
+    be.call("wsl_head_fwd_bwd", be.ptr(d[0]), be.ptr(d[1]), be.ptr(d[2]), 4, float(g[f"{tag}_beta"]), 0.5, 1.0,
+            be.ptr(out), be.ptr(pseudo), be.ptr(dz1), be.ptr(dz2), N, C, H * W, be.ptr(ws), n, be.stream)
+    o = be.np(out)
+    assert rel_err(o[0], g[f"{tag}_loss"]) < 1e-5 and rel_err(o[1], g[f"{tag}_loss_ce"]) < 1e-5
+    assert rel_err(o[2], g[f"{tag}_loss_pse"]) < 1e-5 and o[3] == np.sum(lab != 4)
+    # label map: bit-exact given identical softmax inputs is pinned by test_mix_argmax_bit_exact; here the softmax is
+    # the kernel's own (expf rounding differs from torch's CPU vector exp), so report the mismatch rate instead
+    mism = np.mean(be.np(pseudo) != g[f"{tag}_pseudo"])
+    assert mism <= 1e-3, mism
+    assert rel_err(be.np(dz1), g[f"{tag}_dz1"]) < TOL and rel_err(be.np(dz2), g[f"{tag}_dz2"]) < TOL
+
+
+def test_mix_argmax_bit_exact(be):
+    g = golden("g3_head")
+    s1, s2 = be.arr(g["mix_s1"]), be.arr(g["mix_s2"])
+    N, C, H, W = g["mix_s1"].shape
+    out = be.zeros((N, H, W), np.int64)
+    for i, b in enumerate(g["mix_betas"]):
+        be.call("wsl_mix_argmax", be.ptr(s1), be.ptr(s2), float(b), be.ptr(out), N, C, H * W, be.stream)
+        assert np.array_equal(be.np(out), g["mix_pseudo"][i]), f"beta #{i}"
+
+
+def test_softmax_ce_golden(be):
+    g = golden("g3_head")
+    z, lab = g["ce_z"], g["ce_label"]
+    N, C, H, W = z.shape
+    dz_, dl = be.arr(z), be.arr(lab)
+    loss, dz = be.zeros((1,)), be.zeros(z.shape)
+    ws, n = lws(be, N, C, H * W)
+    be.call("wsl_ce_fwd_bwd", be.ptr(dz_), be.ptr(dl), 0, 4, be.ptr(loss), be.ptr(dz), 1.0, N, C, H * W, be.ptr(ws), n,
+            be.stream)
+    assert rel_err(be.np(loss)[0], g["ce_loss"]) < 1e-5 and rel_err(be.np(dz), g["ce_dz"]) < TOL
+    l64 = be.arr(lab.astype(np.int64))            # int64 labels (.long() in the trainers)
+    be.call("wsl_ce_fwd_bwd", be.ptr(dz_), be.ptr(l64), 1, 4, be.ptr(loss), None, 1.0, N, C, H * W, be.ptr(ws), n, be.stream)
+    assert rel_err(be.np(loss)[0], g["ce_loss"]) < 1e-5
+    allign = be.arr(np.full((N, H, W), 4, np.uint8))
+    be.call("wsl_ce_fwd_bwd", be.ptr(dz_), be.ptr(allign), 0, 4, be.ptr(loss), be.ptr(dz), 1.0, N, C, H * W, be.ptr(ws),
+            n, be.stream)
+    assert np.isnan(be.np(loss)[0]) and np.isnan(g["ce_allignored"]) and np.all(be.np(dz) == 0)
+    # softmax fwd / bwd pair
+    s, ds = be.zeros(z.shape), be.arr(np.random.default_rng(1).standard_normal(z.shape).astype(np.float32))
+    be.call("wsl_softmax_fwd", be.ptr(dz_), be.ptr(s), N, C, H * W, be.stream)
+    import torch
+    zt = torch.from_numpy(z).requires_grad_()
+    st = torch.softmax(zt, 1)
+    (st * torch.from_numpy(be.np(ds))).sum().backward()
+    assert rel_err(be.np(s), st.detach().numpy()) < 1e-6
+    be.call("wsl_softmax_bwd", be.ptr(s), be.ptr(ds), be.ptr(dz), N, C, H * W, be.stream)
+    assert rel_err(be.np(dz), zt.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("pre,ignore", [("pd", 4), ("dl", -1)])
+def test_pdice_golden(be, pre, ignore):
+    g = golden("g3_head")
+    s, t = g[f"{pre}_s"], g[f"{pre}_target"]
+    N, C, H, W = s.shape
+    ds_, dt = be.arr(s), be.arr(t)
+    loss, sums, ds = be.zeros((1,)), be.zeros((3 * C,)), be.zeros(s.shape)
+    ws, n = lws(be, N, C, H * W)
+    be.call("wsl_pdice_fwd", be.ptr(ds_), be.ptr(dt), 1, ignore, be.ptr(loss), be.ptr(sums), N, C, H * W, be.ptr(ws), n,
+            be.stream)
+    be.call("wsl_pdice_bwd", be.ptr(ds_), be.ptr(dt), 1, ignore, be.ptr(sums), None, be.ptr(ds), N, C, H * W, be.stream)
+    assert rel_err(be.np(loss)[0], g[f"{pre}_loss"]) < 1e-5
+    assert rel_err(be.np(ds), g[f"{pre}_ds"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["r5", "r2", "ns5", "ns2", "r1", "alt"])
+def test_gatedcrf_golden(be, tag):
+    g = golden("g4_gatedcrf")
+    y, img, r = g[f"{tag}_y"], g[f"{tag}_img"], int(g[f"{tag}_r"])
+    w, sxy, srgb = (g["alt_desc"] if tag == "alt" else (1.0, 6.0, 0.1))
+    N, C, H, W = y.shape
+    dy_, di = be.arr(y), be.arr(img)
+    msg, loss, dy = be.zeros(y.shape), be.zeros((1,)), be.zeros(y.shape)
+    ws, n = lws(be, N, C, H * W)
+    be.call("wsl_gatedcrf_fwd", be.ptr(dy_), be.ptr(di), be.ptr(msg), be.ptr(loss), N, C, H, W, r, sxy, srgb, w,
+            be.ptr(ws), n, be.stream)
+    be.call("wsl_gatedcrf_bwd", be.ptr(msg), None, 1.0, be.ptr(dy), N, C, H, W, be.stream)
+    assert rel_err(be.np(loss)[0], g[f"{tag}_loss"]) < TOL
+    assert rel_err(be.np(dy), g[f"{tag}_dy"]) < TOL
+
+
+def test_gatedcrf_unsupported_radius(be):
+    x = be.zeros((1, 4, 8, 8))
+    ws, n = lws(be, 1, 4, 64)
+    with pytest.raises(Exception, match="radius 9 not built"):
+        be.call("wsl_gatedcrf_fwd", be.ptr(x), be.ptr(x), be.ptr(x), be.ptr(x), 1, 4, 8, 8, 9, 6.0, 0.1, 1.0, be.ptr(ws), n,
+                be.stream)
+
+
+def test_tv_ms_mse_golden(be):
+    g = golden("g5_tv_ms")
+    for pre, n0 in (("tv", 1), ("tvt", 0)):
+        p = g[f"{pre}_p"]
+        N, C, H, W = p.shape
+        dp_ = be.arr(p)
+        loss, dp = be.zeros((1,)), be.zeros(p.shape)
+        ws, n = lws(be, N, C, H * W)
+        be.call("wsl_tv_fwd_bwd", be.ptr(dp_), n0, be.ptr(loss), be.ptr(dp), 1.0, N, C, H, W, be.ptr(ws), n, be.stream)
+        assert rel_err(be.np(loss)[0], g[f"{pre}_loss"]) < 1e-5, pre
+        assert rel_err(be.np(dp), g[f"{pre}_dp"]) < 1e-5, pre
+    img, p = g["ms_img"], g["ms_p"]
+    N, C, H, W = p.shape
+    di, dp_ = be.arr(img), be.arr(p)
+    loss, dp = be.zeros((1,)), be.zeros(p.shape)
+    ws, n = lws(be, N, C, H * W)
+    be.call("wsl_mumford_shah_fwd_bwd", be.ptr(di), be.ptr(dp_), be.ptr(loss), be.ptr(dp), 1.0, N, C, H, W, be.ptr(ws), n,
+            be.stream)
+    assert rel_err(be.np(loss)[0], g["ms_loss"]) < 1e-5 and rel_err(be.np(dp), g["ms_dp"]) < TOL
+    g = golden("g3_head")
+    a, b = g["mse_a"], g["mse_b"]
+    N, C, H, W = a.shape
+    da_, db_ = be.arr(a), be.arr(b)
+    da = be.zeros(a.shape)
+    ws, n = lws(be, N, C, H * W)
+    be.call("wsl_softmax_mse_fwd_bwd", be.ptr(da_), be.ptr(db_), be.ptr(loss), be.ptr(da), 1.0, N, C, H * W, be.ptr(ws), n,
+            be.stream)
+    assert rel_err(be.np(loss)[0], g["mse_loss"]) < 1e-5 and rel_err(be.np(da), g["mse_da"]) < TOL
+
+
+def test_sgd_ema_golden(be):
+    g = golden("g6_sgd_ema")
+    p, e = be.arr(g["p0"]), be.arr(g["ema0"])
+    buf = be.zeros(g["p0"].shape)
+    n = g["p0"].size
+    for it in range(5):
+        gr = be.arr(g["grads"][it])
+        alpha = min(1 - 1 / (it + 1), 0.99)
+        be.call("wsl_sgd_step", be.ptr(p), be.ptr(gr), be.ptr(buf), n, float(g["lrs"][it]), 0.9, 1e-4, int(it == 0), 1.0,
+                be.ptr(e), alpha, be.stream)
+        assert rel_err(be.np(p), g["params"][it]) < 1e-6 and rel_err(be.np(e), g["emas"][it]) < 1e-6
+    # unaligned / odd-length tail path
+    p2, g2, b2 = be.arr(g["p0"][:1001]), be.arr(g["grads"][0][:1001]), be.zeros((1001,))
+    be.call("wsl_sgd_step", be.ptr(p2) + 4, be.ptr(g2) + 4, be.ptr(b2) + 4, 999, 0.01, 0.9, 1e-4, 1, 1.0, None, 0.0, be.stream)
+    ref = g["p0"][1:1000] - 0.01 * (g["grads"][0][1:1000] + 1e-4 * g["p0"][1:1000])
+    assert rel_err(be.np(p2)[1:1000], ref) < 1e-6 and be.np(p2)[0] == g["p0"][0] and be.np(p2)[1000] == g["p0"][1000]

@@ -1,0 +1,765 @@
+// Weak-supervision losses as wavefront-reduction / stencil kernels (HBM-bound scans over [N,C,H,W] probabilities):
+//   CrossEntropyLoss(ignore_index)      ref: train_weakly_supervised_pCE_2D.py:81,100
+//   mixed pseudo labels + pDLoss        ref: train_weakly_supervised_segmentation_pCE_ours_proposed.py:110-125,
+//                                            utils/losses.py:195-232 (incl. its [N,H,W]x[N,1,H,W] broadcast)
+//   ModelLossSemsegGatedCRF             ref: utils/gate_crf_loss.py:20-124,135-188
+//   tv_loss                             ref: train_weakly_supervised_pCE_TV_2D.py:58-65
+//   MumfordShah_Loss                    ref: utils/losses.py:275-309
+//   softmax_mse_loss                    ref: utils/losses.py:65-82
+// Every reduction is two-stage: per-workgroup partials, then a single-workgroup finalize that merges them in a fixed
+// order in fp64 and does the scalar arithmetic on the device (no host sync, no float atomics).
+#include "wsl_rt.h"
+
+namespace wsl {
+
+constexpr int kMaxC = 8;
+constexpr int kMaxBlocks = 1024;
+constexpr int kMaxK = 48;  // partial values per workgroup
+
+__device__ __forceinline__ double block_sum_d2(double v, double* red) {
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// Sum column k of part[nblk][K] over the workgroup (single-workgroup finalize kernels).
+__device__ __forceinline__ double col_sum(const float* part, int nblk, int K, int k, double* red) {
+  double s = 0;
+  for (int b = threadIdx.x; b < nblk; b += kThreads) s += part[(int64_t)b * K + k];
+  return block_sum_d2(s, red);
+}
+
+template <int K>
+__device__ __forceinline__ void write_partials(float (&v)[K], float* part, float* red) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float s = block_sum(v[k], red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * K + k] = s;
+  }
+}
+
+__device__ __forceinline__ int load_label(const void* lab, int i64, int64_t idx) {
+  return i64 ? (int)static_cast<const int64_t*>(lab)[idx] : (int)static_cast<const uint8_t*>(lab)[idx];
+}
+
+// softmax over C strided values; returns log-sum-exp (max-subtracted).
+__device__ __forceinline__ float softmax_c(const float* z, int64_t stride, int C, float* s) {
+  float m = z[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, z[c * stride]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) {
+    s[c] = expf(z[c * stride] - m);
+    sum += s[c];
+  }
+  const float inv = 1.f / sum;
+  for (int c = 0; c < C; ++c) s[c] *= inv;
+  return m + logf(sum);
+}
+
+__device__ __forceinline__ int mix_argmax_c(const float* s1, const float* s2, int C, float bf, float omb) {
+  int best = 0;
+  float bv = __fadd_rn(__fmul_rn(bf, s1[0]), __fmul_rn(omb, s2[0]));
+  for (int c = 1; c < C; ++c) {
+    const float v = __fadd_rn(__fmul_rn(bf, s1[c]), __fmul_rn(omb, s2[c]));
+    if (v > bv) bv = v, best = c;
+  }
+  return best;
+}
+
+// ------------------------------------------------------------------------------------------------ softmax
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* z, float* s, int C, int HW, int64_t P) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+    float v[kMaxC];
+    softmax_c(z + base, HW, C, v);
+    for (int c = 0; c < C; ++c) s[base + (int64_t)c * HW] = v[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* s, const float* ds, float* dz, int C, int HW,
+                                                          int64_t P) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot = fmaf(ds[base + (int64_t)c * HW], s[base + (int64_t)c * HW], dot);
+    for (int c = 0; c < C; ++c) dz[base + (int64_t)c * HW] = s[base + (int64_t)c * HW] * (ds[base + (int64_t)c * HW] - dot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cross entropy
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* z, const void* lab, int i64, int ignore, int C, int HW,
+                                                        int64_t P, float* part) {
+  __shared__ float red[4];
+  float v[2] = {0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int l = load_label(lab, i64, i);
+    if (l != ignore && l >= 0 && l < C) {
+      const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+      float s[kMaxC];
+      const float lse = softmax_c(z + base, HW, C, s);
+      v[0] += lse - z[base + (int64_t)l * HW];
+      v[1] += 1.f;
+    }
+  }
+  write_partials<2>(v, part, red);
+}
+
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* part, int nblk, float* loss, float* scal) {
+  __shared__ double red[kThreads];
+  const double nll = col_sum(part, nblk, 2, 0, red), cnt = col_sum(part, nblk, 2, 1, red);
+  if (threadIdx.x == 0) {
+    loss[0] = (float)(nll / cnt);  // 0/0 -> NaN like torch when every pixel is ignored
+    scal[0] = cnt > 0 ? (float)(1.0 / cnt) : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* z, const void* lab, int i64, int ignore, int C, int HW,
+                                                     int64_t P, const float* scal, float gscale, float* dz) {
+  const float k = scal[0] * gscale;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+    const int l = load_label(lab, i64, i);
+    if (l != ignore && l >= 0 && l < C) {
+      float s[kMaxC];
+      softmax_c(z + base, HW, C, s);
+      for (int c = 0; c < C; ++c) dz[base + (int64_t)c * HW] = k * (s[c] - (c == l ? 1.f : 0.f));
+    } else {
+      for (int c = 0; c < C; ++c) dz[base + (int64_t)c * HW] = 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ mix + argmax
+__global__ __launch_bounds__(256) void mix_argmax_kernel(const float* s1, const float* s2, float bf, float omb,
+                                                         int64_t* pseudo, int C, int HW, int64_t P) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+    float a[kMaxC], b[kMaxC];
+    for (int c = 0; c < C; ++c) a[c] = s1[base + (int64_t)c * HW], b[c] = s2[base + (int64_t)c * HW];
+    pseudo[i] = mix_argmax_c(a, b, C, bf, omb);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pDLoss / DiceLoss
+// One thread per pixel position, looping over the batch: the reference's broadcast makes every sum
+//   sum_{h,w} (sum_b term[b,h,w]) * (sum_a mask[a,h,w]).
+__global__ __launch_bounds__(256) void pdice_reduce_kernel(const float* s, const void* tgt, int i64, int ignore, int N,
+                                                           int C, int HW, float* part) {
+  __shared__ float red[4];
+  float v[3 * kMaxC];
+  for (int k = 0; k < 3 * kMaxC; ++k) v[k] = 0.f;
+  for (int p = blockIdx.x * kThreads + threadIdx.x; p < HW; p += gridDim.x * kThreads) {
+    float I[kMaxC], Z[kMaxC], Y[kMaxC], M = 0.f;
+    for (int c = 0; c < C; ++c) I[c] = Z[c] = Y[c] = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const int l = load_label(tgt, i64, (int64_t)n * HW + p);
+      M += (ignore >= 0 && l == ignore) ? 0.f : 1.f;
+      for (int c = 0; c < C; ++c) {
+        const float sv = s[((int64_t)n * C + c) * HW + p];
+        Z[c] = fmaf(sv, sv, Z[c]);
+        if (l == c) I[c] += sv, Y[c] += 1.f;
+      }
+    }
+    if (ignore < 0) M = 1.f;
+    for (int c = 0; c < C; ++c) v[c] = fmaf(I[c], M, v[c]), v[kMaxC + c] = fmaf(Z[c], M, v[kMaxC + c]),
+                               v[2 * kMaxC + c] = fmaf(Y[c], M, v[2 * kMaxC + c]);
+  }
+  write_partials<3 * kMaxC>(v, part, red);
+}
+
+__global__ __launch_bounds__(256) void pdice_finalize_kernel(const float* part, int nblk, int C, float* loss, float* sums) {
+  __shared__ double red[kThreads];
+  double acc = 0;
+  for (int c = 0; c < C; ++c) {
+    const double I = col_sum(part, nblk, 3 * kMaxC, c, red), Z = col_sum(part, nblk, 3 * kMaxC, kMaxC + c, red),
+                 Y = col_sum(part, nblk, 3 * kMaxC, 2 * kMaxC + c, red);
+    const float If = (float)I, Zf = (float)Z, Yf = (float)Y;
+    acc += 1.0 - (double)((2.f * If + 1e-5f) / (Zf + Yf + 1e-5f));
+    if (threadIdx.x == 0) sums[c] = If, sums[C + c] = Zf, sums[2 * C + c] = Yf;
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(acc / C);
+}
+
+__global__ __launch_bounds__(256) void pdice_bwd_kernel(const float* s, const void* tgt, int i64, int ignore,
+                                                        const float* sums, const float* gout, float* ds, int N, int C,
+                                                        int HW) {
+  const float go = (gout ? gout[0] : 1.f) / (float)C;
+  float ca[kMaxC], cb[kMaxC];
+  for (int c = 0; c < C; ++c) {
+    const float I = sums[c], D = sums[C + c] + sums[2 * C + c] + 1e-5f;
+    ca[c] = -2.f / D * go;                              // d/ds of -(2I+eps)/D through I  (times t)
+    cb[c] = 2.f * (2.f * I + 1e-5f) / (D * D) * go;     // ... through Z                   (times s)
+  }
+  for (int p = blockIdx.x * kThreads + threadIdx.x; p < HW; p += gridDim.x * kThreads) {
+    float M = 1.f;
+    if (ignore >= 0) {
+      M = 0.f;
+      for (int n = 0; n < N; ++n) M += load_label(tgt, i64, (int64_t)n * HW + p) == ignore ? 0.f : 1.f;
+    }
+    for (int n = 0; n < N; ++n) {
+      const int l = load_label(tgt, i64, (int64_t)n * HW + p);
+      for (int c = 0; c < C; ++c) {
+        const int64_t idx = ((int64_t)n * C + c) * HW + p;
+        ds[idx] = M * (ca[c] * (l == c ? 1.f : 0.f) + cb[c] * s[idx]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fused head
+// partial columns: 0 nll1, 1 nll2, 2 n_valid, 3+c I1, 3+C+c Z1, 3+2C+c I2, 3+3C+c Z2, 3+4C+c Y
+struct HeadP {
+  const float* z1;
+  const float* z2;
+  const uint8_t* label;
+  int ignore, C, HW, N;
+  int64_t P;
+  float bf, omb;
+};
+
+__global__ __launch_bounds__(256) void head_reduce_kernel(HeadP h, int64_t* pseudo, float* part) {
+  __shared__ float red[4];
+  float v[3 + 5 * kMaxC];
+  for (int k = 0; k < 3 + 5 * kMaxC; ++k) v[k] = 0.f;
+  const int C = h.C;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < h.P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / h.HW, p = i - n * h.HW, base = n * C * h.HW + p;
+    const int l = h.label[i];
+    const bool valid = (l != h.ignore) && l < C;
+    float s1[kMaxC], s2[kMaxC];
+    const float lse1 = softmax_c(h.z1 + base, h.HW, C, s1);
+    if (valid) v[0] += lse1 - h.z1[base + (int64_t)l * h.HW], v[2] += 1.f;
+    if (h.z2) {
+      const float lse2 = softmax_c(h.z2 + base, h.HW, C, s2);
+      if (valid) v[1] += lse2 - h.z2[base + (int64_t)l * h.HW];
+      const int t = mix_argmax_c(s1, s2, C, h.bf, h.omb);
+      if (pseudo) pseudo[i] = t;
+      for (int c = 0; c < C; ++c) {
+        v[3 + kMaxC + c] = fmaf(s1[c], s1[c], v[3 + kMaxC + c]);
+        v[3 + 3 * kMaxC + c] = fmaf(s2[c], s2[c], v[3 + 3 * kMaxC + c]);
+        if (c == t) v[3 + c] += s1[c], v[3 + 2 * kMaxC + c] += s2[c], v[3 + 4 * kMaxC + c] += 1.f;
+      }
+    }
+  }
+  write_partials<3 + 5 * kMaxC>(v, part, red);
+}
+
+// scal: 0 inv_nvalid; 1+c ca1, 1+C+c cb1, 1+2C+c ca2, 1+3C+c cb2 (already times w_pse*0.5/C)
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float* part, int nblk, int C, int N, int dual,
+                                                            float w_pse, float* out, float* scal) {
+  __shared__ double red[kThreads];
+  constexpr int K = 3 + 5 * kMaxC;
+  const double nll1 = col_sum(part, nblk, K, 0, red), nll2 = col_sum(part, nblk, K, 1, red),
+               cnt = col_sum(part, nblk, K, 2, red);
+  const float ce1 = (float)(nll1 / cnt), ce2 = (float)(nll2 / cnt);
+  float pse = 0.f;
+  if (dual) {
+    float d1 = 0.f, d2 = 0.f;
+    const float Nf = (float)N;  // pseudo labels are never `ignore`: the broadcast multiplies every sum by N
+    for (int c = 0; c < C; ++c) {
+      const float I1 = Nf * (float)col_sum(part, nblk, K, 3 + c, red), Z1 = Nf * (float)col_sum(part, nblk, K, 3 + kMaxC + c, red),
+                  I2 = Nf * (float)col_sum(part, nblk, K, 3 + 2 * kMaxC + c, red),
+                  Z2 = Nf * (float)col_sum(part, nblk, K, 3 + 3 * kMaxC + c, red),
+                  Y = Nf * (float)col_sum(part, nblk, K, 3 + 4 * kMaxC + c, red);
+      const float D1 = Z1 + Y + 1e-5f, D2 = Z2 + Y + 1e-5f;
+      d1 += 1.f - (2.f * I1 + 1e-5f) / D1;
+      d2 += 1.f - (2.f * I2 + 1e-5f) / D2;
+      if (threadIdx.x == 0) {
+        const float k = w_pse * 0.5f / (float)C * Nf;
+        scal[1 + c] = -2.f / D1 * k;
+        scal[1 + C + c] = 2.f * (2.f * I1 + 1e-5f) / (D1 * D1) * k;
+        scal[1 + 2 * C + c] = -2.f / D2 * k;
+        scal[1 + 3 * C + c] = 2.f * (2.f * I2 + 1e-5f) / (D2 * D2) * k;
+      }
+    }
+    pse = 0.5f * (d1 / (float)C + d2 / (float)C);
+  }
+  if (threadIdx.x == 0) {
+    const float ce = dual ? 0.5f * (ce1 + ce2) : ce1;
+    out[0] = dual ? ce + w_pse * pse : ce;
+    out[1] = ce;
+    out[2] = pse;
+    out[3] = (float)cnt;
+    scal[0] = cnt > 0 ? (float)(1.0 / cnt) : 0.f;
+  }
+}
+
+__device__ __forceinline__ void head_branch_bwd(const float* s, int C, int t, int l, bool valid, const float* ca,
+                                                const float* cb, float kce, float gscale, float* dz, int64_t stride) {
+  float dsv[kMaxC], dot = 0.f;
+  for (int c = 0; c < C; ++c) {
+    dsv[c] = cb ? ca[c] * (c == t ? 1.f : 0.f) + cb[c] * s[c] : 0.f;
+    dot = fmaf(dsv[c], s[c], dot);
+  }
+  for (int c = 0; c < C; ++c) {
+    float g = s[c] * (dsv[c] - dot);
+    if (valid) g += kce * (s[c] - (c == l ? 1.f : 0.f));
+    dz[c * stride] = g * gscale;
+  }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadP h, const float* scal, float gscale, float* dz1, float* dz2) {
+  const int C = h.C;
+  const bool dual = h.z2 != nullptr;
+  const float kce = scal[0] * (dual ? 0.5f : 1.f);
+  float ca1[kMaxC], cb1[kMaxC], ca2[kMaxC], cb2[kMaxC];
+  for (int c = 0; c < C; ++c) ca1[c] = scal[1 + c], cb1[c] = scal[1 + C + c], ca2[c] = scal[1 + 2 * C + c], cb2[c] = scal[1 + 3 * C + c];
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < h.P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / h.HW, p = i - n * h.HW, base = n * C * h.HW + p;
+    const int l = h.label[i];
+    const bool valid = (l != h.ignore) && l < C;
+    float s1[kMaxC], s2[kMaxC];
+    softmax_c(h.z1 + base, h.HW, C, s1);
+    if (dual) {
+      softmax_c(h.z2 + base, h.HW, C, s2);
+      const int t = mix_argmax_c(s1, s2, C, h.bf, h.omb);
+      head_branch_bwd(s1, C, t, l, valid, ca1, cb1, kce, gscale, dz1 + base, h.HW);
+      head_branch_bwd(s2, C, t, l, valid, ca2, cb2, kce, gscale, dz2 + base, h.HW);
+    } else {
+      head_branch_bwd(s1, C, 0, l, valid, nullptr, nullptr, kce, gscale, dz1 + base, h.HW);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GatedCRF
+// 16x16 pixels per workgroup, y (C planes) and the image staged in LDS with a `r` halo.  A tap outside the image sees
+// feature vector 0 and y = 0 (zero-padded unfold): it adds to sum(K) only.
+struct CrfP {
+  const float* y;
+  const float* img;
+  float* msg;
+  int N, C, H, W, r;
+  float sxy, srgb, weight;
+  int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void gatedcrf_fwd_kernel(CrfP q, float* part) {
+  WSL_DYN_SMEM(smem);
+  __shared__ float red[4];
+  const int r = q.r, TS = 16 + 2 * r, C = q.C;
+  float* yt = reinterpret_cast<float*>(smem);   // [C][TS*TS]
+  float* it = yt + C * TS * TS;                 // [TS*TS] image / sigma_rgb, 0 outside
+  int bid = blockIdx.x;
+  const int tx_i = bid % q.tiles_x;
+  bid /= q.tiles_x;
+  const int ty_i = bid % q.tiles_y, n = bid / q.tiles_y;
+  const int y0 = ty_i * 16, x0 = tx_i * 16;
+  const int64_t HW = (int64_t)q.H * q.W;
+  for (int e = threadIdx.x; e < TS * TS; e += kThreads) {
+    const int ty = e / TS, tx = e - ty * TS, gy = y0 + ty - r, gx = x0 + tx - r;
+    const bool in = gy >= 0 && gy < q.H && gx >= 0 && gx < q.W;
+    it[e] = in ? q.img[n * HW + (int64_t)gy * q.W + gx] / q.srgb : 0.f;
+    for (int c = 0; c < C; ++c) yt[c * TS * TS + e] = in ? q.y[((int64_t)n * C + c) * HW + (int64_t)gy * q.W + gx] : 0.f;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15, gy = y0 + ly, gx = x0 + lx;
+  float v[2] = {0.f, 0.f};
+  if (gy < q.H && gx < q.W) {
+    const int ce = (ly + r) * TS + lx + r;
+    const float fpx = (float)gx / q.sxy, fpy = (float)gy / q.sxy, fpi = it[ce];
+    float m[kMaxC];
+    for (int c = 0; c < C; ++c) m[c] = 0.f;
+    float ks = 0.f;
+    for (int dy = -r; dy <= r; ++dy) {
+      const int qy = gy + dy;
+      const bool iny = qy >= 0 && qy < q.H;
+      for (int dx = -r; dx <= r; ++dx) {
+        if (dy == 0 && dx == 0) continue;
+        const int qx = gx + dx;
+        const bool in = iny && qx >= 0 && qx < q.W;
+        const int te = ce + dy * TS + dx;
+        const float fqx = in ? (float)qx / q.sxy : 0.f, fqy = in ? (float)qy / q.sxy : 0.f, fqi = it[te];
+        const float ddx = fqx - fpx, ddy = fqy - fpy, ddi = fqi - fpi;
+        const float e = (-0.5f * (ddx * ddx)) + (-0.5f * (ddy * ddy)) + (-0.5f * (ddi * ddi));
+        const float k = q.weight * expf(e);
+        ks += k;
+        for (int c = 0; c < C; ++c) m[c] = fmaf(k, yt[c * TS * TS + te], m[c]);
+      }
+    }
+    float ym = 0.f;
+    for (int c = 0; c < C; ++c) {
+      q.msg[((int64_t)n * C + c) * HW + (int64_t)gy * q.W + gx] = m[c];
+      ym = fmaf(m[c], yt[c * TS * TS + ce], ym);
+    }
+    v[0] = ks, v[1] = ym;
+  }
+  write_partials<2>(v, part, red);
+}
+
+__global__ __launch_bounds__(256) void gatedcrf_finalize_kernel(const float* part, int nblk, double denom, float* loss) {
+  __shared__ double red[kThreads];
+  const double ks = col_sum(part, nblk, 2, 0, red), ym = col_sum(part, nblk, 2, 1, red);
+  if (threadIdx.x == 0) loss[0] = (float)((ks - ym) / denom);
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float* x, const float* gout, float k, float* out, int64_t n) {
+  const float s = k * (gout ? gout[0] : 1.f);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) out[i] = s * x[i];
+}
+
+// ------------------------------------------------------------------------------------------------ tv_loss
+// 16x16 outputs of one (n, c) plane per workgroup.  Regions (halo): p +4, erosion e +3 (with arg-min), dilation +2
+// (contour flag + arg-max), ge +1, dp +0.  Windows ignore out-of-image taps (max_pool2d pads with -inf); extrema take
+// the first position in row-major window order.
+struct TvP {
+  const float* p;
+  float* dp;
+  int n0, N, C, H, W, tiles_x, tiles_y;
+  float gk;  // gscale / numel
+};
+
+__global__ __launch_bounds__(256) void tv_fwd_bwd_kernel(TvP q, float* part) {
+  __shared__ float pt[24 * 24];
+  __shared__ float et[22 * 22];
+  __shared__ int eargt[22 * 22];
+  __shared__ int dargt[20 * 20];   // arg-max of the dilation (index into et) or -1 when contour <= 0 / outside
+  __shared__ float get[18 * 18];
+  __shared__ float red[4];
+  int bid = blockIdx.x;
+  const int tx_i = bid % q.tiles_x;
+  bid /= q.tiles_x;
+  const int ty_i = bid % q.tiles_y;
+  bid /= q.tiles_y;
+  const int c = bid % q.C, n = bid / q.C;
+  const int y0 = ty_i * 16, x0 = tx_i * 16;
+  const int64_t plane = ((int64_t)n * q.C + c) * q.H * q.W;
+  const bool active = n >= q.n0;
+  float v[1] = {0.f};
+  for (int e = threadIdx.x; e < 24 * 24; e += kThreads) {
+    const int gy = y0 + e / 24 - 4, gx = x0 + e % 24 - 4;
+    pt[e] = (gy >= 0 && gy < q.H && gx >= 0 && gx < q.W) ? q.p[plane + (int64_t)gy * q.W + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 22 * 22; e += kThreads) {       // erosion on halo 3
+    const int ty = e / 22, tx = e % 22, gy = y0 + ty - 3, gx = x0 + tx - 3;
+    float best = 0.f;
+    int arg = -1;
+    if (gy >= 0 && gy < q.H && gx >= 0 && gx < q.W) {
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = gy + dy, xx = gx + dx;
+          if (yy < 0 || yy >= q.H || xx < 0 || xx >= q.W) continue;
+          const int pe = (ty + 1 + dy) * 24 + tx + 1 + dx;
+          if (arg < 0 || pt[pe] < best) best = pt[pe], arg = pe;
+        }
+    }
+    et[e] = best;
+    eargt[e] = arg;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 20 * 20; e += kThreads) {       // dilation + contour on halo 2
+    const int ty = e / 20, tx = e % 20, gy = y0 + ty - 2, gx = x0 + tx - 2;
+    int res = -1;
+    if (gy >= 0 && gy < q.H && gx >= 0 && gx < q.W) {
+      float best = 0.f;
+      int arg = -1;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = gy + dy, xx = gx + dx;
+          if (yy < 0 || yy >= q.H || xx < 0 || xx >= q.W) continue;
+          const int ee = (ty + 1 + dy) * 22 + tx + 1 + dx;
+          if (arg < 0 || et[ee] > best) best = et[ee], arg = ee;
+        }
+      const float contour = best - et[(ty + 1) * 22 + tx + 1];
+      if (contour > 0.f) {
+        res = arg;
+        if (active && ty >= 2 && ty < 18 && tx >= 2 && tx < 18) v[0] += contour;
+      }
+    }
+    dargt[e] = res;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 18 * 18; e += kThreads) {       // ge (gradient wrt the erosion output) on halo 1
+    const int ty = e / 18, tx = e % 18, gy = y0 + ty - 1, gx = x0 + tx - 1;
+    float g = 0.f;
+    if (gy >= 0 && gy < q.H && gx >= 0 && gx < q.W) {
+      const int me = (ty + 2) * 22 + tx + 2;  // this position in et coordinates
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = gy + dy, xx = gx + dx;
+          if (yy < 0 || yy >= q.H || xx < 0 || xx >= q.W) continue;
+          if (dargt[(ty + 1 + dy) * 20 + tx + 1 + dx] == me) g += 1.f;
+        }
+      if (dargt[(ty + 1) * 20 + tx + 1] >= 0) g -= 1.f;
+    }
+    get[e] = g;
+  }
+  __syncthreads();
+  {
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15, gy = y0 + ty, gx = x0 + tx;
+    if (gy < q.H && gx < q.W) {
+      float g = 0.f;
+      if (active) {
+        const int pe = (ty + 4) * 24 + tx + 4;
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = gy + dy, xx = gx + dx;
+            if (yy < 0 || yy >= q.H || xx < 0 || xx >= q.W) continue;
+            if (eargt[(ty + 3 + dy) * 22 + tx + 3 + dx] == pe) g += get[(ty + 1 + dy) * 18 + tx + 1 + dx];
+          }
+      }
+      q.dp[plane + (int64_t)gy * q.W + gx] = g * q.gk;
+    }
+  }
+  write_partials<1>(v, part, red);
+}
+
+__global__ __launch_bounds__(256) void sum_finalize_kernel(const float* part, int nblk, int K, double k, float* loss) {
+  __shared__ double red[kThreads];
+  double s = 0;
+  for (int j = 0; j < K; ++j) s += col_sum(part, nblk, K, j, red);
+  if (threadIdx.x == 0) loss[0] = (float)(s * k);
+}
+
+// ------------------------------------------------------------------------------------------------ Mumford-Shah
+__global__ __launch_bounds__(256) void ms_moment_kernel(const float* img, const float* p, int C, int HW, int chunks,
+                                                        float* mom) {  // mom[n][chunk][C+1]
+  __shared__ float red[4];
+  const int n = blockIdx.y, base = blockIdx.x * 4096;
+  float v[kMaxC + 1];
+  for (int k = 0; k <= kMaxC; ++k) v[k] = 0.f;
+  for (int i = base + threadIdx.x; i < base + 4096 && i < HW; i += kThreads) {
+    const float I = img[(int64_t)n * HW + i];
+    v[kMaxC] += I;
+    for (int c = 0; c < C; ++c) v[c] = fmaf(p[((int64_t)n * C + c) * HW + i], I, v[c]);
+  }
+  for (int k = 0; k <= C; ++k) {
+    const float s = block_sum(v[k == C ? kMaxC : k], red);
+    if (threadIdx.x == 0) mom[((int64_t)n * chunks + blockIdx.x) * (C + 1) + k] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void ms_main_kernel(const float* img, const float* p, const float* mom, int C, int H,
+                                                      int W, int chunks, float gscale, float* dp, float* part) {
+  __shared__ float red[4];
+  __shared__ float cen[kMaxC + 1];
+  const int n = blockIdx.y, HW = H * W, base = blockIdx.x * 4096;
+  if (threadIdx.x <= (unsigned)C) {  // per-sample sums: classes 0..C-1 = sum(p_c*I), entry C = sum(I)
+    double s = 0;
+    for (int k = 0; k < chunks; ++k) s += mom[((int64_t)n * chunks + k) * (C + 1) + threadIdx.x];
+    cen[threadIdx.x] = (float)s;
+  }
+  __syncthreads();
+  float cv[kMaxC];
+  for (int c = 0; c < C; ++c) cv[c] = cen[c] / cen[C];   // centroid divides by sum(I) (losses.py:286-287)
+  float v[2] = {0.f, 0.f};
+  for (int i = base + threadIdx.x; i < base + 4096 && i < HW; i += kThreads) {
+    const int y = i / W, x = i - y * W;
+    const float I = img[(int64_t)n * HW + i];
+    for (int c = 0; c < C; ++c) {
+      const float* pc = p + ((int64_t)n * C + c) * HW;
+      const float pv = pc[i], d = pv - cv[c];
+      v[0] = fmaf(d * d, I, v[0]);
+      float g = 2.f * d * I;
+      if (y + 1 < H) { const float t = pc[i + W] - pv; v[1] += fabsf(t); g -= (t > 0.f) - (t < 0.f); }
+      if (x + 1 < W) { const float t = pc[i + 1] - pv; v[1] += fabsf(t); g -= (t > 0.f) - (t < 0.f); }
+      if (y > 0) { const float t = pv - pc[i - W]; g += (t > 0.f) - (t < 0.f); }
+      if (x > 0) { const float t = pv - pc[i - 1]; g += (t > 0.f) - (t < 0.f); }
+      dp[((int64_t)n * C + c) * HW + i] = g * gscale;
+    }
+  }
+  for (int k = 0; k < 2; ++k) {
+    const float s = block_sum(v[k], red);
+    if (threadIdx.x == 0) part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + k] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ softmax MSE
+__global__ __launch_bounds__(256) void softmax_mse_kernel(const float* a, const float* b, int C, int HW, int64_t P,
+                                                          float k, float* da, float* part) {
+  __shared__ float red[4];
+  float v[1] = {0.f};
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+    float sa[kMaxC], sb[kMaxC], ds[kMaxC], dot = 0.f;
+    softmax_c(a + base, HW, C, sa);
+    softmax_c(b + base, HW, C, sb);
+    for (int c = 0; c < C; ++c) {
+      const float d = sa[c] - sb[c];
+      v[0] = fmaf(d, d, v[0]);
+      ds[c] = 2.f * d * k;
+      dot = fmaf(ds[c], sa[c], dot);
+    }
+    for (int c = 0; c < C; ++c) da[base + (int64_t)c * HW] = sa[c] * (ds[c] - dot);
+  }
+  write_partials<1>(v, part, red);
+}
+
+static int grid_for(int64_t n) {
+  int64_t b = (n + kThreads - 1) / kThreads;
+  return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
+}
+
+}  // namespace wsl
+
+using namespace wsl;
+
+extern "C" size_t wsl_loss_ws_bytes(int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  const size_t tiles = (size_t)N * C * ((HW + 255) / 256 + 64);  // generous bound on 16x16 tile counts (any aspect)
+  const size_t part = (tiles > (size_t)kMaxBlocks ? tiles : (size_t)kMaxBlocks) * kMaxK;
+  return sizeof(float) * (part + 64 + (size_t)N * ((HW + 4095) / 4096) * (kMaxC + 1));
+}
+
+#define WSL_WS_OK(fn)                                                              \
+  do {                                                                             \
+    if (!ws || ws_bytes < wsl_loss_ws_bytes(N, C, HW_)) {                           \
+      set_error(fn ": workspace %zu < %zu", ws_bytes, wsl_loss_ws_bytes(N, C, HW_)); \
+      return WSL_EWORKSPACE;                                                       \
+    }                                                                              \
+  } while (0)
+
+extern "C" int wsl_softmax_fwd(const float* z, float* s, int N, int C, int HW, void* stream) {
+  WSL_REQUIRE(z && s && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "softmax_fwd: bad args (C <= %d)", kMaxC);
+  const int64_t P = (int64_t)N * HW;
+  WSL_LAUNCH(softmax_fwd_kernel, dim3(grid_for(P)), dim3(kThreads), 0, stream, z, s, C, HW, P);
+  return check_launch("softmax_fwd_kernel");
+}
+
+extern "C" int wsl_softmax_bwd(const float* s, const float* ds, float* dz, int N, int C, int HW, void* stream) {
+  WSL_REQUIRE(s && ds && dz && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "softmax_bwd: bad args");
+  const int64_t P = (int64_t)N * HW;
+  WSL_LAUNCH(softmax_bwd_kernel, dim3(grid_for(P)), dim3(kThreads), 0, stream, s, ds, dz, C, HW, P);
+  return check_launch("softmax_bwd_kernel");
+}
+
+extern "C" int wsl_ce_fwd_bwd(const float* z, const void* label, int label_i64, int ignore, float* loss, float* dz,
+                              float gscale, int N, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(z && label && loss && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "ce_fwd_bwd: bad args");
+  const int HW_ = HW;
+  WSL_WS_OK("ce_fwd_bwd");
+  const int64_t P = (int64_t)N * HW;
+  const int nb = grid_for(P);
+  float* part = static_cast<float*>(ws);
+  float* scal = part + (size_t)kMaxBlocks * kMaxK;
+  WSL_LAUNCH(ce_reduce_kernel, dim3(nb), dim3(kThreads), 0, stream, z, label, label_i64, ignore, C, HW, P, part);
+  WSL_LAUNCH(ce_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, loss, scal);
+  if (dz) WSL_LAUNCH(ce_bwd_kernel, dim3(nb), dim3(kThreads), 0, stream, z, label, label_i64, ignore, C, HW, P, scal, gscale, dz);
+  return check_launch("ce_fwd_bwd");
+}
+
+extern "C" int wsl_mix_argmax(const float* s1, const float* s2, double beta, int64_t* pseudo, int N, int C, int HW,
+                              void* stream) {
+  WSL_REQUIRE(s1 && s2 && pseudo && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "mix_argmax: bad args");
+  const int64_t P = (int64_t)N * HW;
+  WSL_LAUNCH(mix_argmax_kernel, dim3(grid_for(P)), dim3(kThreads), 0, stream, s1, s2, (float)beta, (float)(1.0 - beta),
+             pseudo, C, HW, P);
+  return check_launch("mix_argmax_kernel");
+}
+
+extern "C" int wsl_pdice_fwd(const float* s, const void* target, int target_i64, int ignore, float* loss, float* sums,
+                             int N, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(s && target && loss && sums && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "pdice_fwd: bad args");
+  const int HW_ = HW;
+  WSL_WS_OK("pdice_fwd");
+  const int nb = grid_for(HW);
+  float* part = static_cast<float*>(ws);
+  WSL_LAUNCH(pdice_reduce_kernel, dim3(nb), dim3(kThreads), 0, stream, s, target, target_i64, ignore, N, C, HW, part);
+  WSL_LAUNCH(pdice_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, C, loss, sums);
+  return check_launch("pdice_fwd");
+}
+
+extern "C" int wsl_pdice_bwd(const float* s, const void* target, int target_i64, int ignore, const float* sums,
+                             const float* gout, float* ds, int N, int C, int HW, void* stream) {
+  WSL_REQUIRE(s && target && sums && ds && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "pdice_bwd: bad args");
+  WSL_LAUNCH(pdice_bwd_kernel, dim3(grid_for(HW)), dim3(kThreads), 0, stream, s, target, target_i64, ignore, sums, gout,
+             ds, N, C, HW);
+  return check_launch("pdice_bwd_kernel");
+}
+
+extern "C" int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int ignore, double beta,
+                                float w_pse, float gscale, float* out, int64_t* pseudo, float* dz1, float* dz2, int N,
+                                int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(z1 && label && out && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "head_fwd_bwd: bad args");
+  WSL_REQUIRE((dz1 == nullptr) || (z2 == nullptr) || (dz2 != nullptr), "head_fwd_bwd: dz2 missing");
+  const int HW_ = HW;
+  WSL_WS_OK("head_fwd_bwd");
+  HeadP h{z1, z2, label, ignore, C, HW, N, (int64_t)N * HW, (float)beta, (float)(1.0 - beta)};
+  const int nb = grid_for(h.P);
+  float* part = static_cast<float*>(ws);
+  float* scal = part + (size_t)kMaxBlocks * kMaxK;
+  WSL_LAUNCH(head_reduce_kernel, dim3(nb), dim3(kThreads), 0, stream, h, pseudo, part);
+  WSL_LAUNCH(head_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, C, N, z2 ? 1 : 0, w_pse, out, scal);
+  if (dz1) WSL_LAUNCH(head_bwd_kernel, dim3(nb), dim3(kThreads), 0, stream, h, scal, gscale, dz1, dz2);
+  return check_launch("head_fwd_bwd");
+}
+
+extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, float* loss, int N, int C, int H, int W,
+                                int radius, float sigma_xy, float sigma_rgb, float weight, void* ws, size_t ws_bytes,
+                                void* stream) {
+  WSL_REQUIRE(y && img && msg && loss && N > 0 && H > 0 && W > 0 && C > 0 && C <= kMaxC, "gatedcrf_fwd: bad args");
+  if (radius < 1 || radius > 8) {
+    set_error("gatedcrf_fwd: radius %d not built (1..8 are)", radius);
+    return WSL_EUNSUPPORTED;
+  }
+  const int HW_ = H * W;
+  WSL_WS_OK("gatedcrf_fwd");
+  CrfP q{y, img, msg, N, C, H, W, radius, sigma_xy, sigma_rgb, weight, cdiv(W, 16), cdiv(H, 16)};
+  const int nb = N * q.tiles_x * q.tiles_y;
+  const int TS = 16 + 2 * radius;
+  const size_t smem = sizeof(float) * (size_t)(C + 1) * TS * TS;
+  float* part = static_cast<float*>(ws);
+  WSL_LAUNCH(gatedcrf_fwd_kernel, dim3(nb), dim3(kThreads), smem, stream, q, part);
+  WSL_LAUNCH(gatedcrf_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, (double)N * H * W, loss);
+  return check_launch("gatedcrf_fwd");
+}
+
+extern "C" int wsl_gatedcrf_bwd(const float* msg, const float* gout, float gscale, float* dy, int N, int C, int H, int W,
+                                void* stream) {
+  WSL_REQUIRE(msg && dy && N > 0 && C > 0 && H > 0 && W > 0, "gatedcrf_bwd: bad args");
+  const int64_t n = (int64_t)N * C * H * W;
+  WSL_LAUNCH(scale_kernel, dim3(grid_for(n / 4 + 1)), dim3(kThreads), 0, stream, msg, gout,
+             (float)(-2.0 * gscale / ((double)N * H * W)), dy, n);
+  return check_launch("scale_kernel");
+}
+
+extern "C" int wsl_tv_fwd_bwd(const float* p, int n0, float* loss, float* dp, float gscale, int N, int C, int H, int W,
+                              void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(p && loss && dp && N > 0 && C > 0 && H > 0 && W > 0 && n0 >= 0 && n0 < N, "tv_fwd_bwd: bad args");
+  const int HW_ = H * W;
+  WSL_WS_OK("tv_fwd_bwd");
+  const double numel = (double)(N - n0) * C * H * W;
+  TvP q{p, dp, n0, N, C, H, W, cdiv(W, 16), cdiv(H, 16), (float)(gscale / numel)};
+  const int nb = N * C * q.tiles_x * q.tiles_y;
+  float* part = static_cast<float*>(ws);
+  WSL_LAUNCH(tv_fwd_bwd_kernel, dim3(nb), dim3(kThreads), 0, stream, q, part);
+  WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, 1, 1.0 / numel, loss);
+  return check_launch("tv_fwd_bwd");
+}
+
+extern "C" int wsl_mumford_shah_fwd_bwd(const float* img, const float* p, float* loss, float* dp, float gscale, int N,
+                                        int C, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(img && p && loss && dp && N > 0 && C > 0 && C <= kMaxC && H > 0 && W > 0, "mumford_shah: bad args");
+  const int HW_ = H * W;
+  WSL_WS_OK("mumford_shah_fwd_bwd");
+  const int chunks = cdiv(H * W, 4096);
+  float* part = static_cast<float*>(ws);
+  float* mom = part + (size_t)kMaxBlocks * kMaxK + 64;
+  if ((size_t)N * chunks * 2 > (size_t)kMaxBlocks * kMaxK) {
+    set_error("mumford_shah: N*chunks too large for the partial buffer");
+    return WSL_EUNSUPPORTED;
+  }
+  WSL_LAUNCH(ms_moment_kernel, dim3(chunks, N), dim3(kThreads), 0, stream, img, p, C, H * W, chunks, mom);
+  WSL_LAUNCH(ms_main_kernel, dim3(chunks, N), dim3(kThreads), 0, stream, img, p, mom, C, H, W, chunks, gscale, dp, part);
+  WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, N * chunks, 2, 1.0, loss);
+  return check_launch("mumford_shah_fwd_bwd");
+}
+
+extern "C" int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* loss, float* da, float gscale, int N, int C,
+                                       int HW, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(a && b && loss && da && N > 0 && C > 0 && C <= kMaxC && HW > 0, "softmax_mse: bad args");
+  const int HW_ = HW;
+  WSL_WS_OK("softmax_mse_fwd_bwd");
+  const int64_t P = (int64_t)N * HW;
+  const double numel = (double)P * C;
+  const int nb = grid_for(P);
+  float* part = static_cast<float*>(ws);
+  WSL_LAUNCH(softmax_mse_kernel, dim3(nb), dim3(kThreads), 0, stream, a, b, C, HW, P, (float)(gscale / numel), da, part);
+  WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, 1, 1.0 / numel, loss);
+  return check_launch("softmax_mse_fwd_bwd");
+}
