@@ -1,0 +1,65 @@
+"""Helpers shared by the network-level tests: arenas from the C ABI's entry table."""
+import ctypes as C
+
+import numpy as np
+
+from detinit import det_state, sample_index
+from wsl4mis_amd import _lib
+
+
+def net_desc(net, N, H, W, in_chns=1, n_class=4):
+    return _lib.WslNetDesc(in_chns, n_class, 2 if net == "unet_cct" else 1, N, H, W)
+
+
+def entries(lib, d):
+    out = []
+    for i in range(lib.wsl_net_num_entries(C.byref(d))):
+        e = _lib.WslNetEntry()
+        assert lib.wsl_net_entry(C.byref(d), i, C.byref(e)) == 0
+        out.append((e.name.decode(), e.kind, tuple(e.shape[k] for k in range(e.ndim)), e.offset))
+    return out
+
+
+def det_arenas(lib, d, seed):
+    """(params, buffers, nbt, entries) filled with the deterministic state used by the golden generator."""
+    ents = entries(lib, d)
+    vals = det_state({n: s for n, _, s, _ in ents}, seed)
+    params = np.zeros(lib.wsl_net_param_count(C.byref(d)), np.float32)
+    bufs = np.zeros(lib.wsl_net_buffer_count(C.byref(d)), np.float32)
+    nbt = np.zeros(sum(1 for e in ents if e[1] == 2), np.int64)
+    for n, kind, shape, off in ents:
+        v = np.asarray(vals[n])
+        if kind == 0:
+            params[off:off + v.size] = v.ravel()
+        elif kind == 1:
+            bufs[off:off + v.size] = v.ravel()
+        else:
+            nbt[off] = int(v)
+    return params, bufs, nbt, ents
+
+
+def ptr_array(be, arrs):
+    """const T* const* from a list of device arrays (or None)."""
+    if arrs is None:
+        return None
+    a = (C.c_void_p * len(arrs))(*[be.ptr(x) if x is not None else None for x in arrs])
+    return a
+
+
+def check_grads(g, grads, ents, grad_tol, prefix="g."):
+    bad = []
+    for n, kind, shape, off in ents:
+        if kind != 0:
+            continue
+        size = int(np.prod(shape)) if shape else 1
+        got = grads[off:off + size]
+        ref = g[f"{prefix}{n}"]
+        err = float(np.max(np.abs(got[sample_index(size)] - ref)))
+        if err > grad_tol(n, ref):
+            bad.append((n, err, float(np.max(np.abs(ref)))))
+        nrm = g[f"{prefix.replace('g.', 'gn.')}{n}"] if f"{prefix.replace('g.', 'gn.')}{n}" in g else None
+        if nrm is not None and nrm[0] > 1e-4:
+            got_n = np.sqrt((got.astype(np.float64) ** 2).sum())
+            if abs(got_n - nrm[0]) > 2e-4 * nrm[0] + 1e-6:
+                bad.append((n + " (norm)", got_n, nrm[0]))
+    return bad

@@ -1,0 +1,450 @@
+// UNet / UNet_CCT forward + backward over flat arenas (ref: networks/unet.py:71-135 Encoder/Decoder, :286-303 UNet,
+// :327-346 UNet_CCT; factory networks/net_factory.py:6-22).  Host-side sequencing only: every arithmetic step is one of
+// the kernels of this library enqueued on the caller's stream; nothing here allocates or synchronises.
+//
+// What is kept in HBM between forward and backward: the raw (pre-BatchNorm) output of every convolution, the pooled
+// encoder inputs, the 1x1-conv / upsampled decoder tensors and 4*C BatchNorm coefficients per layer.  Normalised /
+// activated / dropped-out / concatenated tensors are never materialised: consumers rebuild them while staging tiles.
+#include <stdio.h>
+#include <string.h>
+#include <initializer_list>
+
+#include "wsl_rt.h"
+
+namespace wsl {
+
+static const int kFt[5] = {16, 32, 64, 128, 256};            // unet.py:291
+static const float kDrop[5] = {0.05f, 0.1f, 0.2f, 0.3f, 0.5f};  // unet.py:292
+static const float kEps = 1e-5f, kMom = 0.1f;
+
+struct ConvRef { int64_t w, b; int Ci, Co, ks; };
+struct BnRef { int64_t gamma, beta, rmean, rvar; int nbt, C; };
+struct BlockRef { ConvRef c1, c2; BnRef b1, b2; };
+struct BlkWs { size_t y1, y2, st1, st2; };  // st*: mean | invstd | scale | shift (4*C floats)
+
+struct Plan {
+  WslNetDesc d;
+  int H[5], W[5];
+  BlockRef enc[5];
+  struct Dec { ConvRef c1x1[4]; BlockRef blk[4]; ConvRef out; } dec[2];
+  int64_t n_param, n_enc_param, n_buf, n_bn;
+  // workspace (float offsets)
+  BlkWs wenc[5];
+  size_t pooled[5];
+  struct DecWs { size_t u[4], up[4], dcat[4], glow4; BlkWs blk[4]; } wdec[2];
+  size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws;
+  size_t wg_bytes, bn_bytes, total_floats;
+};
+
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t n) {
+    const size_t o = off;
+    off += (n + 63) & ~(size_t)63;
+    return o;
+  }
+};
+
+static void plan_conv(ConvRef& c, int Ci, int Co, int ks, int64_t& po) {
+  c.Ci = Ci, c.Co = Co, c.ks = ks;
+  c.w = po, po += (int64_t)Co * Ci * ks * ks;
+  c.b = po, po += Co;
+}
+static void plan_bn(BnRef& b, int C, int64_t& po, int64_t& bo, int64_t& nbn) {
+  b.C = C;
+  b.gamma = po, po += C;
+  b.beta = po, po += C;
+  b.rmean = bo, bo += C;
+  b.rvar = bo, bo += C;
+  b.nbt = (int)nbn++;
+}
+static void plan_block(BlockRef& k, int Ci, int Co, int64_t& po, int64_t& bo, int64_t& nbn) {
+  plan_conv(k.c1, Ci, Co, 3, po);
+  plan_bn(k.b1, Co, po, bo, nbn);
+  plan_conv(k.c2, Co, Co, 3, po);
+  plan_bn(k.b2, Co, po, bo, nbn);
+}
+
+static int make_plan(const WslNetDesc* d, Plan& P) {
+  WSL_REQUIRE(d, "net: null descriptor");
+  WSL_REQUIRE(d->n_dec == 1 || d->n_dec == 2, "net: n_dec must be 1 (unet) or 2 (unet_cct)");
+  WSL_REQUIRE(d->in_chns > 0 && d->n_class > 0 && d->n_class <= 8, "net: bad channel counts");
+  WSL_REQUIRE(d->N > 0 && d->H >= 16 && d->W >= 16 && d->H % 16 == 0 && d->W % 16 == 0,
+              "net: N=%d H=%d W=%d (H, W must be multiples of 16)", d->N, d->H, d->W);
+  P.d = *d;
+  for (int l = 0; l < 5; ++l) P.H[l] = d->H >> l, P.W[l] = d->W >> l;
+  int64_t po = 0, bo = 0, nbn = 0;
+  plan_block(P.enc[0], d->in_chns, kFt[0], po, bo, nbn);
+  for (int l = 1; l < 5; ++l) plan_block(P.enc[l], kFt[l - 1], kFt[l], po, bo, nbn);
+  P.n_enc_param = po;
+  for (int k = 0; k < d->n_dec; ++k) {
+    for (int i = 0; i < 4; ++i) {  // stage i+1 ("up{i+1}"): level 3-i, C1 = ft[4-i] -> C2 = ft[3-i]
+      const int c1 = kFt[4 - i], c2 = kFt[3 - i];
+      plan_conv(P.dec[k].c1x1[i], c1, c2, 1, po);
+      plan_block(P.dec[k].blk[i], 2 * c2, c2, po, bo, nbn);
+    }
+    plan_conv(P.dec[k].out, kFt[0], d->n_class, 3, po);
+  }
+  P.n_param = po, P.n_buf = bo, P.n_bn = nbn;
+
+  // ---- workspace
+  Bump B;
+  const size_t N = d->N;
+  size_t max_stat = 0, max_cnt = 0;
+  P.wg_bytes = 0, P.bn_bytes = 0;
+  auto plan_blkws = [&](BlkWs& w, const BlockRef& k, int l) {
+    const size_t e = N * k.c1.Co * P.H[l] * P.W[l];
+    w.y1 = B.take(e), w.y2 = B.take(e);
+    w.st1 = B.take(4 * k.c1.Co), w.st2 = B.take(4 * k.c1.Co);
+    for (const ConvRef* c : {&k.c1, &k.c2}) {
+      const size_t nb = wsl_conv2d_stat_blocks(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
+      if (nb * c->Co * 2 > max_stat) max_stat = nb * c->Co * 2;
+      if (nb > max_cnt) max_cnt = nb;
+      const size_t wb = wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
+      if (wb > P.wg_bytes) P.wg_bytes = wb;
+    }
+    const size_t bb = wsl_bnact_bwd_ws_bytes(d->N, k.c1.Co, P.H[l], P.W[l]);
+    if (bb > P.bn_bytes) P.bn_bytes = bb;
+  };
+  for (int l = 0; l < 5; ++l) {
+    plan_blkws(P.wenc[l], P.enc[l], l);
+    P.pooled[l] = l ? B.take(N * kFt[l - 1] * P.H[l] * P.W[l]) : 0;
+  }
+  for (int k = 0; k < d->n_dec; ++k) {
+    for (int i = 0; i < 4; ++i) {
+      const int l = 3 - i, c2 = kFt[l];
+      P.wdec[k].u[i] = B.take(N * c2 * P.H[l + 1] * P.W[l + 1]);
+      P.wdec[k].up[i] = B.take(N * c2 * P.H[l] * P.W[l]);
+      P.wdec[k].dcat[i] = B.take(N * 2 * c2 * P.H[l] * P.W[l]);
+      plan_blkws(P.wdec[k].blk[i], P.dec[k].blk[i], l);
+      const size_t wb = wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l + 1], P.W[l + 1], kFt[l + 1], c2, 1);
+      if (wb > P.wg_bytes) P.wg_bytes = wb;
+    }
+    P.wdec[k].glow4 = B.take(N * kFt[4] * P.H[4] * P.W[4]);
+    const size_t wb = wsl_conv2d_wgrad_ws_bytes(d->N, P.H[0], P.W[0], kFt[0], d->n_class, 3);
+    if (wb > P.wg_bytes) P.wg_bytes = wb;
+  }
+  const size_t big = N * kFt[0] * P.H[0] * P.W[0];  // largest activation (level 0; every deeper level is <= half)
+  P.tmp_g = B.take(big), P.tmp_g1 = B.take(big), P.tmp_dy = B.take(big);
+  P.tmp_du = B.take(big / 4), P.tmp_gpool = B.take(big / 4);
+  P.stat_part = B.take(max_stat), P.stat_cnt = B.take(max_cnt);
+  P.wg_ws = B.take((P.wg_bytes + 3) / 4), P.bn_ws = B.take((P.bn_bytes + 3) / 4);
+  P.total_floats = B.off;
+  return WSL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+struct Ctx {
+  const Plan& P;
+  const float* params;
+  float* buffers;
+  int64_t* nbt;
+  float* grads;
+  float* ws;
+  void* stream;
+  int training;
+};
+
+static WslSrc raw_src(const float* x, int C, int64_t bs) {
+  WslSrc s{};
+  s.x = x, s.C = C, s.bs = bs, s.emask_scale = 1.f;
+  return s;
+}
+// virtual tensor leaky(bn(y)) [* emask] [* cmask]
+static WslSrc act_src(const Ctx& c, size_t y, size_t st, int C, int HW, const uint8_t* emask, float es, const float* cmask) {
+  WslSrc s{};
+  s.x = c.ws + y, s.C = C, s.bs = (int64_t)C * HW;
+  s.scale = c.ws + st + 2 * C, s.shift = c.ws + st + 3 * C;
+  s.emask = emask, s.emask_scale = es, s.cmask = cmask;
+  return s;
+}
+
+#define WSL_TRY(expr)           \
+  do {                          \
+    if (int rc_ = (expr)) return rc_; \
+  } while (0)
+
+// conv + (train: batch statistics -> BN coefficients | eval: running statistics)
+static int conv_bn_fwd(const Ctx& c, const ConvRef& cv, const BnRef& bn, const WslSrc* a, const WslSrc* b, size_t y,
+                       size_t st, int H, int W) {
+  const Plan& P = c.P;
+  const int N = P.d.N, C = cv.Co;
+  float* stp = c.training ? c.ws + P.stat_part : nullptr;
+  float* stc = c.training ? c.ws + P.stat_cnt : nullptr;
+  WSL_TRY(wsl_conv2d_fwd(a, b, c.params + cv.w, c.params + cv.b, c.ws + y, (int64_t)C * H * W, N, H, W, C, cv.ks, 0, stp,
+                         stc, c.stream));
+  float* s = c.ws + st;
+  if (c.training) {
+    const int nblk = wsl_conv2d_stat_blocks(N, H, W, cv.Ci, C, cv.ks);
+    return wsl_bn_stats_finalize(stp, stc, nblk, C, c.params + bn.gamma, c.params + bn.beta, kEps, kMom,
+                                 c.buffers + bn.rmean, c.buffers + bn.rvar, c.nbt ? c.nbt + bn.nbt : nullptr, s, s + C,
+                                 s + 2 * C, s + 3 * C, c.stream);
+  }
+  return wsl_bn_eval_affine(c.params + bn.gamma, c.params + bn.beta, c.buffers + bn.rmean, c.buffers + bn.rvar, kEps, C,
+                            s + 2 * C, s + 3 * C, c.stream);
+}
+
+static int block_fwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslSrc* a, const WslSrc* b, int l,
+                     const uint8_t* emask, float es) {
+  const int H = c.P.H[l], W = c.P.W[l], C = k.c1.Co;
+  WSL_TRY(conv_bn_fwd(c, k.c1, k.b1, a, b, w.y1, w.st1, H, W));
+  const WslSrc mid = act_src(c, w.y1, w.st1, C, H * W, c.training ? emask : nullptr, es, nullptr);
+  return conv_bn_fwd(c, k.c2, k.b2, &mid, nullptr, w.y2, w.st2, H, W);
+}
+
+// backward of one ConvBlock given g = dL/d(block output) in `g` (batch stride g_bs).  Writes parameter grads;
+// if dgrad_out != NULL also d(block input) (all Ci channels, dense).
+static int block_bwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslSrc* a, const WslSrc* b, int l,
+                     const uint8_t* emask, float es, const float* g, int64_t g_bs, float* dgrad_out) {
+  const Plan& P = c.P;
+  const int N = P.d.N, H = P.H[l], W = P.W[l], C = k.c1.Co;
+  const int64_t CHW = (int64_t)C * H * W;
+  float* dy = c.ws + P.tmp_dy;
+  float* g1 = c.ws + P.tmp_g1;
+  const float* s1 = c.ws + w.st1;
+  const float* s2 = c.ws + w.st2;
+  // BN2 + LeakyReLU (no dropout after the second activation)
+  WSL_TRY(wsl_bnact_bwd(g, g_bs, c.ws + w.y2, s2, s2 + C, c.params + k.b2.gamma, c.params + k.b2.beta, nullptr, 1.f, dy,
+                        c.grads + k.b2.gamma, c.grads + k.b2.beta, N, C, H, W, c.ws + P.bn_ws, P.bn_bytes, c.stream));
+  const WslSrc mid = act_src(c, w.y1, w.st1, C, H * W, emask, es, nullptr);
+  WSL_TRY(wsl_conv2d_wgrad(&mid, nullptr, dy, CHW, c.grads + k.c2.w, c.grads + k.c2.b, N, H, W, C, 3, c.ws + P.wg_ws,
+                           P.wg_bytes, c.stream));
+  const WslSrc dys = raw_src(dy, C, CHW);
+  WSL_TRY(wsl_conv2d_fwd(&dys, nullptr, c.params + k.c2.w, nullptr, g1, CHW, N, H, W, C, 3, 1, nullptr, nullptr, c.stream));
+  // BN1 + LeakyReLU + Dropout(p)
+  WSL_TRY(wsl_bnact_bwd(g1, CHW, c.ws + w.y1, s1, s1 + C, c.params + k.b1.gamma, c.params + k.b1.beta, emask, es, dy,
+                        c.grads + k.b1.gamma, c.grads + k.b1.beta, N, C, H, W, c.ws + P.bn_ws, P.bn_bytes, c.stream));
+  WSL_TRY(wsl_conv2d_wgrad(a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, N, H, W, C, 3, c.ws + P.wg_ws, P.wg_bytes,
+                           c.stream));
+  if (dgrad_out) {
+    const WslSrc dys1 = raw_src(dy, C, CHW);
+    WSL_TRY(wsl_conv2d_fwd(&dys1, nullptr, c.params + k.c1.w, nullptr, dgrad_out, (int64_t)k.c1.Ci * H * W, N, H, W,
+                           k.c1.Ci, 3, 1, nullptr, nullptr, c.stream));
+  }
+  return WSL_OK;
+}
+
+static WslSrc feat_src(const Ctx& c, int l, const float* cmask) {
+  return act_src(c, c.P.wenc[l].y2, c.P.wenc[l].st2, kFt[l], c.P.H[l] * c.P.W[l], nullptr, 1.f, cmask);
+}
+
+static int decoder_fwd(const Ctx& c, int k, const float* const* cmasks, float* logits) {
+  const Plan& P = c.P;
+  const int N = P.d.N;
+  for (int i = 0; i < 4; ++i) {
+    const int l = 3 - i, c1 = kFt[l + 1], c2 = kFt[l];
+    const int h = P.H[l + 1], w = P.W[l + 1], H = P.H[l], W = P.W[l];
+    const WslSrc low = i == 0 ? feat_src(c, 4, cmasks ? cmasks[4] : nullptr)
+                              : act_src(c, P.wdec[k].blk[i - 1].y2, P.wdec[k].blk[i - 1].st2, c1, h * w, nullptr, 1.f, nullptr);
+    const ConvRef& cv = P.dec[k].c1x1[i];
+    WSL_TRY(wsl_conv2d_fwd(&low, nullptr, c.params + cv.w, c.params + cv.b, c.ws + P.wdec[k].u[i], (int64_t)c2 * h * w, N,
+                           h, w, c2, 1, 0, nullptr, nullptr, c.stream));
+    WSL_TRY(wsl_bilinear_up2_fwd(c.ws + P.wdec[k].u[i], c.ws + P.wdec[k].up[i], (int64_t)c2 * H * W, N, c2, h, w, c.stream));
+    const WslSrc skip = feat_src(c, l, cmasks ? cmasks[l] : nullptr);
+    const WslSrc up = raw_src(c.ws + P.wdec[k].up[i], c2, (int64_t)c2 * H * W);
+    WSL_TRY(block_fwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f));
+  }
+  const WslSrc last = act_src(c, P.wdec[k].blk[3].y2, P.wdec[k].blk[3].st2, kFt[0], P.H[0] * P.W[0], nullptr, 1.f, nullptr);
+  const ConvRef& oc = P.dec[k].out;
+  return wsl_conv2d_fwd(&last, nullptr, c.params + oc.w, c.params + oc.b, logits, (int64_t)oc.Co * P.H[0] * P.W[0], N, P.H[0],
+                        P.W[0], oc.Co, 3, 0, nullptr, nullptr, c.stream);
+}
+
+static int decoder_bwd(const Ctx& c, int k, const float* const* cmasks, const float* dlogits) {
+  const Plan& P = c.P;
+  const int N = P.d.N, H0 = P.H[0], W0 = P.W[0];
+  float* g = c.ws + P.tmp_g;
+  const ConvRef& oc = P.dec[k].out;
+  const WslSrc last = act_src(c, P.wdec[k].blk[3].y2, P.wdec[k].blk[3].st2, kFt[0], H0 * W0, nullptr, 1.f, nullptr);
+  WSL_TRY(wsl_conv2d_wgrad(&last, nullptr, dlogits, (int64_t)oc.Co * H0 * W0, c.grads + oc.w, c.grads + oc.b, N, H0, W0,
+                           oc.Co, 3, c.ws + P.wg_ws, P.wg_bytes, c.stream));
+  const WslSrc dl = raw_src(dlogits, oc.Co, (int64_t)oc.Co * H0 * W0);
+  WSL_TRY(wsl_conv2d_fwd(&dl, nullptr, c.params + oc.w, nullptr, g, (int64_t)kFt[0] * H0 * W0, N, H0, W0, kFt[0], 3, 1,
+                         nullptr, nullptr, c.stream));
+  for (int i = 3; i >= 0; --i) {
+    const int l = 3 - i, c1 = kFt[l + 1], c2 = kFt[l];
+    const int h = P.H[l + 1], w = P.W[l + 1], H = P.H[l], W = P.W[l];
+    const WslSrc skip = feat_src(c, l, cmasks ? cmasks[l] : nullptr);
+    const WslSrc up = raw_src(c.ws + P.wdec[k].up[i], c2, (int64_t)c2 * H * W);
+    float* dcat = c.ws + P.wdec[k].dcat[i];
+    WSL_TRY(block_bwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f, g, (int64_t)c2 * H * W, dcat));
+    // d(up) = dcat[:, c2:]  ->  d(u)  ->  conv1x1 backward
+    float* du = c.ws + P.tmp_du;
+    WSL_TRY(wsl_bilinear_up2_bwd(dcat + (int64_t)c2 * H * W, (int64_t)2 * c2 * H * W, du, N, c2, h, w, c.stream));
+    const WslSrc low = i == 0 ? feat_src(c, 4, cmasks ? cmasks[4] : nullptr)
+                              : act_src(c, P.wdec[k].blk[i - 1].y2, P.wdec[k].blk[i - 1].st2, c1, h * w, nullptr, 1.f, nullptr);
+    const ConvRef& cv = P.dec[k].c1x1[i];
+    WSL_TRY(wsl_conv2d_wgrad(&low, nullptr, du, (int64_t)c2 * h * w, c.grads + cv.w, c.grads + cv.b, N, h, w, c2, 1,
+                             c.ws + P.wg_ws, P.wg_bytes, c.stream));
+    const WslSrc dus = raw_src(du, c2, (int64_t)c2 * h * w);
+    float* glow = i == 0 ? c.ws + P.wdec[k].glow4 : g;
+    WSL_TRY(wsl_conv2d_fwd(&dus, nullptr, c.params + cv.w, nullptr, glow, (int64_t)c1 * h * w, N, h, w, c1, 1, 1, nullptr,
+                           nullptr, c.stream));
+  }
+  return WSL_OK;
+}
+
+static int encoder_bwd(const Ctx& c, const float* x, const uint8_t* const* emasks, const float* const* cmasks) {
+  const Plan& P = c.P;
+  const int N = P.d.N;
+  const bool dual = P.d.n_dec == 2;
+  float* g = c.ws + P.tmp_g;
+  float* gpool = c.ws + P.tmp_gpool;
+  for (int l = 4; l >= 0; --l) {
+    const int C = kFt[l], H = P.H[l], W = P.W[l];
+    const WslSrc f = feat_src(c, l, nullptr);
+    const float *ga, *gb = nullptr;
+    int64_t bs;
+    if (l == 4) {
+      ga = c.ws + P.wdec[0].glow4, bs = (int64_t)C * H * W;
+      if (dual) gb = c.ws + P.wdec[1].glow4;
+    } else {
+      const int i = 3 - l;
+      ga = c.ws + P.wdec[0].dcat[i], bs = (int64_t)2 * C * H * W;
+      if (dual) gb = c.ws + P.wdec[1].dcat[i];
+    }
+    WSL_TRY(wsl_feat_grad_combine(&f, ga, bs, gb, bs, dual ? cmasks[l] : nullptr, l < 4 ? gpool : nullptr, g, N, H, W,
+                                  c.stream));
+    const WslSrc in = l == 0 ? raw_src(x, P.d.in_chns, (int64_t)P.d.in_chns * H * W)
+                             : raw_src(c.ws + P.pooled[l], kFt[l - 1], (int64_t)kFt[l - 1] * H * W);
+    WSL_TRY(block_bwd(c, P.enc[l], P.wenc[l], &in, nullptr, l, emasks[l], 1.f / (1.f - kDrop[l]), g, (int64_t)C * H * W,
+                      l > 0 ? gpool : nullptr));
+  }
+  return WSL_OK;
+}
+
+}  // namespace wsl
+
+using namespace wsl;
+
+static void entry_set(WslNetEntry* e, const char* name, int kind, int ndim, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
+                      int64_t off) {
+  memset(e, 0, sizeof(*e));
+  snprintf(e->name, sizeof(e->name), "%s", name);
+  e->kind = kind, e->ndim = ndim, e->offset = off;
+  e->shape[0] = s0, e->shape[1] = s1, e->shape[2] = s2, e->shape[3] = s3;
+}
+
+// state_dict order of the reference module (7 entries per conv+bn pair, see oracle/torch_ref.py:state_layout)
+static int enumerate_entries(const Plan& P, int want, WslNetEntry* out) {
+  int idx = 0;
+  char nm[128];
+  auto conv = [&](const char* pre, const char* sfx, const ConvRef& c) {
+    snprintf(nm, sizeof(nm), "%s%s.weight", pre, sfx);
+    if (idx++ == want) entry_set(out, nm, 0, 4, c.Co, c.Ci, c.ks, c.ks, c.w);
+    snprintf(nm, sizeof(nm), "%s%s.bias", pre, sfx);
+    if (idx++ == want) entry_set(out, nm, 0, 1, c.Co, 0, 0, 0, c.b);
+  };
+  auto bn = [&](const char* pre, const char* sfx, const BnRef& b) {
+    const char* f[5] = {"weight", "bias", "running_mean", "running_var", "num_batches_tracked"};
+    const int64_t off[5] = {b.gamma, b.beta, b.rmean, b.rvar, b.nbt};
+    const int kind[5] = {0, 0, 1, 1, 2};
+    for (int k = 0; k < 5; ++k) {
+      snprintf(nm, sizeof(nm), "%s%s.%s", pre, sfx, f[k]);
+      if (idx++ == want) entry_set(out, nm, kind[k], k == 4 ? 0 : 1, k == 4 ? 0 : b.C, 0, 0, 0, off[k]);
+    }
+  };
+  auto block = [&](const char* pre, const BlockRef& k) {
+    conv(pre, ".0", k.c1), bn(pre, ".1", k.b1), conv(pre, ".4", k.c2), bn(pre, ".5", k.b2);
+  };
+  char pre[96];
+  block("encoder.in_conv.conv_conv", P.enc[0]);
+  for (int l = 1; l < 5; ++l) {
+    snprintf(pre, sizeof(pre), "encoder.down%d.maxpool_conv.1.conv_conv", l);
+    block(pre, P.enc[l]);
+  }
+  for (int k = 0; k < P.d.n_dec; ++k) {
+    const char* dn = P.d.n_dec == 1 ? "decoder" : (k == 0 ? "main_decoder" : "aux_decoder1");
+    for (int i = 0; i < 4; ++i) {
+      snprintf(pre, sizeof(pre), "%s.up%d.conv1x1", dn, i + 1);
+      conv(pre, "", P.dec[k].c1x1[i]);
+      snprintf(pre, sizeof(pre), "%s.up%d.conv.conv_conv", dn, i + 1);
+      block(pre, P.dec[k].blk[i]);
+    }
+    snprintf(pre, sizeof(pre), "%s.out_conv", dn);
+    conv(pre, "", P.dec[k].out);
+  }
+  return idx;
+}
+
+extern "C" int wsl_net_num_entries(const WslNetDesc* d) {
+  Plan P;
+  if (make_plan(d, P)) return -1;
+  return enumerate_entries(P, -1, nullptr);
+}
+extern "C" int wsl_net_entry(const WslNetDesc* d, int i, WslNetEntry* out) {
+  Plan P;
+  WSL_TRY(make_plan(d, P));
+  WSL_REQUIRE(out && i >= 0, "net_entry: bad args");
+  const int n = enumerate_entries(P, i, out);
+  WSL_REQUIRE(i < n, "net_entry: index %d out of %d", i, n);
+  return WSL_OK;
+}
+extern "C" int64_t wsl_net_param_count(const WslNetDesc* d) {
+  Plan P;
+  return make_plan(d, P) ? -1 : P.n_param;
+}
+extern "C" int64_t wsl_net_encoder_param_count(const WslNetDesc* d) {
+  Plan P;
+  return make_plan(d, P) ? -1 : P.n_enc_param;
+}
+extern "C" int64_t wsl_net_buffer_count(const WslNetDesc* d) {
+  Plan P;
+  return make_plan(d, P) ? -1 : P.n_buf;
+}
+extern "C" size_t wsl_net_ws_bytes(const WslNetDesc* d) {
+  Plan P;
+  return make_plan(d, P) ? 0 : P.total_floats * sizeof(float);
+}
+
+extern "C" int wsl_net_forward(const WslNetDesc* d, const float* params, float* buffers, int64_t* nbt, const float* x,
+                               const uint8_t* const* emasks, const float* const* cmasks, int training, float* logits_main,
+                               float* logits_aux, void* ws, size_t ws_bytes, void* stream) {
+  Plan P;
+  WSL_TRY(make_plan(d, P));
+  WSL_REQUIRE(params && buffers && x && logits_main && ws, "net_forward: null argument");
+  WSL_REQUIRE(d->n_dec == 1 || (logits_aux && cmasks), "net_forward: unet_cct needs logits_aux and cmasks");
+  WSL_REQUIRE(!training || emasks, "net_forward: training needs the 5 dropout keep-masks");
+  if (ws_bytes < P.total_floats * sizeof(float)) {
+    set_error("net_forward: workspace %zu < %zu", ws_bytes, P.total_floats * sizeof(float));
+    return WSL_EWORKSPACE;
+  }
+  Ctx c{P, params, buffers, nbt, nullptr, static_cast<float*>(ws), stream, training};
+  const int N = d->N;
+  for (int l = 0; l < 5; ++l) {
+    const int H = P.H[l], W = P.W[l];
+    WslSrc in;
+    if (l == 0) {
+      in = raw_src(x, d->in_chns, (int64_t)d->in_chns * H * W);
+    } else {
+      const WslSrc prev = feat_src(c, l - 1, nullptr);
+      WSL_TRY(wsl_pool2_fwd(&prev, c.ws + P.pooled[l], N, P.H[l - 1], P.W[l - 1], stream));
+      in = raw_src(c.ws + P.pooled[l], kFt[l - 1], (int64_t)kFt[l - 1] * H * W);
+    }
+    WSL_TRY(block_fwd(c, P.enc[l], P.wenc[l], &in, nullptr, l, training ? emasks[l] : nullptr, 1.f / (1.f - kDrop[l])));
+  }
+  WSL_TRY(decoder_fwd(c, 0, nullptr, logits_main));
+  if (d->n_dec == 2) WSL_TRY(decoder_fwd(c, 1, cmasks, logits_aux));
+  return WSL_OK;
+}
+
+extern "C" int wsl_net_backward(const WslNetDesc* d, const float* params, const float* x, const uint8_t* const* emasks,
+                                const float* const* cmasks, const float* dlogits_main, const float* dlogits_aux,
+                                float* grads, void* ws, size_t ws_bytes, int phase, void* stream) {
+  Plan P;
+  WSL_TRY(make_plan(d, P));
+  WSL_REQUIRE(params && x && emasks && grads && ws, "net_backward: null argument");
+  WSL_REQUIRE(phase >= 0 && phase <= 2, "net_backward: phase %d", phase);
+  WSL_REQUIRE(phase == 2 || (dlogits_main && (d->n_dec == 1 || (dlogits_aux && cmasks))), "net_backward: missing dlogits");
+  if (ws_bytes < P.total_floats * sizeof(float)) {
+    set_error("net_backward: workspace %zu < %zu", ws_bytes, P.total_floats * sizeof(float));
+    return WSL_EWORKSPACE;
+  }
+  Ctx c{P, params, nullptr, nullptr, grads, static_cast<float*>(ws), stream, 1};
+  if (phase == 0 || phase == 1) {
+    WSL_TRY(decoder_bwd(c, 0, nullptr, dlogits_main));
+    if (d->n_dec == 2) WSL_TRY(decoder_bwd(c, 1, cmasks, dlogits_aux));
+  }
+  if (phase == 0 || phase == 2) WSL_TRY(encoder_bwd(c, x, emasks, cmasks));
+  return WSL_OK;
+}
