@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): training slices/sec of the dual-branch UNet (unet_cct) with partial-CE +
+GatedCRF on synthetic 256x256 4-class scribble slices, batch 64 per GPU, data-parallel over N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = masks -> forward -> loss head (+GatedCRF) -> backward -> gradient all-reduce -> SGD, i.e. one optimiser
+step on one batch of 64 slices per GPU, inputs resident in HBM.  Prints ONE JSON line on rank 0 with the `roofline`
+(HIP events around the dominant kernel family, recorded on the launch stream during the timed region) and, at N=1,
+the `cpu_baseline` (the oracle's torch-CPU restatement of the same step, timed on this box's host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce"])
+    ap.add_argument("--crf-radius", type=int, default=5, help="reference default 5 (11x11); 2 = the 5x5 of BASELINE.json")
+    ap.add_argument("--net", default="unet_cct", choices=["unet_cct", "unet"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (torch-CPU restatement of the reference step) on a bounded sample of the same workload."""
+    from oracle import torch_ref as R
+    n_thr = os.cpu_count() or 1
+    torch.set_num_threads(n_thr)
+    B, S = args.cpu_batch, args.size
+    g = torch.Generator().manual_seed(1)
+    sd = {}
+    for k, shp in R.state_layout(args.net, 1, 4):
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.int64)
+        elif k.endswith("running_var") or (k.split(".")[-2] in ("1", "5") and k.endswith("weight")):
+            sd[k] = torch.ones(shp)
+        elif len(shp) == 4:
+            sd[k] = torch.randn(shp, generator=g) * (1.0 / (shp[1] * shp[2] * shp[3]) ** 0.5)
+        else:
+            sd[k] = torch.zeros(shp)
+    tr = R.RefTrainer(sd, args.net)
+    from wsl4mis_amd.synthetic import scribble_labels
+    x = torch.rand((B, 1, S, S), generator=g)
+    lab = torch.from_numpy(scribble_labels(B, S, S, 5))
+    em = [(torch.rand((B, 16 << l, S >> l, S >> l), generator=g) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
+    cm = [(torch.rand((B, 16 << l), generator=g) >= 0.5).float() * 2 for l in range(5)]
+    crf = args.crf_radius if args.loss == "pce_gatedcrf" else None
+    if args.loss == "pce":
+        raise SystemExit("cpu baseline for --loss pce: use ours_proposed or pce_gatedcrf")
+    tr.step(x, lab, 0.4, em, cm, crf)                      # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_iters):
+        tr.step(x, lab, 0.4, em, cm, crf)
+    dt = time.perf_counter() - t0
+    return {"value": round(B * args.cpu_iters / dt, 3), "unit": "slices/s", "cores": n_thr, "kind": "port",
+            "sample": f"oracle/torch_ref.py RefTrainer (stock torch CPU ops), {args.net} {args.loss}, batch {B} at "
+                      f"{S}x{S}, 1 warm-up + {args.cpu_iters} timed steps, {n_thr} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path in the product)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from wsl4mis_amd import _lib
+    from wsl4mis_amd.engine import TrainEngine
+    from wsl4mis_amd.synthetic import batch
+    dev = torch.device("cuda", local)
+    torch.manual_seed(2022)                                   # same initial weights on every rank
+    eng = TrainEngine(args.net, 1, 4, base_lr=0.01, max_iterations=60000, loss=args.loss, crf_radius=args.crf_radius)
+    torch.manual_seed(2022 + 1000 * rank)                     # different dropout masks / data per rank
+    x, lab = batch(args.batch, args.size, args.size, 2022 + rank, dev)
+    random.seed(2022)                                         # identical beta stream on all ranks
+    for _ in range(args.warmup):
+        eng.step(x, lab, random.random() + 1e-10)
+    L = _lib.lib()
+    if not args.no_prof:
+        L.wsl_prof_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(x, lab, random.random() + 1e-10)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    losses = eng.losses()
+    rows = (_lib.WslProfRow * 6)()
+    roof, fams = None, {}
+    if not args.no_prof:
+        L.wsl_prof_report(rows, 6)
+        L.wsl_prof_enable(0)
+        for r in rows:
+            if r.calls:
+                fams[r.name.decode()] = {"calls": int(r.calls), "ms": round(r.ms, 3),
+                                         "avg_us": round(1e3 * r.ms / r.calls, 2),
+                                         "tflops": round(r.flops / (r.ms * 1e-3) / 1e12, 2) if r.flops else None,
+                                         "algo_GBps": round(r.bytes / (r.ms * 1e-3) / 1e9, 1)}
+        conv = [r for r in rows if r.calls and r.flops > 0]
+        if conv:
+            dom = max(conv, key=lambda r: r.ms)
+            ach = dom.flops / (dom.ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom.name.decode(), "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": int(dom.calls), "avg_launch_us": round(1e3 * dom.ms / dom.calls, 2),
+                    "flops_per_launch": dom.flops / dom.calls,
+                    "all_mfma_kernels_tflops": round(sum(r.flops for r in conv) / (sum(r.ms for r in conv) * 1e-3) / 1e12, 2),
+                    "all_mfma_kernels_ms_per_step": round(sum(r.ms for r in conv) / args.steps, 3)}
+    if rank == 0:
+        gflop = 28.98 if args.net == "unet_cct" else 17.68     # conv-stack training GFLOP/slice
+        value = args.batch * world * args.steps / dt
+        out = {"metric": "training slices/sec (256x256, bs64, unet_cct pCE+GatedCRF)", "value": round(value, 2),
+               "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{args.net} {args.loss}" + (f" r={args.crf_radius}" if args.loss == "pce_gatedcrf" else "")
+                          + f", {args.size}x{args.size}x1 4-class synthetic scribble slices, batch {args.batch}/GPU, SGD+poly LR",
+                          "global_batch": args.batch * world, "parallelism": f"dp{world}", "crf_radius": args.crf_radius},
+               "whole_step_conv_mfma_frac": round(value / world * gflop * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+               "roofline": roof, "kernels": fams, "last_losses": {k: round(v, 5) for k, v in losses.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,18 @@ int wsl_version(void);              /* 100*major + minor */
 const char* wsl_last_error(void);   /* thread-local, valid until the next failing call on this thread */
 const char* wsl_build_info(void);   /* "gfx950 hipcc ..." or "HOST-EMULATION (tests only)" */
 
+/* Opt-in measurement: HIP events bracket every launch of the heavy kernel families on the launch stream while
+ * enabled; wsl_prof_report() waits for those events (the library's only synchronising call) and fills one row per
+ * family with the launch count, summed duration and the ALGORITHMIC flops / bytes those launches covered. */
+#define WSL_PROF_FAMILIES 6
+typedef struct WslProfRow {
+  char name[48];
+  int64_t calls;
+  double ms, flops, bytes;
+} WslProfRow;
+int wsl_prof_enable(int on);                      /* also clears what was recorded so far */
+int wsl_prof_report(WslProfRow* rows, int max_rows);
+
 /* ------------------------------------------------------------------------------------------------ conv stack
  * One channel-range of a convolution's *virtual* input.  The loader applies, per element,
  *     v = x[n, c, y, x]
@@ -135,6 +147,13 @@ int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int
                      float gscale, float* out, int64_t* pseudo, float* dz1, float* dz2, int N, int C, int HW,
                      void* ws, size_t ws_bytes, void* stream);
 size_t wsl_loss_ws_bytes(int N, int C, int HW);
+
+/* y = beta*softmax(z1) + (1-beta)*softmax(z2) (z2 == NULL: softmax(z1)) -- the prediction the GatedCRF term regularises
+ * in the dual-branch composition (ref: train_ACDC_scribblevc.py:171-206; single branch: ...pCE_GatedCRFLoss_2D.py:112).
+ * Backward: dz_k (+)= softmax_bwd(s_k, w_k * k * dy), w_1 = beta, w_2 = 1-beta; accumulate != 0 adds into dz. */
+int wsl_mixprob_fwd(const float* z1, const float* z2, double beta, float* y, int N, int C, int HW, void* stream);
+int wsl_mixprob_bwd(const float* z1, const float* z2, double beta, const float* dy, float k, float* dz1, float* dz2,
+                    int accumulate, int N, int C, int HW, void* stream);
 
 /* ModelLossSemsegGatedCRF.forward, one {'weight','xy','rgb'} descriptor, Potts model, no masks, prediction at input
  * resolution (ref: utils/gate_crf_loss.py:20-124,135-188).  loss[0] = (sum K - sum y*msg)/(N*H*W);

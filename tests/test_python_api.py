@@ -1,0 +1,203 @@
+"""The host-side mirror of the reference interface (networks.net_factory, utils.losses, utils.gate_crf_loss, the
+fused engine): module structure, autograd wiring and end-to-end parity with the reference's golden vectors.
+`mode` = emul runs the Python layer against the host-emulation library with CPU tensors (host-logic check);
+`mode` = hip (gpu mark) is the real thing."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import get_backend, golden, grad_tol, rel_err
+from detinit import det_state, sample_index
+
+TOL = 1e-4
+
+
+@pytest.fixture(params=[pytest.param("emul"), pytest.param("hip", marks=pytest.mark.gpu)])
+def mode(request):
+    from wsl4mis_amd import _lib, runtime
+    _lib._reset_for_tests()
+    runtime._ws_cache.clear()
+    if request.param == "emul":
+        _lib.use_library_for_tests(get_backend("emul").lib)
+    yield request.param
+    _lib._reset_for_tests()
+    runtime._ws_cache.clear()
+
+
+def dev():
+    from wsl4mis_amd import runtime
+    return runtime.device()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def load_det(model, seed):
+    sd = model.state_dict()
+    vals = det_state({k: tuple(v.shape) for k, v in sd.items()}, seed)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+
+
+def test_net_factory_default_init_is_the_reference_init(mode):
+    from wsl4mis_amd.networks.net_factory import net_factory
+    g = golden("g0_init")
+    for net in ("unet", "unet_cct"):
+        torch.manual_seed(2022)
+        m = net_factory(net, 1, 4)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(g[f"{net}_keys"])
+        assert [str(tuple(v.shape)) for v in sd.values()] == list(g[f"{net}_shapes"])
+        sums = np.array([float(v.double().sum()) for v in sd.values()])
+        assert np.allclose(sums, g[f"{net}_sum"], rtol=0, atol=1e-9)          # same RNG draws, bit for bit
+        heads = np.stack([np.resize(v.double().cpu().numpy().ravel(), 4) for v in sd.values()])
+        assert np.array_equal(heads, g[f"{net}_head"])
+        assert [tuple(p.shape) for p in m.parameters()] == [tuple(v.shape) for k, v in sd.items()
+                                                            if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    assert net_factory("no_such_net") is None
+    with pytest.raises(NotImplementedError):
+        net_factory("unet_ds")
+
+
+def test_module_autograd_matches_reference_script_composition(mode):
+    """model(x) -> softmax -> CE + mixed pseudo-label pDice written exactly like ours_proposed.py:108-128, with the
+    drop-in modules; gradients land in p.grad through ordinary autograd; torch.optim.SGD updates the arena views."""
+    from wsl4mis_amd.networks.net_factory import net_factory
+    from wsl4mis_amd.utils import losses
+    g = golden("g2_cct32")
+    model = net_factory("unet_cct", 1, 4)
+    load_det(model, 2022)
+    model.train()
+    model.set_dropout_masks([T(g[f"emask{i}"]) for i in range(5)], [T(g[f"cmask{i}"]) for i in range(5)])
+    x, lab = T(g["x"]), T(g["label"])
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    ce_loss, dice_loss = losses.PartialCrossEntropyLoss(ignore_index=4), losses.pDLoss(4, ignore_index=4)
+    outputs, outputs_aux1 = model(x)
+    assert rel_err(outputs.detach().cpu(), g["logits_main"]) < TOL and rel_err(outputs_aux1.detach().cpu(), g["logits_aux"]) < TOL
+    s1, s2 = losses.softmax(outputs), losses.softmax(outputs_aux1)
+    loss_ce = 0.5 * (ce_loss(outputs, lab.long()) + ce_loss(outputs_aux1, lab.long()))
+    beta = float(g["beta"])
+    pseudo = losses.mix_argmax(s1, s2, beta)
+    loss_pse = 0.5 * (dice_loss(s1, pseudo.unsqueeze(1)) + dice_loss(s2, pseudo.unsqueeze(1)))
+    loss = loss_ce + 0.5 * loss_pse
+    opt.zero_grad()
+    loss.backward()
+    assert rel_err([loss.item(), loss_ce.item(), loss_pse.item()], g["loss_parts"]) < TOL
+    before = model.flat_params().clone()
+    for k, p in model.named_parameters():
+        gr = p.grad.detach().cpu().numpy().ravel()
+        ref = g[f"g.{k}"]
+        assert np.max(np.abs(gr[sample_index(gr.size)] - ref)) <= grad_tol(k, ref), k
+    opt.step()
+    assert not torch.equal(before, model.flat_params())            # the optimiser moved the arena through the views
+    # fused head == the composed form
+    model.zero_grad()
+    outputs, outputs_aux1 = model(x)
+    l2, parts, ps = losses.wsl_head(outputs, outputs_aux1, lab, beta)
+    assert torch.equal(ps, losses.mix_argmax(losses.softmax(outputs), losses.softmax(outputs_aux1), beta))
+    with pytest.raises(NotImplementedError):
+        model(x.clone().requires_grad_())
+
+
+def test_eval_and_state_dict_roundtrip(mode):
+    from wsl4mis_amd.networks.net_factory import net_factory
+    g = golden("g2_unet32")
+    m = net_factory("unet", 1, 4)
+    load_det(m, 2022)
+    m.train()
+    m.set_dropout_masks([T(g[f"emask{i}"]) for i in range(5)])
+    out = m(T(g["x"]))
+    assert rel_err(out.detach().cpu(), g["logits_main"]) < TOL
+    m.eval()
+    with torch.no_grad():
+        ev = m(T(g["x"]))
+    assert rel_err(ev.cpu(), g["logits_eval"]) < TOL
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in sd:
+        if k.endswith(("running_mean", "running_var")):
+            assert rel_err(sd[k].cpu(), g[f"b.{k}"]) < TOL
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == 4
+    m2 = net_factory("unet", 1, 4)
+    m2.load_state_dict(sd)
+    m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m2(T(g["x"])), ev)
+
+
+def test_loss_modules_against_reference(mode):
+    from wsl4mis_amd.utils import losses
+    from wsl4mis_amd.utils.gate_crf_loss import ModelLossSemsegGatedCRF
+    g = golden("g4_gatedcrf")
+    crf = ModelLossSemsegGatedCRF()
+    y = T(g["ns5_y"]).requires_grad_()
+    out = crf(y, [{"weight": 1, "xy": 6, "rgb": 0.1}], 5, T(g["ns5_img"]), 48, 40)["loss"]
+    (2.0 * out).backward()
+    assert rel_err(out.item(), g["ns5_loss"]) < TOL and rel_err(y.grad.cpu(), 2.0 * g["ns5_dy"]) < TOL
+    with pytest.raises(NotImplementedError):
+        crf(y, [{"weight": 1, "xy": 6, "rgb": 0.1}], 5, T(g["ns5_img"]), 48, 40, mask_src=T(g["ns5_img"]))
+    with pytest.raises(NotImplementedError):
+        crf(y, [{"weight": 1, "xy": 6}], 5, T(g["ns5_img"]), 48, 40)
+    with pytest.raises(AssertionError):
+        crf(y, [{"weight": 1, "xy": 6, "rgb": 0.1}], 5, T(g["ns5_img"]), 50, 40)
+    g = golden("g5_tv_ms")
+    p = T(g["tv_p"]).requires_grad_()
+    l = losses.tv_loss(p[1:])
+    l.backward()
+    assert rel_err(l.item(), g["tv_loss"]) < 1e-5 and rel_err(p.grad.cpu(), g["tv_dp"]) < 1e-5
+    p = T(g["ms_p"]).requires_grad_()
+    l = losses.MumfordShah_Loss()(T(g["ms_img"]), p)
+    (l * 1e-6).backward()
+    assert rel_err(l.item(), g["ms_loss"]) < 1e-5 and rel_err(p.grad.cpu(), 1e-6 * g["ms_dp"]) < TOL
+    g = golden("g3_head")
+    s = T(g["dl_s"]).requires_grad_()
+    l = losses.DiceLoss(4)(s, T(g["dl_target"]))
+    l.backward()
+    assert rel_err(l.item(), g["dl_loss"]) < 1e-5 and rel_err(s.grad.cpu(), g["dl_ds"]) < TOL
+    with pytest.raises(NotImplementedError):
+        losses.DiceLoss(4)(s, T(g["dl_target"]), weight=[1, 2, 1, 1])
+    a = T(g["mse_a"]).requires_grad_()
+    l = torch.mean(losses.softmax_mse_loss(a, T(g["mse_b"])))
+    l.backward()
+    assert rel_err(l.item(), g["mse_loss"]) < 1e-5 and rel_err(a.grad.cpu(), g["mse_da"]) < TOL
+    a2 = T(g["mse_a"]).requires_grad_()
+    l2 = losses.softmax_mse_mean(a2, T(g["mse_b"]))
+    l2.backward()
+    assert rel_err(l2.item(), g["mse_loss"]) < 1e-5 and rel_err(a2.grad.cpu(), g["mse_da"]) < TOL
+    from wsl4mis_amd.utils.ramps import sigmoid_rampup
+    assert abs(sigmoid_rampup(0, 200) - np.exp(-5.0)) < 1e-12 and sigmoid_rampup(300, 200) == 1.0
+
+
+def run_curve(steps):
+    from wsl4mis_amd.engine import TrainEngine
+    g = golden("g7_curve")
+    eng = TrainEngine("unet_cct", 1, 4, base_lr=0.01, max_iterations=60000, loss="ours_proposed")
+    load_det(eng.model, 7)
+    got = []
+    for it in range(steps):
+        xs = T(g["xs"][it])
+        N, _, H, W = xs.shape
+        em = [T(np.unpackbits(g[f"em{it}_{l}"])[:N * (16 << l) * (H >> l) * (W >> l)].reshape(N, 16 << l, H >> l, W >> l))
+              for l in range(5)]
+        cm = [T(g[f"cm{it}_{l}"]) for l in range(5)]
+        eng.model.set_dropout_masks(em, cm)
+        eng.step(xs, T(g["labels"][it]), float(g["betas"][it]))
+        o = eng.losses()
+        got.append([o["loss"], o["ce"], o["pse"]])
+    return np.array(got), g, eng
+
+
+def test_engine_loss_curve_start(mode):
+    """first optimiser steps of the fused engine vs the reference loop (SGD + poly LR incl. its one-step lag)."""
+    steps = 2 if mode == "emul" else 12
+    got, g, eng = run_curve(steps)
+    ref = g["losses"][:steps]
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < (1e-4 if steps == 2 else 2e-3), (got, ref)
+    if steps == 12:
+        sd = eng.model.state_dict()
+        for k in ("encoder.in_conv.conv_conv.0.weight", "main_decoder.out_conv.weight", "aux_decoder1.up1.conv1x1.bias",
+                  "encoder.down4.maxpool_conv.1.conv_conv.5.running_var"):
+            assert rel_err(sd[k].cpu().numpy().ravel()[:256], g[f"final.{k}"]) < 5e-3, k

@@ -17,6 +17,11 @@ class WslSrc(C.Structure):
                 ("shift", c_fp), ("emask", c_fp), ("emask_scale", C.c_float), ("_pad1", C.c_float), ("cmask", c_fp)]
 
 
+class WslProfRow(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("calls", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class WslNetDesc(C.Structure):
     _fields_ = [("in_chns", C.c_int32), ("n_class", C.c_int32), ("n_dec", C.c_int32), ("N", C.c_int32),
                 ("H", C.c_int32), ("W", C.c_int32)]
@@ -35,6 +40,8 @@ _PROTOS = {
     "wsl_version": (i32, []),
     "wsl_last_error": (C.c_char_p, []),
     "wsl_build_info": (C.c_char_p, []),
+    "wsl_prof_enable": (i32, [i32]),
+    "wsl_prof_report": (i32, [C.POINTER(WslProfRow), i32]),
     "wsl_conv2d_fwd": (i32, [PS, PS, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
     "wsl_conv2d_stat_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "wsl_conv2d_wgrad": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),
@@ -59,6 +66,8 @@ _PROTOS = {
     "wsl_head_fwd_bwd": (i32, [c_fp, c_fp, c_fp, i32, f64, f32, f32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, sz,
                                c_fp]),
     "wsl_loss_ws_bytes": (sz, [i32, i32, i32]),
+    "wsl_mixprob_fwd": (i32, [c_fp, c_fp, f64, c_fp, i32, i32, i32, c_fp]),
+    "wsl_mixprob_bwd": (i32, [c_fp, c_fp, f64, c_fp, f32, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "wsl_gatedcrf_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, f32, f32, c_fp, sz, c_fp]),
     "wsl_gatedcrf_bwd": (i32, [c_fp, c_fp, f32, c_fp, i32, i32, i32, i32, c_fp]),
     "wsl_tv_fwd_bwd": (i32, [c_fp, i32, c_fp, c_fp, f32, i32, i32, i32, i32, c_fp, sz, c_fp]),
@@ -111,6 +120,28 @@ def lib():
             raise WslError("refusing to use a host-emulation build as the product library")
         _lib = cdll
     return _lib
+
+
+_test_emul = False
+
+
+def use_library_for_tests(cdll):
+    """TEST HOOK ONLY: make the Python layer talk to the host-emulation build (tests/emul) with CPU tensors so the
+    host logic can be exercised without a GPU.  Never called by the package, bench.py or __graft_entry__."""
+    global _lib, _test_emul
+    bind(cdll, strict=False)
+    if b"HOST-EMULATION" not in cdll.wsl_build_info():
+        raise WslError("use_library_for_tests expects the emulation build")
+    _lib, _test_emul = cdll, True
+
+
+def _reset_for_tests():
+    global _lib, _test_emul
+    _lib, _test_emul = None, False
+
+
+def is_test_emulation():
+    return _test_emul
 
 
 def check(rc, cdll=None):

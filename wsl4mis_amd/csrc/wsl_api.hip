@@ -1,6 +1,9 @@
 // Error reporting / version entry points of libwslhip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <vector>
 
 #include "wsl_rt.h"
 
@@ -25,6 +28,71 @@ int check_launch(const char* what) {
 }
 
 }  // namespace wsl
+
+// ---------------------------------------------------------------------------------------------- opt-in profiling
+// HIP events around the launches of the heavy kernel families, recorded on the stream the kernel is launched on
+// (what bench.py's roofline object is computed from).  Off by default; wsl_prof_report() is the only call of the
+// library that synchronises (on its own events).
+namespace wsl {
+#ifndef WSL_HOST_EMUL
+struct ProfRec { int fam; double flops, bytes; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static const char* kFamNames[WSL_PROF_FAMILIES] = {"conv_mfma_kernel(fwd)", "conv_mfma_kernel(dgrad)", "wgrad_mfma_kernel",
+                                                   "wgrad_reduce_kernel", "gatedcrf_fwd_kernel", "other"};
+void* prof_begin(int fam, double flops, double bytes, void* stream) {
+  if (!g_prof_on) return nullptr;
+  ProfRec r{fam, flops, bytes, nullptr, nullptr};
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+  (void)hipEventRecord(r.a, (hipStream_t)stream);
+  g_prof.push_back(r);
+  return (void*)(uintptr_t)g_prof.size();
+}
+void prof_end(void* tok, void* stream) {
+  if (!tok) return;
+  (void)hipEventRecord(g_prof[(size_t)(uintptr_t)tok - 1].b, (hipStream_t)stream);
+}
+#else
+void* prof_begin(int, double, double, void*) { return nullptr; }
+void prof_end(void*, void*) {}
+#endif
+}  // namespace wsl
+
+extern "C" int wsl_prof_enable(int on) {
+#ifndef WSL_HOST_EMUL
+  for (auto& r : wsl::g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  wsl::g_prof.clear();
+  wsl::g_prof_on = on != 0;
+#else
+  (void)on;
+#endif
+  return WSL_OK;
+}
+
+extern "C" int wsl_prof_report(WslProfRow* rows, int max_rows) {
+  WSL_REQUIRE(rows && max_rows >= WSL_PROF_FAMILIES, "prof_report: need %d rows", WSL_PROF_FAMILIES);
+  for (int f = 0; f < WSL_PROF_FAMILIES; ++f) {
+    memset(&rows[f], 0, sizeof(WslProfRow));
+#ifndef WSL_HOST_EMUL
+    snprintf(rows[f].name, sizeof(rows[f].name), "%s", wsl::kFamNames[f]);
+#endif
+  }
+#ifndef WSL_HOST_EMUL
+  for (auto& r : wsl::g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    rows[r.fam].calls += 1;
+    rows[r.fam].ms += ms;
+    rows[r.fam].flops += r.flops;
+    rows[r.fam].bytes += r.bytes;
+  }
+#endif
+  return WSL_PROF_FAMILIES;
+}
 
 extern "C" int wsl_version(void) { return 100; }
 extern "C" const char* wsl_last_error(void) { return wsl::g_err; }

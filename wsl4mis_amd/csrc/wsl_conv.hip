@@ -237,7 +237,10 @@ static int launch_conv(ConvP& p, void* stream) {
     attr_done = true;
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Co, CO_T));
+  const double px = (double)p.N * p.in.H * p.in.W;
+  void* tok = prof_begin(p.wmode ? 1 : 0, 2.0 * px * p.Co * p.in.Ci * KS * KS, 4.0 * px * (p.Co + p.in.Ci), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
   return check_launch("conv_mfma_kernel");
 }
 
@@ -470,7 +473,10 @@ static int launch_wgrad(WgradP& p, const WgPlan& g, void* stream) {
     attr_done = true;
   }
   dim3 grid(g.co_blocks * g.ci_blocks, g.nsplit);
+  const double px = (double)p.N * p.in.H * p.in.W;
+  void* tok = prof_begin(2, 2.0 * px * p.Co * p.in.Ci * KS * KS, 4.0 * px * (p.Co + p.in.Ci), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
   return check_launch("wgrad_mfma_kernel");
 }
 
@@ -564,6 +570,8 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   // a ci-block beyond the first never writes db and a (co,ci) element outside the tensor is never written: no memset
   if (int rc = (ks == 3 ? dispatch_wgrad<3>(p, g, stream) : dispatch_wgrad<1>(p, g, stream))) return rc;
   const int64_t total = (int64_t)KK * Co * Ci + (db ? Co : 0);
+  void* tok = prof_begin(3, 0.0, 4.0 * (double)total * (g.nsplit + 1), stream);
+  struct EndProf { void* t; void* s; ~EndProf() { prof_end(t, s); } } endprof{tok, stream};
   if (g.nsplit >= 64) {
     WSL_LAUNCH((wgrad_reduce_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(kThreads), 0, stream, p.part_dw,
                p.part_db, dw, db, Co, Ci, KK, g.nsplit);

@@ -590,6 +590,46 @@ __global__ __launch_bounds__(256) void softmax_mse_kernel(const float* a, const 
   write_partials<1>(v, part, red);
 }
 
+// ------------------------------------------------------------------------------------------------ mixed probabilities
+// y = beta*softmax(z1) + (1-beta)*softmax(z2): the prediction the dual-branch + GatedCRF composition regularises
+// (ref: train_ACDC_scribblevc.py:171-206).  z2 == NULL: y = softmax(z1).
+__global__ __launch_bounds__(256) void mixprob_fwd_kernel(const float* z1, const float* z2, float bf, float omb, float* y,
+                                                          int C, int HW, int64_t P) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+    float s1[kMaxC], s2[kMaxC];
+    softmax_c(z1 + base, HW, C, s1);
+    if (z2) {
+      softmax_c(z2 + base, HW, C, s2);
+      for (int c = 0; c < C; ++c) y[base + (int64_t)c * HW] = __fadd_rn(__fmul_rn(bf, s1[c]), __fmul_rn(omb, s2[c]));
+    } else {
+      for (int c = 0; c < C; ++c) y[base + (int64_t)c * HW] = s1[c];
+    }
+  }
+}
+
+// dz_k (+)= softmax_bwd(s_k, w_k * k * dy)   with w_1 = beta, w_2 = 1-beta
+__global__ __launch_bounds__(256) void mixprob_bwd_kernel(const float* z1, const float* z2, float bf, float omb,
+                                                          const float* dy, float k, float* dz1, float* dz2, int accumulate,
+                                                          int C, int HW, int64_t P) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+    float g[kMaxC], s[kMaxC];
+    for (int c = 0; c < C; ++c) g[c] = k * dy[base + (int64_t)c * HW];
+    for (int br = 0; br < (z2 ? 2 : 1); ++br) {
+      const float wgt = z2 ? (br == 0 ? bf : omb) : 1.f;
+      float* dz = br == 0 ? dz1 : dz2;
+      softmax_c((br == 0 ? z1 : z2) + base, HW, C, s);
+      float dot = 0.f;
+      for (int c = 0; c < C; ++c) dot = fmaf(g[c], s[c], dot);
+      for (int c = 0; c < C; ++c) {
+        const float v = wgt * s[c] * (g[c] - dot);
+        dz[base + (int64_t)c * HW] = accumulate ? dz[base + (int64_t)c * HW] + v : v;
+      }
+    }
+  }
+}
+
 static int grid_for(int64_t n) {
   int64_t b = (n + kThreads - 1) / kThreads;
   return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
@@ -704,7 +744,9 @@ extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, fl
   const int TS = 16 + 2 * radius;
   const size_t smem = sizeof(float) * (size_t)(C + 1) * TS * TS;
   float* part = static_cast<float*>(ws);
+  void* tok = prof_begin(4, 0.0, 4.0 * (double)N * H * W * (2 * C + 1), stream);
   WSL_LAUNCH(gatedcrf_fwd_kernel, dim3(nb), dim3(kThreads), smem, stream, q, part);
+  prof_end(tok, stream);
   WSL_LAUNCH(gatedcrf_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, (double)N * H * W, loss);
   return check_launch("gatedcrf_fwd");
 }
@@ -762,4 +804,21 @@ extern "C" int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* lo
   WSL_LAUNCH(softmax_mse_kernel, dim3(nb), dim3(kThreads), 0, stream, a, b, C, HW, P, (float)(gscale / numel), da, part);
   WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, 1, 1.0 / numel, loss);
   return check_launch("softmax_mse_fwd_bwd");
+}
+
+extern "C" int wsl_mixprob_fwd(const float* z1, const float* z2, double beta, float* y, int N, int C, int HW, void* stream) {
+  WSL_REQUIRE(z1 && y && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "mixprob_fwd: bad args");
+  const int64_t P = (int64_t)N * HW;
+  WSL_LAUNCH(mixprob_fwd_kernel, dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), y,
+             C, HW, P);
+  return check_launch("mixprob_fwd_kernel");
+}
+
+extern "C" int wsl_mixprob_bwd(const float* z1, const float* z2, double beta, const float* dy, float k, float* dz1,
+                               float* dz2, int accumulate, int N, int C, int HW, void* stream) {
+  WSL_REQUIRE(z1 && dy && dz1 && (!z2 || dz2) && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "mixprob_bwd: bad args");
+  const int64_t P = (int64_t)N * HW;
+  WSL_LAUNCH(mixprob_bwd_kernel, dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta),
+             dy, k, dz1, dz2, accumulate, C, HW, P);
+  return check_launch("mixprob_bwd_kernel");
 }

@@ -29,6 +29,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 namespace wsl {
 
 void set_error(const char* fmt, ...);
+// opt-in HIP-event bracketing of one launch (wsl_api.hip); fam: 0 conv fwd, 1 conv dgrad, 2 wgrad, 3 wgrad reduce,
+// 4 gatedcrf, 5 other
+void* prof_begin(int fam, double flops, double bytes, void* stream);
+void prof_end(void* tok, void* stream);
 int check_launch(const char* what);
 
 #define WSL_REQUIRE(cond, ...)     \

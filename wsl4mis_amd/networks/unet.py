@@ -1,0 +1,223 @@
+"""HIP-backed UNet / UNet_CCT with the reference's module interface (ref: networks/unet.py:286-303, 327-346).
+
+Same constructor arguments, same forward return ((N,C,H,W) logits, or a pair for UNet_CCT), same state_dict keys /
+shapes / order (202 entries for unet_cct) and parameters() order, so reference checkpoints load both ways and
+`optim.SGD(model.parameters())`, `loss.backward()`, `model.train()/eval()` work unchanged.
+
+MI355X-first differences of form: all parameters are views into ONE flat fp32 arena (so the optimiser and the RCCL
+all-reduce see a single buffer), buffers likewise, and a forward is ONE autograd node that enqueues the whole HIP
+kernel sequence through the C ABI (wsl_net_forward / wsl_net_backward) instead of ~150 ATen ops.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .. import runtime as rt
+
+_FT = (16, 32, 64, 128, 256)
+_DROP = (0.05, 0.1, 0.2, 0.3, 0.5)
+
+
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        outs = mod._run_forward(x, keep_for_backward=True)
+        ctx.mod, ctx.x, ctx.token = mod, x, mod._fwd_token
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        mod = ctx.mod
+        if ctx.token != mod._fwd_token:
+            raise _lib.WslError("backward() after a newer training forward of the same module: the activations kept "
+                                "in the module's workspace were overwritten (use a second model instance)")
+        grads = mod._run_backward(ctx.x, gouts)
+        return (None, None) + grads
+
+
+class _HipUNet(nn.Module):
+    _n_dec = 1
+
+    def __init__(self, in_chns, class_num):
+        super().__init__()
+        self.in_chns, self.class_num = int(in_chns), int(class_num)
+        dev = rt.device()
+        d0 = self._desc(1, 16, 16)
+        L = rt.L()
+        n_ent = L.wsl_net_num_entries(C.byref(d0))
+        if n_ent <= 0:
+            raise _lib.WslError(L.wsl_last_error().decode())
+        self._entries = []
+        for i in range(n_ent):
+            e = _lib.WslNetEntry()
+            rt.call("wsl_net_entry", C.byref(d0), i, C.byref(e))
+            self._entries.append((e.name.decode(), e.kind, tuple(e.shape[k] for k in range(e.ndim)), e.offset))
+        self.n_param = L.wsl_net_param_count(C.byref(d0))
+        self.n_enc_param = L.wsl_net_encoder_param_count(C.byref(d0))
+        n_buf = L.wsl_net_buffer_count(C.byref(d0))
+        n_bn = sum(1 for e in self._entries if e[1] == 2)
+        # flat arenas (device memory); 64-float padding keeps float4 paths legal for any tail
+        self._param_arena = torch.zeros(self.n_param + 64, dtype=torch.float32, device=dev)
+        self._grad_arena = torch.zeros(self.n_param + 64, dtype=torch.float32, device=dev)
+        self._buf_arena = torch.zeros(n_buf + 64, dtype=torch.float32, device=dev)
+        self._nbt = torch.zeros(n_bn, dtype=torch.int64, device=dev)
+        self._build_tree()
+        self._default_init()
+        self._fwd_token = 0
+        self._forced_masks = None
+        self._last_masks = None
+
+    # ------------------------------------------------------------------ structure
+    def _desc(self, N, H, W):
+        return _lib.WslNetDesc(self.in_chns, self.class_num, self._n_dec, N, H, W)
+
+    def _build_tree(self):
+        """Container modules named after the reference's attribute path, so state_dict() keys are identical."""
+        self._plist = []
+        for name, kind, shape, off in self._entries:
+            *path, leaf = name.split(".")
+            m = self
+            for part in path:
+                if part not in m._modules:
+                    m.add_module(part, nn.Module())
+                m = m._modules[part]
+            n = int(math.prod(shape)) if shape else 1
+            if kind == 0:
+                p = nn.Parameter(self._param_arena[off:off + n].view(shape))
+                m.register_parameter(leaf, p)
+                self._plist.append((p, off, n, shape))
+            elif kind == 1:
+                m.register_buffer(leaf, self._buf_arena[off:off + n].view(shape))
+            else:
+                m.register_buffer(leaf, self._nbt[off])
+
+    @torch.no_grad()
+    def _default_init(self):
+        """nn.Conv2d / nn.BatchNorm2d default initialisation drawn from torch's global CPU generator in the reference's
+        construction order, so `torch.manual_seed(s); net_factory(...)` reproduces the reference's initial weights bit
+        for bit (ref: net_factory.py:9-10 builds the module on the CPU, then .cuda())."""
+        for name, kind, shape, off in self._entries:
+            n = int(math.prod(shape)) if shape else 1
+            if kind == 0 and len(shape) == 4:
+                w = torch.empty(shape)
+                nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                self._param_arena[off:off + n].copy_(w.view(-1))
+                self._pending_fan_in = shape[1] * shape[2] * shape[3]
+            elif kind == 0:
+                parts = name.split(".")
+                is_bn = parts[-2] in ("1", "5")
+                if is_bn:
+                    self._param_arena[off:off + n].fill_(1.0 if parts[-1] == "weight" else 0.0)
+                else:
+                    bound = 1 / math.sqrt(self._pending_fan_in)
+                    self._param_arena[off:off + n].copy_(torch.empty(shape).uniform_(-bound, bound))
+            elif kind == 1:
+                self._buf_arena[off:off + n].fill_(1.0 if name.endswith("running_var") else 0.0)
+        self._nbt.zero_()
+
+    def _ensure_arena(self):
+        """Re-attach parameters that were re-allocated behind our back (model.to(...), p.data = ...)."""
+        base = self._param_arena.data_ptr()
+        for p, off, n, shape in self._plist:
+            if p.data_ptr() != base + 4 * off:
+                if p.device != self._param_arena.device or p.dtype != torch.float32:
+                    raise _lib.WslError("model parameters were moved off the GPU / cast away from float32")
+                with torch.no_grad():
+                    self._param_arena[off:off + n].copy_(p.data.reshape(-1))
+                    p.data = self._param_arena[off:off + n].view(shape)
+
+    # ------------------------------------------------------------------ masks (host-side RNG = torch's, on the device)
+    def set_dropout_masks(self, emasks, cmasks=None):
+        """Inject the Bernoulli masks of the next forward(s) (parity tests replay the reference's); None = draw."""
+        self._forced_masks = None if emasks is None and cmasks is None else (emasks, cmasks)
+
+    def _draw_masks(self, N, H, W, training):
+        dev = self._param_arena.device
+        if self._forced_masks is not None:
+            em, cm = self._forced_masks
+        else:
+            em = cm = None
+        if training and em is None:
+            em = [(torch.rand((N, _FT[l], H >> l, W >> l), device=dev) >= _DROP[l]).to(torch.uint8) for l in range(5)]
+        if self._n_dec == 2 and cm is None:     # F.dropout2d(x, 0.5) is active in eval mode too (unet.py:254-256,344)
+            cm = [(torch.rand((N, _FT[l]), device=dev) >= 0.5).to(torch.float32) * 2.0 for l in range(5)]
+        return em, cm
+
+    # ------------------------------------------------------------------ execution
+    def _run_forward(self, x, keep_for_backward=False):
+        x = rt.f32c(x, "input")
+        if x.dim() != 4 or x.shape[1] != self.in_chns:
+            raise _lib.WslError(f"expected input [N,{self.in_chns},H,W], got {tuple(x.shape)}")
+        N, _, H, W = x.shape
+        self._ensure_arena()
+        d = self._desc(N, H, W)
+        nws = rt.L().wsl_net_ws_bytes(C.byref(d))
+        if nws == 0:
+            raise _lib.WslError(rt.L().wsl_last_error().decode())
+        training = self.training
+        grad_mode = training and keep_for_backward      # (grad mode is off inside autograd.Function.forward)
+        ws = rt.workspace(("net", id(self), "train" if grad_mode else "infer"), nws)
+        em, cm = self._draw_masks(N, H, W, training)
+        lm = torch.empty((N, self.class_num, H, W), dtype=torch.float32, device=x.device)
+        la = torch.empty_like(lm) if self._n_dec == 2 else None
+        rt.call("wsl_net_forward", C.byref(d), rt.ptr(self._param_arena), rt.ptr(self._buf_arena), rt.ptr(self._nbt),
+                rt.ptr(x), rt.ptr_array(em) if training else None, rt.ptr_array(cm), int(training), rt.ptr(lm), rt.ptr(la),
+                rt.ptr(ws), nws, rt.stream())
+        self._last_masks = (em, cm)
+        if grad_mode:
+            self._fwd_token += 1
+            self._saved = (d, ws, nws, em, cm)
+        return (lm, la) if la is not None else (lm,)
+
+    def _run_backward(self, x, gouts, phase=0):
+        d, ws, nws, em, cm = self._saved
+        g = [rt.f32c(t, "grad_output") if t is not None else None for t in gouts]
+        if g[0] is None or (self._n_dec == 2 and g[1] is None):
+            shape = (d.N, self.class_num, d.H, d.W)
+            g = [t if t is not None else torch.zeros(shape, dtype=torch.float32, device=x.device) for t in
+                 (g + [None])[:self._n_dec]]
+        rt.call("wsl_net_backward", C.byref(d), rt.ptr(self._param_arena), rt.ptr(x), rt.ptr_array(em), rt.ptr_array(cm),
+                rt.ptr(g[0]), rt.ptr(g[1]) if self._n_dec == 2 else None, rt.ptr(self._grad_arena), rt.ptr(ws), nws, phase,
+                rt.stream())
+        ga = self._grad_arena
+        return tuple(ga[off:off + n].view(shape) for _, off, n, shape in self._plist)
+
+    def forward(self, x):
+        if x.requires_grad:
+            raise NotImplementedError("gradient with respect to the input image is not built (no trainer of the "
+                                      "reference's hot path asks for it)")
+        if self.training and torch.is_grad_enabled():
+            return _NetFn.apply(self, x, *[p for p, _, _, _ in self._plist])
+        outs = self._run_forward(x)
+        return outs if len(outs) > 1 else outs[0]
+
+    # flat views for the fused trainer / data-parallel engine
+    def flat_params(self):
+        self._ensure_arena()
+        return self._param_arena[:self.n_param]
+
+    def flat_grads(self):
+        return self._grad_arena[:self.n_param]
+
+    def cuda(self, device=None):   # already resident; keep net_factory(...).cuda()-style call sites working
+        return self
+
+
+class UNet(_HipUNet):
+    """ref: networks/unet.py:286-303 (in_chns, class_num) -> logits [N, class_num, H, W]."""
+    _n_dec = 1
+
+    def __init__(self, in_chns, class_num):
+        super().__init__(in_chns, class_num)
+
+
+class UNet_CCT(_HipUNet):
+    """ref: networks/unet.py:327-346 (in_chns, class_num) -> (main_seg, aux_seg1); the aux decoder sees
+    F.dropout2d(feature, 0.5) of all five encoder features, in train AND eval mode."""
+    _n_dec = 2
+
+    def __init__(self, in_chns, class_num):
+        super().__init__(in_chns, class_num)
