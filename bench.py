@@ -43,13 +43,15 @@ def parse():
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU leg and print its JSON")
     return ap.parse_args()
 
 
 def cpu_baseline(args):
     """The oracle (torch-CPU restatement of the reference step) on a bounded sample of the same workload."""
     from oracle import torch_ref as R
-    n_thr = os.cpu_count() or 1
+    n_thr = args.cpu_threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(n_thr)
     B, S = args.cpu_batch, args.size
     g = torch.Generator().manual_seed(1)
@@ -72,18 +74,39 @@ def cpu_baseline(args):
     crf = args.crf_radius if args.loss == "pce_gatedcrf" else None
     if args.loss == "pce":
         raise SystemExit("cpu baseline for --loss pce: use ours_proposed or pce_gatedcrf")
-    tr.step(x, lab, 0.4, em, cm, crf)                      # warm-up
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_iters):
+    tr.step(x, lab, 0.4, em, cm, crf)                      # warm-up (thread pool, oneDNN primitives)
+    iters, t0 = 0, time.perf_counter()
+    while iters < max(2, args.cpu_iters) or (time.perf_counter() - t0 < 15.0 and iters < 12):   # ~15-30 s of CPU work
         tr.step(x, lab, 0.4, em, cm, crf)
+        iters += 1
     dt = time.perf_counter() - t0
-    return {"value": round(B * args.cpu_iters / dt, 3), "unit": "slices/s", "cores": n_thr, "kind": "port",
-            "sample": f"oracle/torch_ref.py RefTrainer (stock torch CPU ops), {args.net} {args.loss}, batch {B} at "
-                      f"{S}x{S}, 1 warm-up + {args.cpu_iters} timed steps, {n_thr} threads"}
+    return {"value": round(B * iters / dt, 3), "unit": "slices/s", "cores": n_thr, "kind": "port",
+            "sample": f"oracle/torch_ref.py RefTrainer (stock torch CPU ops), {args.net} {args.loss}"
+                      + (f" r={args.crf_radius}" if crf else "") + f", batch {B} at {S}x{S}, 1 warm-up + {iters} timed "
+                      f"steps, {n_thr} threads of {os.cpu_count()} host cores"}
+
+
+def cpu_baseline_subprocess(args):
+    """Run the CPU leg in its own interpreter with a hard time limit, so a slow host can never cost the GPU result."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--loss", args.loss, "--net", args.net,
+           "--size", str(args.size), "--crf-radius", str(args.crf_radius), "--cpu-batch", str(args.cpu_batch),
+           "--cpu-iters", str(args.cpu_iters), "--cpu-threads", str(args.cpu_threads)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "slices/s", "cores": 0, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "slices/s", "cores": 0, "kind": "port", "sample": "timed out after 240 s"}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -159,7 +182,7 @@ def main():
                "whole_step_conv_mfma_frac": round(value / world * gflop * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
                "roofline": roof, "kernels": fams, "last_losses": {k: round(v, 5) for k, v in losses.items()}}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

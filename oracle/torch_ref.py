@@ -278,4 +278,4 @@ class RefTrainer:
             sgd_step(ps, [p.grad for p in ps], self.bufs, self.lr, first=(self.it == 0))
         self.lr = poly_lr(self.base_lr, self.it, self.max_it)
         self.it += 1
-        return float(loss), float(lce), float(lpse)
+        return float(loss.detach()), float(lce.detach()), float(lpse.detach())

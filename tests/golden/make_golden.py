@@ -95,6 +95,39 @@ class DropoutRecorder:
         torch.nn.functional.dropout, torch.nn.functional.dropout2d = self._d, self._d2
 
 
+class KinkMargins:
+    """Records how close the forward came to a point where the gradient is discontinuous: the smallest |z| fed to a
+    LeakyReLU and the smallest gap between the two largest values of a MaxPool2d(2) window.  fp32 parity of gradients is
+    undefined when such a margin is inside cross-implementation rounding noise (~1e-6): the sign / arg-max flips and the
+    gradient jumps -- the reference's own CPU and GPU runs would disagree there.  gen_net() therefore picks inputs whose
+    margins are clear of that noise and stores them in the fixture."""
+
+    def __enter__(self):
+        self.leaky, self.pool = float("inf"), float("inf")
+        self._l, self._p = F.leaky_relu, F.max_pool2d
+        me = self
+
+        def leaky_relu(x, negative_slope=0.01, inplace=False):
+            me.leaky = min(me.leaky, float(x.detach().abs().min()))
+            return me._l(x, negative_slope, inplace)
+
+        def max_pool2d(x, kernel_size, *a, **k):
+            if kernel_size in (2, (2, 2)):
+                N, C, H, W = x.shape
+                w = x.detach().view(N, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(-1, 4)
+                top = torch.topk(w, 2, dim=1).values
+                me.pool = min(me.pool, float((top[:, 0] - top[:, 1]).min()))
+            return me._p(x, kernel_size, *a, **k)
+
+        F.leaky_relu, F.max_pool2d = leaky_relu, max_pool2d
+        torch.nn.functional.leaky_relu, torch.nn.functional.max_pool2d = leaky_relu, max_pool2d
+        return self
+
+    def __exit__(self, *a):
+        F.leaky_relu, F.max_pool2d = self._l, self._p
+        torch.nn.functional.leaky_relu, torch.nn.functional.max_pool2d = self._l, self._p
+
+
 def load_det(module, seed):
     sd = module.state_dict()
     vals = det_state({k: tuple(v.shape) for k, v in sd.items()}, seed)
@@ -378,18 +411,41 @@ def pack_param_grads(module, out, prefix):
 
 
 def gen_net():
-    for net, tag, (N, H, W) in (("unet_cct", "cct32", (2, 32, 32)), ("unet", "unet32", (2, 32, 32)),
-                                ("unet_cct", "cct64", (2, 64, 64)), ("unet_cct", "cct48x80", (3, 48, 80))):
+    # (net, tag, shape, leaky margin asked for).  The margin a fixture can have shrinks with its activation count n
+    # (P[min|z| > d] ~ exp(-0.8 n d)): the 16^2 / 32^2 cases are searched until clear of fp32 noise and get the strict
+    # 1e-4 gradient check; the larger ones record the best margin found and are checked kink-tolerantly.
+    for net, tag, (N, H, W), want in (("unet_cct", "cct16", (4, 16, 16), 1e-5), ("unet_cct", "cct32", (2, 32, 32), 4e-6),
+                                      ("unet", "unet32", (2, 32, 32), 4e-6), ("unet_cct", "cct64", (2, 64, 64), None),
+                                      ("unet_cct", "cct48x80", (3, 48, 80), None)):
         out = {}
-        torch.manual_seed(200 + len(tag))
         random.seed(2022)
+        beta = random.random() + 1e-10
+        lab = torch.from_numpy(scribble_labels(N, H, W, seed=3))
+        best = None
+        for attempt in range(120 if want else 6):   # pick an input whose forward stays clear of gradient discontinuities
+            seed = 200 + len(tag) + 1000 * attempt
+            torch.manual_seed(seed)
+            model = (UNet_CCT if net == "unet_cct" else UNet)(1, 4).train()
+            load_det(model, 2022)
+            x = torch.rand(N, 1, H, W)
+            with torch.no_grad(), DropoutRecorder(), KinkMargins() as km:
+                model(x)
+            if best is None or km.leaky > best[0]:
+                best = (km.leaky, km.pool, seed)
+            if want and km.leaky > want and km.pool > want / 4:
+                best = (km.leaky, km.pool, seed)
+                break
+        else:
+            if want:
+                raise RuntimeError(f"{tag}: no well-separated input found (best {best})")
+        torch.manual_seed(best[2])
         model = (UNet_CCT if net == "unet_cct" else UNet)(1, 4).train()
         load_det(model, 2022)
         x = torch.rand(N, 1, H, W)
-        lab = torch.from_numpy(scribble_labels(N, H, W, seed=3))
-        beta = random.random() + 1e-10
-        with DropoutRecorder() as rec:
+        with DropoutRecorder() as rec, KinkMargins() as km:
             res_m = model(x)
+        print(f"    {tag}: seed {best[2]}, leaky margin {km.leaky:.2e}, pool margin {km.pool:.2e}")
+        out["margins"] = np.array([km.leaky, km.pool])
         if net == "unet_cct":
             o1, o2 = res_m
             res = ours_proposed_loss(o1, o2, lab, beta)

@@ -63,3 +63,24 @@ def check_grads(g, grads, ents, grad_tol, prefix="g."):
             if abs(got_n - nrm[0]) > 2e-4 * nrm[0] + 1e-6:
                 bad.append((n + " (norm)", got_n, nrm[0]))
     return bad
+
+
+def grad_l2(g, grads, ents, prefix="g."):
+    """Relative L2 error over the sampled entries of every parameter-gradient tensor."""
+    num = den = 0.0
+    for n, kind, shape, off in ents:
+        if kind != 0:
+            continue
+        size = int(np.prod(shape)) if shape else 1
+        got = grads[off:off + size][sample_index(size)].astype(np.float64)
+        ref = g[f"{prefix}{n}"].astype(np.float64)
+        num += float(((got - ref) ** 2).sum())
+        den += float((ref ** 2).sum())
+    return (num / den) ** 0.5
+
+
+def strict_grads(g):
+    """True when the fixture's forward stays clear of gradient discontinuities (LeakyReLU kink, max-pool ties) by more
+    than cross-implementation fp32 noise -- see KinkMargins in tests/golden/make_golden.py."""
+    m = g["margins"]
+    return bool(m[0] >= 4e-6 and m[1] >= 1e-6)

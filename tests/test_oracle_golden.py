@@ -31,7 +31,7 @@ def test_state_layout_matches_reference_keys():
     assert sum(int(np.prod(s)) for k, s in R.state_layout("unet") if R.is_param(k)) == 1813764
 
 
-@pytest.mark.parametrize("tag,net", [("cct32", "unet_cct"), ("unet32", "unet"), ("cct48x80", "unet_cct")])
+@pytest.mark.parametrize("tag,net", [("cct16", "unet_cct"), ("cct32", "unet_cct"), ("unet32", "unet"), ("cct64", "unet_cct"), ("cct48x80", "unet_cct")])
 def test_net_forward_backward(tag, net):
     g = golden(f"g2_{tag}")
     sd = det_sd(net)

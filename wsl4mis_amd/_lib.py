@@ -6,6 +6,11 @@ tests themselves through `bind()`, never by this loader.)"""
 import ctypes as C
 import os
 
+# torch must be imported BEFORE libwslhip.so is dlopen'ed: the library needs libamdhip64.so.7, and the process must
+# resolve that soname to the HIP runtime torch ships (torch/lib), not to a second copy from /opt/rocm -- with the system
+# copy loaded first, torch and the library end up on a runtime that reports "no ROCm-capable device" on the GPU box.
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwslhip.so")
 
