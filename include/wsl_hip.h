@@ -75,6 +75,13 @@ typedef struct WslSrc {
 int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y, int64_t y_bs,
                    int N, int H, int W, int Co, int ks, int wmode, float* stat_part, float* stat_cnt, void* stream);
 int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int ks);
+/* Fast path: wmode 2 (forward) / 3 (data gradient) take `w` = a PACKED weight image [ks*ks][Ci][Co] produced by
+ * wsl_conv2d_pack_weights(w_raw, packed, Co, Ci, ks, wmode_raw = 0 or 1) -- for wmode_raw 1 the raw tensor is the
+ * forward weight [Ci][Co][ks][ks] and Co/Ci are the data-gradient GEMM's output/input channel counts.  The packed path
+ * needs W % 4 == 0 and 16-byte aligned tensors and batch strides (wsl_conv2d_fast_ok() != 0); it stages tiles with
+ * aligned float4 loads and prefetches the next channel chunk during the MFMA loop. */
+int wsl_conv2d_pack_weights(const float* w, float* packed, int Co, int Ci, int ks, int wmode_raw, void* stream);
+int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int W);
 
 /* dw[Co][Ci][ks][ks] = sum_{n,y,x} dy[n,co,y,x] * in[n,ci,y+ky-p,x+kx-p];  db[Co] = sum dy  (db may be NULL).
  * Split over pixels into partials in `ws`, then an order-fixed second stage. */

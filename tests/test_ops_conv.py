@@ -30,6 +30,10 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
     (1, 10, 70, 2, 0, 33, 3, False),
     (1, 20, 32, 9, 0, 40, 3, False),
     (2, 16, 16, 17, 0, 48, 1, True),
+    (1, 16, 64, 10, 6, 24, 3, True),
+    (1, 24, 128, 4, 0, 8, 3, True),
+    (2, 8, 32, 20, 12, 70, 3, False),
+    (1, 16, 64, 9, 0, 12, 1, True),
 ]
 
 
@@ -69,6 +73,18 @@ def test_conv_fwd_dgrad_wgrad_stats(be, case):
     be.call("wsl_conv2d_fwd", sa, sb, be.ptr(d["w"]), be.ptr(d["bias"]), be.ptr(y), Co * H * W, N, H, W, Co, ks, 0,
             be.ptr(part), be.ptr(cnt), be.stream)
     assert rel_err(be.np(y), y_ref.detach().numpy()) < TOL
+    # ---- packed fast path (aligned float4 staging + register prefetch), same outputs incl. the statistics
+    fast = bool(be.lib.wsl_conv2d_fast_ok(sa, sb, be.ptr(y), Co * H * W, W))
+    assert fast == (W % 4 == 0)
+    if fast:
+        wp, y2 = be.zeros((ks * ks, Ci, Co)), be.zeros((N, Co, H, W))
+        part2, cnt2 = be.zeros((nblk, Co, 2)), be.zeros((nblk,))
+        be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(wp), Co, Ci, ks, 0, be.stream)
+        be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), be.ptr(d["bias"]), be.ptr(y2), Co * H * W, N, H, W, Co, ks, 2,
+                be.ptr(part2), be.ptr(cnt2), be.stream)
+        assert rel_err(be.np(y2), y_ref.detach().numpy()) < TOL
+        assert rel_err(be.np(part2)[..., 0], be.np(part)[..., 0]) < 1e-5 and np.array_equal(be.np(cnt2), be.np(cnt))
+        assert rel_err(be.np(part2)[..., 1], be.np(part)[..., 1]) < 1e-4
     # BatchNorm statistics from the epilogue partials
     gamma, beta = be.arr(np.linspace(0.5, 1.5, Co, dtype=np.float32)), be.arr(np.linspace(-0.2, 0.2, Co, dtype=np.float32))
     rm, rv = be.arr(np.full(Co, 0.1, np.float32)), be.arr(np.full(Co, 0.9, np.float32))
@@ -90,6 +106,12 @@ def test_conv_fwd_dgrad_wgrad_stats(be, case):
     be.call("wsl_conv2d_fwd", sr, be.src(), be.ptr(d["w"]), None, be.ptr(dx), Ci * H * W, N, H, W, Ci, ks, 1, None, None,
             be.stream)
     assert rel_err(be.np(dx), vin.grad.numpy()) < TOL
+    if bool(be.lib.wsl_conv2d_fast_ok(sr, be.src(), be.ptr(dx), Ci * H * W, W)):
+        wpd, dx2 = be.zeros((ks * ks, Co, Ci)), be.zeros((N, Ci, H, W))
+        be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(wpd), Ci, Co, ks, 1, be.stream)
+        be.call("wsl_conv2d_fwd", sr, be.src(), be.ptr(wpd), None, be.ptr(dx2), Ci * H * W, N, H, W, Ci, ks, 3, None, None,
+                be.stream)
+        assert rel_err(be.np(dx2), vin.grad.numpy()) < TOL
     # ---- weight / bias gradient
     nws = be.lib.wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks)
     ws, dw, db = be.ws(nws), be.zeros((Co, Ci, ks, ks)), be.zeros((Co,))

@@ -444,15 +444,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_dw,
 struct WgPlan {
   int th, tw, cb, ib, wk, nsplit, items, tiles_x, tiles_y, co_blocks, ci_blocks;
 };
-static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co) {
+// v2 = the prefetching kernels of wsl_conv2.hip: half-height tiles keep the register-held prefetch set small
+static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co, bool v2 = false) {
   WgPlan g;
   const bool small = (Co <= 16 || Ci <= 16);
   if (small) {
     g.cb = g.ib = 16, g.wk = 4;
-    if (W >= 64) g.th = 8, g.tw = 64; else if (W >= 32) g.th = 8, g.tw = 32; else g.th = 16, g.tw = 16;
+    if (W >= 64) g.th = v2 ? 4 : 8, g.tw = 64; else if (W >= 32) g.th = v2 ? 4 : 8, g.tw = 32; else g.th = v2 ? 8 : 16, g.tw = 16;
   } else {
     g.cb = g.ib = 32, g.wk = 1;
-    if (W >= 32) g.th = 8, g.tw = 32; else g.th = 16, g.tw = 16;
+    if (W >= 32) g.th = v2 ? 4 : 8, g.tw = 32; else g.th = v2 ? 8 : 16, g.tw = 16;
   }
   g.tiles_x = cdiv(W, g.tw), g.tiles_y = cdiv(H, g.th);
   g.items = N * g.tiles_x * g.tiles_y;
@@ -496,7 +497,32 @@ static int dispatch_wgrad(WgradP& p, const WgPlan& g, void* stream) {
 
 }  // namespace wsl
 
+namespace wsl {
+// wsl_conv2.hip
+bool conv2_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_bs, int W, int Ci);
+int conv2_pack(const float* w, float* wp, int Co, int Ci, int ks, int wmode, void* stream);
+int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
+              int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
+              void* stream);
+bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, int W);
+int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
+                  int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
+                  int tiles_y, int co_blocks, int ci_blocks, void* stream);
+}  // namespace wsl
+
 using namespace wsl;
+
+extern "C" int wsl_conv2d_pack_weights(const float* w, float* packed, int Co, int Ci, int ks, int wmode_raw, void* stream) {
+  WSL_REQUIRE(w && packed && Co > 0 && Ci > 0 && (ks == 1 || ks == 3) && (wmode_raw == 0 || wmode_raw == 1),
+              "conv2d_pack_weights: bad args");
+  return conv2_pack(w, packed, Co, Ci, ks, wmode_raw, stream);
+}
+
+extern "C" int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int W) {
+  if (!a) return 0;
+  const int Ci = a->C + ((b && b->C > 0) ? b->C : 0);
+  return conv2_eligible(*a, b, y, y_bs, W, Ci) ? 1 : 0;
+}
 
 extern "C" int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int ks) {
   (void)Ci;
@@ -512,7 +538,7 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
   WSL_REQUIRE(a && w && y, "conv2d_fwd: null argument");
   WSL_REQUIRE(N > 0 && H > 0 && W > 0 && Co > 0, "conv2d_fwd: bad shape N=%d H=%d W=%d Co=%d", N, H, W, Co);
   WSL_REQUIRE(ks == 1 || ks == 3, "conv2d_fwd: kernel size %d not built (1 and 3 are)", ks);
-  WSL_REQUIRE(wmode == 0 || wmode == 1, "conv2d_fwd: wmode %d", wmode);
+  WSL_REQUIRE(wmode >= 0 && wmode <= 3, "conv2d_fwd: wmode %d", wmode);
   WSL_REQUIRE((stat_part == nullptr) == (stat_cnt == nullptr), "conv2d_fwd: stat_part and stat_cnt come together");
   if (int rc = check_src(a, H * W, "conv2d_fwd(a)")) return rc;
   ConvP p;
@@ -528,6 +554,14 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
   p.w = w, p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.Co = Co, p.wmode = wmode;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
   const FwdPlan f = fwd_plan(W, Co);
+  if (wmode >= 2) {
+    if (!conv2_eligible(p.in.a, &p.in.b, y, y_bs, W, p.in.Ci)) {
+      set_error("conv2d_fwd: packed weights (wmode %d) need W %% 4 == 0 and 16-byte aligned tensors", wmode);
+      return WSL_EINVAL;
+    }
+    return conv2_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
+                     stat_cnt, stream);
+  }
   p.tiles_x = cdiv(W, f.tw), p.tiles_y = cdiv(H, f.th);
   p.vec_ok = (W % 4 == 0) && (y_bs % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
   return ks == 3 ? dispatch_conv<3>(p, f, stream) : dispatch_conv<1>(p, f, stream);
@@ -535,8 +569,8 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
 
 extern "C" size_t wsl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co, int ks) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
-  const WgPlan g = wgrad_plan(N, H, W, Ci, Co);
-  return sizeof(float) * (size_t)g.nsplit * ((size_t)ks * ks * Co * Ci + Co);
+  const WgPlan g = wgrad_plan(N, H, W, Ci, Co), g2 = wgrad_plan(N, H, W, Ci, Co, true);
+  return sizeof(float) * (size_t)(g.nsplit > g2.nsplit ? g.nsplit : g2.nsplit) * ((size_t)ks * ks * Co * Ci + Co);
 }
 
 extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db,
@@ -556,7 +590,8 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   p.in.H = H, p.in.W = W, p.in.Ci = a->C + p.in.b.C;
   const int Ci = p.in.Ci;
   WSL_REQUIRE(dy_bs >= (int64_t)Co * H * W, "conv2d_wgrad: dy batch stride too small");
-  const WgPlan g = wgrad_plan(N, H, W, Ci, Co);
+  const bool v2 = wgrad2_eligible(p.in.a, &p.in.b, dy, dy_bs, W);
+  const WgPlan g = wgrad_plan(N, H, W, Ci, Co, v2);
   const size_t need = wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks);
   if (ws_bytes < need) {
     set_error("conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
@@ -568,7 +603,13 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   p.part_db = p.part_dw + (size_t)g.nsplit * KK * Co * Ci;
   p.tiles_x = g.tiles_x, p.tiles_y = g.tiles_y, p.items = g.items, p.nsplit = g.nsplit, p.co_blocks = g.co_blocks;
   // a ci-block beyond the first never writes db and a (co,ci) element outside the tensor is never written: no memset
-  if (int rc = (ks == 3 ? dispatch_wgrad<3>(p, g, stream) : dispatch_wgrad<1>(p, g, stream))) return rc;
+  if (v2) {
+    if (int rc = wgrad2_launch(p.in.a, &p.in.b, dy, dy_bs, p.part_dw, p.part_db, N, H, W, Co, ks, g.th, g.tw, g.cb, g.ib,
+                               g.nsplit, g.items, g.tiles_x, g.tiles_y, g.co_blocks, g.ci_blocks, stream))
+      return rc;
+  } else if (int rc = (ks == 3 ? dispatch_wgrad<3>(p, g, stream) : dispatch_wgrad<1>(p, g, stream))) {
+    return rc;
+  }
   const int64_t total = (int64_t)KK * Co * Ci + (db ? Co : 0);
   void* tok = prof_begin(3, 0.0, 4.0 * (double)total * (g.nsplit + 1), stream);
   struct EndProf { void* t; void* s; ~EndProf() { prof_end(t, s); } } endprof{tok, stream};

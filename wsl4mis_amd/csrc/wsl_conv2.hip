@@ -1,0 +1,631 @@
+// v2 of the MFMA convolution kernels: same implicit-GEMM mapping and LDS operand layout as wsl_conv.hip, with the
+// HBM -> LDS staging rebuilt for throughput (profiles/r1a: staging, not MFMA issue, bounded v1):
+//   * every global access is an aligned 16-byte load: the halo tile is staged with a row pitch of TW+8 (4 columns of
+//     padding on each side instead of 1) so rows start on a float4 boundary; keep-masks travel as uchar4;
+//   * each thread owns ONE float4 position of the tile and walks the channels of a chunk: all index arithmetic and the
+//     bounds test are hoisted out of the loops, the loads of a chunk are independent and issued back to back;
+//   * register prefetch: the loads of chunk k+1 (tile t+1 in the weight-gradient) are issued before the MFMA loop of
+//     chunk k and written to LDS after it (one LDS buffer, two barriers per chunk);
+//   * weights are read from a packed [tap][ci][co] image (wsl_conv2d_pack_weights), so a chunk's B operands are
+//     contiguous rows copied with float4 loads instead of a 4-byte gather;
+//   * the producer's BN scale/shift live in LDS for the whole workgroup.
+// Requires W % 4 == 0 and 16-byte aligned tensors / batch strides; anything else takes the v1 kernels.
+#include "wsl_rt.h"
+
+namespace wsl {
+
+struct Src2 {            // one source, device view
+  const float* x;
+  const uint8_t* emask;
+  const float* scale;
+  const float* shift;
+  const float* cmask;
+  int64_t bs;
+  int C;
+  float es;
+};
+
+struct Conv2P {
+  Src2 a, b;
+  const float* wp;       // packed [KK][Ci][Co]
+  const float* bias;
+  float* y;
+  int64_t y_bs;
+  int N, H, W, Ci, Co, tiles_x, tiles_y;
+  float* stat_part;
+  float* stat_cnt;
+};
+
+template <int KS, int TH, int TW, int CO_T, int KC>
+struct Conv2Cfg {
+  static constexpr int P = KS / 2, KK = KS * KS, PADL = P ? 4 : 0;
+  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2 * P, ROWP4 = ROWP / 4, POS = ROWS * ROWP4;
+  static constexpr int G = 256 / POS, NLD = (KC + G - 1) / G;
+  static constexpr int PLANE = ((ROWS * ROWP - 16 + 31) / 32) * 32 + 16;  // == 16 (mod 32)
+  static constexpr int CSTR = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;
+  static constexpr int SEGS = TW / 16, MT_TOTAL = TH * SEGS, MT = MT_TOTAL / 4, NT = CO_T / 16;
+  static constexpr int IN_FLOATS = KC * PLANE, W_FLOATS = KK * KC * CSTR;
+  static constexpr int WQ = CO_T / 4, WF4 = KK * KC * WQ, NWL = (WF4 + 255) / 256;
+  static constexpr int MAXC = 512;  // channels whose BN coefficients fit the LDS table
+  static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + W_FLOATS + 3 * MAXC);
+  // workgroups per CU the register allocator must leave room for (2nd __launch_bounds__ argument = waves per SIMD)
+  static constexpr int MINW = (MT * NT * 4 <= 32) ? 3 : 2;
+  static_assert(POS <= 256 && G >= 1, "one float4 position per thread");
+  static_assert(MT_TOTAL % 4 == 0 && KC % 4 == 0 && (8 * CO_T) <= IN_FLOATS, "tile shape");
+};
+
+template <int KS, int TH, int TW, int CO_T, int KC>
+__global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void conv_mfma2_kernel(Conv2P p) {
+  using C = Conv2Cfg<KS, TH, TW, CO_T, KC>;
+  WSL_DYN_SMEM(smem);
+  float* in_t = reinterpret_cast<float*>(smem);
+  float* w_t = in_t + C::IN_FLOATS;
+  float* sc_l = w_t + C::W_FLOATS;   // [Ci] scale (1 when the source is raw)
+  float* sh_l = sc_l + C::MAXC;      // [Ci] shift
+  float* cm_l = sh_l + C::MAXC;      // [Ci] channel multiplier of this sample (1 if none)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = blockIdx.y * CO_T;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = p.H, W = p.W, Ci = p.Ci;
+  const int64_t HW = (int64_t)H * W;
+
+  for (int c = tid; c < Ci; c += kThreads) {
+    const bool ina = c < p.a.C;
+    const Src2& s = ina ? p.a : p.b;
+    const int ch = ina ? c : c - p.a.C;
+    sc_l[c] = s.scale ? s.scale[ch] : 1.f;
+    sh_l[c] = s.scale ? s.shift[ch] : 0.f;
+    cm_l[c] = s.cmask ? s.cmask[(int64_t)n * s.C + ch] : 1.f;
+  }
+
+  // ---- this thread's staging position (fixed for the whole kernel)
+  const int grp = tid / C::POS, pos = tid - grp * C::POS;
+  const int pty = pos / C::ROWP4, ptx4 = pos - pty * C::ROWP4;
+  const int gy = y0 + pty - C::P, gx = x0 + ptx4 * 4 - C::PADL;
+  const bool pvalid = grp < C::G && gy >= 0 && gy < H && gx >= 0 && gx < W;
+  const int64_t goff = (int64_t)gy * W + gx;
+  const int loff = pty * C::ROWP + ptx4 * 4;
+
+  v4f acc[C::MT][C::NT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  int abase[C::MT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i) {
+    const int mt = wave * C::MT + i;
+    abase[i] = (lane >> 4) * C::PLANE + (mt / C::SEGS) * C::ROWP + (mt % C::SEGS) * 16 + (lane & 15) + (C::PADL - C::P);
+  }
+  const int bbase = (lane >> 4) * C::CSTR + (lane & 15);
+
+  float4 pre[C::NLD];
+  uchar4 prm[C::NLD];
+  float4 prw[C::NWL];
+  const bool co_vec = (p.Co & 3) == 0;
+
+  auto issue = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      const int c = grp + i * C::G, cg = c0 + c;
+      pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      prm[i] = make_uchar4(1, 1, 1, 1);
+      if (pvalid && c < KC && cg < Ci) {
+        const bool ina = cg < p.a.C;
+        const Src2& s = ina ? p.a : p.b;
+        const int ch = ina ? cg : cg - p.a.C;
+        pre[i] = *reinterpret_cast<const float4*>(s.x + n * s.bs + ch * HW + goff);
+        if (s.emask) prm[i] = *reinterpret_cast<const uchar4*>(s.emask + ((int64_t)n * s.C + ch) * HW + goff);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) {
+      const int f = tid + i * kThreads;
+      prw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < C::WF4) {
+        const int row = f / C::WQ, q = f - row * C::WQ;
+        const int tap = row / KC, c = row - tap * KC;
+        const int cg = c0 + c, cog = co0 + q * 4;
+        if (cg < Ci && cog < p.Co) {
+          const float* src = p.wp + ((int64_t)tap * Ci + cg) * p.Co + cog;
+          if (co_vec) {
+            prw[i] = *reinterpret_cast<const float4*>(src);
+          } else {
+            prw[i].x = src[0];
+            if (cog + 1 < p.Co) prw[i].y = src[1];
+            if (cog + 2 < p.Co) prw[i].z = src[2];
+            if (cog + 3 < p.Co) prw[i].w = src[3];
+          }
+        }
+      }
+    }
+  };
+
+  auto commit = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      const int c = grp + i * C::G, cg = c0 + c;
+      if (grp < C::G && c < KC) {
+        float4 v = pre[i];
+        if (pvalid && cg < Ci) {
+          const bool ina = cg < p.a.C;
+          const Src2& s = ina ? p.a : p.b;
+          if (s.scale) {
+            const float sc = sc_l[cg], sh = sh_l[cg];
+            v.x = leaky(fmaf(v.x, sc, sh)), v.y = leaky(fmaf(v.y, sc, sh));
+            v.z = leaky(fmaf(v.z, sc, sh)), v.w = leaky(fmaf(v.w, sc, sh));
+          }
+          if (s.emask) {
+            const uchar4 m = prm[i];
+            v.x = m.x ? v.x * s.es : 0.f, v.y = m.y ? v.y * s.es : 0.f;
+            v.z = m.z ? v.z * s.es : 0.f, v.w = m.w ? v.w * s.es : 0.f;
+          }
+          if (s.cmask) {
+            const float cm = cm_l[cg];
+            v.x *= cm, v.y *= cm, v.z *= cm, v.w *= cm;
+          }
+        }
+        *reinterpret_cast<float4*>(in_t + c * C::PLANE + loff) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) {
+      const int f = tid + i * kThreads;
+      if (f < C::WF4) {
+        const int row = f / C::WQ, q = f - row * C::WQ;
+        *reinterpret_cast<float4*>(w_t + row * C::CSTR + q * 4) = prw[i];
+      }
+    }
+  };
+
+  issue(0);
+  __syncthreads();  // BN tables visible
+  for (int c0 = 0; c0 < Ci; c0 += KC) {
+    commit(c0);
+    __syncthreads();
+    if (c0 + KC < Ci) issue(c0 + KC);  // prefetch: in flight during the MFMA loop below
+    const int ngroups = (Ci - c0 >= KC) ? KC / 4 : (Ci - c0 + 3) / 4;
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky) {   // rolled: keeps the scheduler from hoisting a whole chunk's LDS reads
+      const float* in_r = in_t + ky * C::ROWP;
+      const float* w_r = w_t + ky * KS * KC * C::CSTR;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+        for (int cg = 0; cg < KC / 4; ++cg) {
+          if (cg < ngroups) {
+            float bv[C::NT];
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) bv[j] = w_r[(kx * KC + cg * 4) * C::CSTR + j * 16 + bbase];
+#pragma unroll
+            for (int i = 0; i < C::MT; ++i) {
+              const float av = in_r[cg * 4 * C::PLANE + kx + abase[i]];
+#pragma unroll
+              for (int j = 0; j < C::NT; ++j) acc[i][j] = WSL_MFMA16(av, bv[j], acc[i][j]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (identical to v1): bias, float4 stores, BatchNorm partial statistics
+  float bsum[C::NT];
+#pragma unroll
+  for (int j = 0; j < C::NT; ++j) {
+    const int co = co0 + j * 16 + (lane & 15);
+    const float bias = (p.bias && co < p.Co) ? p.bias[co] : 0.f;
+    bsum[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i) {
+      const int mt = wave * C::MT + i;
+      const int oy = y0 + mt / C::SEGS, ox = x0 + (mt % C::SEGS) * 16 + (lane >> 4) * 4;
+      v4f v = acc[i][j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += bias;
+      acc[i][j] = v;
+      if (co < p.Co && oy < H && ox < W) {  // W % 4 == 0: a float4 is inside or outside as a whole
+        *reinterpret_cast<float4*>(p.y + n * p.y_bs + co * HW + (int64_t)oy * W + ox) = make_float4(v[0], v[1], v[2], v[3]);
+        bsum[j] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+  }
+  if (p.stat_part) {
+    float* red1 = in_t;
+    float* red2 = in_t + 4 * CO_T;
+    const int vh = (H - y0 < TH) ? H - y0 : TH, vw = (W - x0 < TW) ? W - x0 : TW;
+    const float cnt = (float)(vh * vw);
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int col = j * 16 + (lane & 15);
+      const int co = co0 + col;
+      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i) {
+        const int mt = wave * C::MT + i;
+        const int oy = y0 + mt / C::SEGS, ox = x0 + (mt % C::SEGS) * 16 + (lane >> 4) * 4;
+        if (co < p.Co && oy < H && ox < W) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = acc[i][j][r] - mean_b;
+            q = fmaf(d, d, q);
+          }
+        }
+      }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) {
+        const int col = j * 16 + lane, co = co0 + col;
+        if (co < p.Co) {
+          float* dst = p.stat_part + ((int64_t)blockIdx.x * p.Co + co) * 2;
+          dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+          dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+        }
+      }
+      if (lane == 0 && blockIdx.y == 0) p.stat_cnt[blockIdx.x] = cnt;
+    }
+  }
+}
+
+// packed[tap][ci][co] = wmode 0: w[co][ci][tap]   |   wmode 1 (data gradient): w[ci][co][KK-1-tap]
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* wp, int Co, int Ci, int KK, int wmode) {
+  const int64_t total = (int64_t)KK * Ci * Co;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+    const int co = (int)(e % Co);
+    const int64_t r = e / Co;
+    const int ci = (int)(r % Ci), tap = (int)(r / Ci);
+    wp[e] = wmode == 0 ? w[((int64_t)co * Ci + ci) * KK + tap] : w[((int64_t)ci * Co + co) * KK + (KK - 1 - tap)];
+  }
+}
+
+template <int KS, int TH, int TW, int CO_T>
+static int launch_conv2(Conv2P& p, int wmode_for_prof, void* stream) {
+  using C = Conv2Cfg<KS, TH, TW, CO_T, 8>;
+  auto kern = conv_mfma2_kernel<KS, TH, TW, CO_T, 8>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Co, CO_T));
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_mfma2_kernel");
+}
+
+static Src2 to_src2(const WslSrc& s) {
+  return Src2{s.x, s.emask, s.scale, s.shift, s.cmask, s.bs, s.C, s.emask_scale};
+}
+
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+bool conv2_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_bs, int W, int Ci) {
+  if ((W & 3) || Ci > 512) return false;
+  if (!aligned16(a.x) || (a.bs & 3) || (a.emask && (reinterpret_cast<uintptr_t>(a.emask) & 3))) return false;
+  if (b && b->C > 0 && (!aligned16(b->x) || (b->bs & 3) || (b->emask && (reinterpret_cast<uintptr_t>(b->emask) & 3))))
+    return false;
+  return y == nullptr || (aligned16(y) && !(y_bs & 3));
+}
+
+int conv2_pack(const float* w, float* wp, int Co, int Ci, int ks, int wmode, void* stream) {
+  const int64_t total = (int64_t)ks * ks * Ci * Co;
+  int64_t blocks = (total + kThreads - 1) / kThreads;
+  if (blocks > 1024) blocks = 1024;
+  WSL_LAUNCH(pack_weights_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, w, wp, Co, Ci, ks * ks, wmode);
+  return check_launch("pack_weights_kernel");
+}
+
+int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
+              int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
+              void* stream) {
+  Conv2P p;
+  p.a = to_src2(a);
+  p.b = (b && b->C > 0) ? to_src2(*b) : Src2{};
+  p.wp = wp, p.bias = bias, p.y = y, p.y_bs = y_bs;
+  p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
+  p.tiles_x = cdiv(W, tw), p.tiles_y = cdiv(H, th);
+  p.stat_part = stat_part, p.stat_cnt = stat_cnt;
+#define WSL_CASE(KS_, TH_, TW_, CO_) \
+  if (ks == KS_ && th == TH_ && tw == TW_ && co_t == CO_) return launch_conv2<KS_, TH_, TW_, CO_>(p, is_dgrad, stream);
+  WSL_CASE(3, 8, 64, 16) WSL_CASE(3, 8, 64, 32) WSL_CASE(3, 8, 32, 16) WSL_CASE(3, 8, 32, 32) WSL_CASE(3, 8, 32, 64)
+  WSL_CASE(3, 16, 16, 16) WSL_CASE(3, 16, 16, 32) WSL_CASE(3, 16, 16, 64)
+  WSL_CASE(1, 8, 64, 16) WSL_CASE(1, 8, 64, 32) WSL_CASE(1, 8, 32, 16) WSL_CASE(1, 8, 32, 32) WSL_CASE(1, 8, 32, 64)
+  WSL_CASE(1, 16, 16, 16) WSL_CASE(1, 16, 16, 32) WSL_CASE(1, 16, 16, 64)
+#undef WSL_CASE
+  set_error("conv2: no kernel for ks %d tile %dx%d co_t %d", ks, th, tw, co_t);
+  return WSL_EUNSUPPORTED;
+}
+
+// ================================================================================================ weight gradient v2
+struct Wgrad2P {
+  Src2 a, b;
+  const float* dy;
+  int64_t dy_bs;
+  float* part_dw;  // [nsplit][KK][Co][Ci]
+  float* part_db;  // [nsplit][Co]
+  int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, co_blocks;
+};
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+struct Wgrad2Cfg {
+  static constexpr int P = KS / 2, KK = KS * KS, PADL = P ? 4 : 0;
+  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2 * P, ROWP4 = ROWP / 4, S = TH * TW;
+  static constexpr int PD = S / 4, PA = ROWS * ROWP4;          // float4 positions per channel (dy / input)
+  static constexpr int GD = 256 / PD, GA = 256 / PA;
+  static constexpr int ND = (CB + GD - 1) / GD, NA = (IB + GA - 1) / GA;
+  static constexpr int PLD = ((S - 2 + 31) / 32) * 32 + 2;                // == 2 (mod 32)
+  static constexpr int PLA = ((ROWS * ROWP - 2 + 31) / 32) * 32 + 2;      // == 2 (mod 32)
+  static constexpr int CBT = CB / 16, IBT = IB / 16, PAIRS = CBT * IBT, WP = 4 / WK, PP = PAIRS / WP;
+  static constexpr int DY_FLOATS = CB * PLD, A_FLOATS = IB * PLA;
+  static constexpr int RED_FLOATS = (WK > 1) ? 4 * 64 * (PP * (KK + 1) * 4) : 0;
+  static constexpr int MAIN_FLOATS = DY_FLOATS + A_FLOATS > RED_FLOATS ? DY_FLOATS + A_FLOATS : RED_FLOATS;
+  static constexpr size_t SMEM = sizeof(float) * (MAIN_FLOATS + 2 * IB);
+  static_assert(PD <= 256 && PA <= 256 && GD >= 1 && GA >= 1 && PAIRS % WP == 0 && TH % WK == 0, "wgrad2 tile shape");
+};
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma2_kernel(Wgrad2P p) {
+  using C = Wgrad2Cfg<KS, TH, TW, CB, IB, WK>;
+  WSL_DYN_SMEM(smem);
+  float* dy_t = reinterpret_cast<float*>(smem);
+  float* a_t = dy_t + C::DY_FLOATS;
+  float* sc_l = dy_t + C::MAIN_FLOATS;  // [IB] scale / shift of this block's input channels
+  float* sh_l = sc_l + IB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = blockIdx.x % p.co_blocks, ib = blockIdx.x / p.co_blocks, split = blockIdx.y;
+  const int co0 = cb * CB, ci0 = ib * IB;
+  const int wp_ = wave % C::WP, wk = wave / C::WP;
+  const int H = p.H, W = p.W, Ci = p.Ci;
+  const int64_t HW = (int64_t)H * W;
+
+  for (int c = tid; c < IB; c += kThreads) {
+    const int cg = ci0 + c;
+    float sc = 1.f, sh = 0.f;
+    if (cg < Ci) {
+      const bool ina = cg < p.a.C;
+      const Src2& s = ina ? p.a : p.b;
+      const int ch = ina ? cg : cg - p.a.C;
+      if (s.scale) sc = s.scale[ch], sh = s.shift[ch];
+    }
+    sc_l[c] = sc, sh_l[c] = sh;
+  }
+
+  // fixed staging positions of this thread
+  const int gd = tid / C::PD, pd = tid - gd * C::PD;             // dy: float4 index pd inside the TH x TW tile
+  const int dty = (pd * 4) / TW, dtx = (pd * 4) - dty * TW;
+  const int ga = tid / C::PA, pa = tid - ga * C::PA;             // input: float4 index inside the halo tile
+  const int aty = pa / C::ROWP4, atx4 = pa - aty * C::ROWP4;
+  const int aloff = aty * C::ROWP + atx4 * 4;
+
+  v4f acc[C::PP][C::KK];
+  v4f accb[C::PP];
+#pragma unroll
+  for (int j = 0; j < C::PP; ++j) {
+    accb[j] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C::KK; ++t) acc[j][t] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_db = (ib == 0) && (p.part_db != nullptr);
+  const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
+
+  float4 prd[C::ND], pra[C::NA];
+  uchar4 prm[C::NA];
+  float prc[C::NA];
+  bool pr_aok = false;   // the prefetched input position lies inside the image (the BN transform applies)
+
+  auto issue = [&](int item) {
+    int q = item;
+    const int tx_i = q % p.tiles_x;
+    q /= p.tiles_x;
+    const int ty_i = q % p.tiles_y;
+    const int n = q / p.tiles_y;
+    const int y0 = ty_i * TH, x0 = tx_i * TW;
+    {
+      const int gy = y0 + dty, gx = x0 + dtx;
+      const bool ok = gd < C::GD && gy < H && gx < W;
+#pragma unroll
+      for (int i = 0; i < C::ND; ++i) {
+        const int c = gd + i * C::GD, co = co0 + c;
+        prd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && c < CB && co < p.Co)
+          prd[i] = *reinterpret_cast<const float4*>(p.dy + n * p.dy_bs + co * HW + (int64_t)gy * W + gx);
+      }
+    }
+    {
+      const int gy = y0 + aty - C::P, gx = x0 + atx4 * 4 - C::PADL;
+      pr_aok = ga < C::GA && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int64_t goff = (int64_t)gy * W + gx;
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) {
+        const int c = ga + i * C::GA, cg = ci0 + c;
+        pra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        prm[i] = make_uchar4(1, 1, 1, 1);
+        prc[i] = 1.f;
+        if (pr_aok && c < IB && cg < Ci) {
+          const bool ina = cg < p.a.C;
+          const Src2& s = ina ? p.a : p.b;
+          const int ch = ina ? cg : cg - p.a.C;
+          pra[i] = *reinterpret_cast<const float4*>(s.x + n * s.bs + ch * HW + goff);
+          if (s.emask) prm[i] = *reinterpret_cast<const uchar4*>(s.emask + ((int64_t)n * s.C + ch) * HW + goff);
+          if (s.cmask) prc[i] = s.cmask[(int64_t)n * s.C + ch];
+        }
+      }
+    }
+  };
+
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) {
+      const int c = gd + i * C::GD;
+      if (gd < C::GD && c < CB) {
+        float* dst = dy_t + c * C::PLD + pd * 4;   // plane stride == 2 (mod 32): 8-byte aligned, not 16
+        dst[0] = prd[i].x, dst[1] = prd[i].y, dst[2] = prd[i].z, dst[3] = prd[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i) {
+      const int c = ga + i * C::GA, cg = ci0 + c;
+      if (ga < C::GA && c < IB) {
+        float4 v = pra[i];
+        if (pr_aok && cg < Ci) {
+          const bool ina = cg < p.a.C;
+          const Src2& s = ina ? p.a : p.b;
+          if (s.scale) {
+            const float sc = sc_l[c], sh = sh_l[c];
+            v.x = leaky(fmaf(v.x, sc, sh)), v.y = leaky(fmaf(v.y, sc, sh));
+            v.z = leaky(fmaf(v.z, sc, sh)), v.w = leaky(fmaf(v.w, sc, sh));
+          }
+          if (s.emask) {
+            const uchar4 m = prm[i];
+            v.x = m.x ? v.x * s.es : 0.f, v.y = m.y ? v.y * s.es : 0.f;
+            v.z = m.z ? v.z * s.es : 0.f, v.w = m.w ? v.w * s.es : 0.f;
+          }
+          if (s.cmask) v.x *= prc[i], v.y *= prc[i], v.z *= prc[i], v.w *= prc[i];
+        }
+        float* dst = a_t + c * C::PLA + aloff;
+        dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+      }
+    }
+  };
+
+  if (it0 < it1) issue(it0);
+  __syncthreads();  // BN tables visible
+  for (int item = it0; item < it1; ++item) {
+    commit();
+    __syncthreads();
+    if (item + 1 < it1) issue(item + 1);   // prefetch the next tile; in flight during the MFMA loop
+    constexpr int RW = TH / WK;
+#pragma unroll 1
+    for (int r = wk * RW; r < wk * RW + RW; ++r) {
+#pragma unroll 1
+      for (int x4 = 0; x4 < TW / 4; ++x4) {
+        const int pix = r * TW + x4 * 4 + (lane >> 4);
+        const int apix = r * C::ROWP + x4 * 4 + (lane >> 4) + (C::PADL - C::P);
+#pragma unroll
+        for (int j = 0; j < C::PP; ++j) {
+          const int pr = wp_ * C::PP + j, cot = pr / C::IBT, cit = pr % C::IBT;
+          const float av = dy_t[(cot * 16 + (lane & 15)) * C::PLD + pix];
+          if (want_db && cit == 0) accb[j] = WSL_MFMA16(av, 1.0f, accb[j]);
+#pragma unroll
+          for (int t = 0; t < C::KK; ++t) {
+            const float bv = a_t[(cit * 16 + (lane & 15)) * C::PLA + apix + (t / KS) * C::ROWP + (t % KS)];
+            acc[j][t] = WSL_MFMA16(av, bv, acc[j][t]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- merge the WK row-groups (fixed order) and store partials
+  if (WK > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int PER = C::PP * (C::KK + 1) * 4;
+    float* mine = red + (wave * 64 + lane) * PER;
+#pragma unroll
+    for (int j = 0; j < C::PP; ++j) {
+#pragma unroll
+      for (int t = 0; t < C::KK; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(j * (C::KK + 1) + t) * 4 + r] = acc[j][t][r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(j * (C::KK + 1) + C::KK) * 4 + r] = accb[j][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int j = 0; j < C::PP; ++j) {
+#pragma unroll
+        for (int t = 0; t <= C::KK; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sum = 0.f;
+            for (int k = 0; k < WK; ++k) sum += red[((k * C::WP + wp_) * 64 + lane) * PER + (j * (C::KK + 1) + t) * 4 + r];
+            if (t < C::KK) acc[j][t][r] = sum; else accb[j][r] = sum;
+          }
+      }
+    }
+  }
+  if (wk == 0) {
+#pragma unroll
+    for (int j = 0; j < C::PP; ++j) {
+      const int pr = wp_ * C::PP + j, cot = pr / C::IBT, cit = pr % C::IBT;
+      const int ci = ci0 + cit * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + cot * 16 + (lane >> 4) * 4 + r;
+        if (co < p.Co && ci < Ci) {
+#pragma unroll
+          for (int t = 0; t < C::KK; ++t)
+            p.part_dw[(((int64_t)split * C::KK + t) * p.Co + co) * Ci + ci] = acc[j][t][r];
+        }
+        if (want_db && cit == 0 && (lane & 15) == 0 && co < p.Co) p.part_db[(int64_t)split * p.Co + co] = accb[j][r];
+      }
+    }
+  }
+}
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+static int launch_wgrad2(Wgrad2P& p, int ci_blocks, void* stream) {
+  using C = Wgrad2Cfg<KS, TH, TW, CB, IB, WK>;
+  auto kern = wgrad_mfma2_kernel<KS, TH, TW, CB, IB, WK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("wgrad_mfma2_kernel");
+}
+
+bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, int W) {
+  return conv2_eligible(a, b, nullptr, 0, W, 0) && aligned16(dy) && !(dy_bs & 3);
+}
+
+int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
+                  int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
+                  int tiles_y, int co_blocks, int ci_blocks, void* stream) {
+  Wgrad2P p;
+  p.a = to_src2(a);
+  p.b = (b && b->C > 0) ? to_src2(*b) : Src2{};
+  p.dy = dy, p.dy_bs = dy_bs, p.part_dw = part_dw, p.part_db = part_db;
+  p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
+  p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
+#define WSL_CASE(KS_, TH_, TW_, CB_, IB_, WK_) \
+  if (ks == KS_ && th == TH_ && tw == TW_ && cb == CB_ && ib == IB_)  \
+    return launch_wgrad2<KS_, TH_, TW_, CB_, IB_, WK_>(p, ci_blocks, stream);
+  WSL_CASE(3, 4, 64, 16, 16, 4) WSL_CASE(3, 4, 32, 16, 16, 4) WSL_CASE(3, 8, 16, 16, 16, 4)
+  WSL_CASE(3, 4, 32, 32, 32, 1) WSL_CASE(3, 8, 16, 32, 32, 1)
+  WSL_CASE(1, 4, 64, 16, 16, 4) WSL_CASE(1, 4, 32, 16, 16, 4) WSL_CASE(1, 8, 16, 16, 16, 4)
+  WSL_CASE(1, 4, 32, 32, 32, 1) WSL_CASE(1, 8, 16, 32, 32, 1)
+#undef WSL_CASE
+  set_error("wgrad2: no kernel for ks %d tile %dx%d cb %d ib %d", ks, th, tw, cb, ib);
+  return WSL_EUNSUPPORTED;
+}
+
+}  // namespace wsl

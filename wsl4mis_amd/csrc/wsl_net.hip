@@ -32,7 +32,7 @@ struct Plan {
   BlkWs wenc[5];
   size_t pooled[5];
   struct DecWs { size_t u[4], up[4], dcat[4], glow4; BlkWs blk[4]; } wdec[2];
-  size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws;
+  size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws, packf, packd;
   size_t wg_bytes, bn_bytes, total_floats;
 };
 
@@ -129,6 +129,7 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   P.tmp_du = B.take(big / 4), P.tmp_gpool = B.take(big / 4);
   P.stat_part = B.take(max_stat), P.stat_cnt = B.take(max_cnt);
   P.wg_ws = B.take((P.wg_bytes + 3) / 4), P.bn_ws = B.take((P.bn_bytes + 3) / 4);
+  P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);  // packed [tap][ci][co] weight images (fwd / data-gradient)
   P.total_floats = B.off;
   return WSL_OK;
 }
@@ -164,6 +165,39 @@ static WslSrc act_src(const Ctx& c, size_t y, size_t st, int C, int HW, const ui
     if (int rc_ = (expr)) return rc_; \
   } while (0)
 
+// forward (dgrad == 0) or data-gradient (dgrad == 1) convolution of layer `cv`: the packed fast path when the shapes
+// are float4-aligned (every layer of a net whose H, W are multiples of 16), the generic kernel otherwise.
+static int conv_any(const Ctx& c, const ConvRef& cv, int dgrad, const WslSrc* a, const WslSrc* b, const float* bias,
+                    float* y, int64_t y_bs, int H, int W, float* stp, float* stc) {
+  const int N = c.P.d.N, Co = dgrad ? cv.Ci : cv.Co;
+  if (wsl_conv2d_fast_ok(a, b, y, y_bs, W))
+    return wsl_conv2d_fwd(a, b, c.ws + (dgrad ? c.P.packd : c.P.packf) + cv.w, bias, y, y_bs, N, H, W, Co, cv.ks,
+                          dgrad ? 3 : 2, stp, stc, c.stream);
+  return wsl_conv2d_fwd(a, b, c.params + cv.w, bias, y, y_bs, N, H, W, Co, cv.ks, dgrad, stp, stc, c.stream);
+}
+
+static int pack_all(const Ctx& c, int dgrad) {
+  const Plan& P = c.P;
+  float* dst = c.ws + (dgrad ? P.packd : P.packf);
+  auto one = [&](const ConvRef& cv) {
+    return wsl_conv2d_pack_weights(c.params + cv.w, dst + cv.w, dgrad ? cv.Ci : cv.Co, dgrad ? cv.Co : cv.Ci, cv.ks, dgrad,
+                                   c.stream);
+  };
+  for (int l = 0; l < 5; ++l) {
+    WSL_TRY(one(P.enc[l].c1));
+    WSL_TRY(one(P.enc[l].c2));
+  }
+  for (int k = 0; k < P.d.n_dec; ++k) {
+    for (int i = 0; i < 4; ++i) {
+      WSL_TRY(one(P.dec[k].c1x1[i]));
+      WSL_TRY(one(P.dec[k].blk[i].c1));
+      WSL_TRY(one(P.dec[k].blk[i].c2));
+    }
+    WSL_TRY(one(P.dec[k].out));
+  }
+  return WSL_OK;
+}
+
 // conv + (train: batch statistics -> BN coefficients | eval: running statistics)
 static int conv_bn_fwd(const Ctx& c, const ConvRef& cv, const BnRef& bn, const WslSrc* a, const WslSrc* b, size_t y,
                        size_t st, int H, int W) {
@@ -171,8 +205,7 @@ static int conv_bn_fwd(const Ctx& c, const ConvRef& cv, const BnRef& bn, const W
   const int N = P.d.N, C = cv.Co;
   float* stp = c.training ? c.ws + P.stat_part : nullptr;
   float* stc = c.training ? c.ws + P.stat_cnt : nullptr;
-  WSL_TRY(wsl_conv2d_fwd(a, b, c.params + cv.w, c.params + cv.b, c.ws + y, (int64_t)C * H * W, N, H, W, C, cv.ks, 0, stp,
-                         stc, c.stream));
+  WSL_TRY(conv_any(c, cv, 0, a, b, c.params + cv.b, c.ws + y, (int64_t)C * H * W, H, W, stp, stc));
   float* s = c.ws + st;
   if (c.training) {
     const int nblk = wsl_conv2d_stat_blocks(N, H, W, cv.Ci, C, cv.ks);
@@ -210,7 +243,7 @@ static int block_bwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslS
   WSL_TRY(wsl_conv2d_wgrad(&mid, nullptr, dy, CHW, c.grads + k.c2.w, c.grads + k.c2.b, N, H, W, C, 3, c.ws + P.wg_ws,
                            P.wg_bytes, c.stream));
   const WslSrc dys = raw_src(dy, C, CHW);
-  WSL_TRY(wsl_conv2d_fwd(&dys, nullptr, c.params + k.c2.w, nullptr, g1, CHW, N, H, W, C, 3, 1, nullptr, nullptr, c.stream));
+  WSL_TRY(conv_any(c, k.c2, 1, &dys, nullptr, nullptr, g1, CHW, H, W, nullptr, nullptr));
   // BN1 + LeakyReLU + Dropout(p)
   WSL_TRY(wsl_bnact_bwd(g1, CHW, c.ws + w.y1, s1, s1 + C, c.params + k.b1.gamma, c.params + k.b1.beta, emask, es, dy,
                         c.grads + k.b1.gamma, c.grads + k.b1.beta, N, C, H, W, c.ws + P.bn_ws, P.bn_bytes, c.stream));
@@ -218,8 +251,7 @@ static int block_bwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslS
                            c.stream));
   if (dgrad_out) {
     const WslSrc dys1 = raw_src(dy, C, CHW);
-    WSL_TRY(wsl_conv2d_fwd(&dys1, nullptr, c.params + k.c1.w, nullptr, dgrad_out, (int64_t)k.c1.Ci * H * W, N, H, W,
-                           k.c1.Ci, 3, 1, nullptr, nullptr, c.stream));
+    WSL_TRY(conv_any(c, k.c1, 1, &dys1, nullptr, nullptr, dgrad_out, (int64_t)k.c1.Ci * H * W, H, W, nullptr, nullptr));
   }
   return WSL_OK;
 }
@@ -237,8 +269,8 @@ static int decoder_fwd(const Ctx& c, int k, const float* const* cmasks, float* l
     const WslSrc low = i == 0 ? feat_src(c, 4, cmasks ? cmasks[4] : nullptr)
                               : act_src(c, P.wdec[k].blk[i - 1].y2, P.wdec[k].blk[i - 1].st2, c1, h * w, nullptr, 1.f, nullptr);
     const ConvRef& cv = P.dec[k].c1x1[i];
-    WSL_TRY(wsl_conv2d_fwd(&low, nullptr, c.params + cv.w, c.params + cv.b, c.ws + P.wdec[k].u[i], (int64_t)c2 * h * w, N,
-                           h, w, c2, 1, 0, nullptr, nullptr, c.stream));
+    WSL_TRY(conv_any(c, cv, 0, &low, nullptr, c.params + cv.b, c.ws + P.wdec[k].u[i], (int64_t)c2 * h * w, h, w, nullptr,
+                     nullptr));
     WSL_TRY(wsl_bilinear_up2_fwd(c.ws + P.wdec[k].u[i], c.ws + P.wdec[k].up[i], (int64_t)c2 * H * W, N, c2, h, w, c.stream));
     const WslSrc skip = feat_src(c, l, cmasks ? cmasks[l] : nullptr);
     const WslSrc up = raw_src(c.ws + P.wdec[k].up[i], c2, (int64_t)c2 * H * W);
@@ -246,8 +278,8 @@ static int decoder_fwd(const Ctx& c, int k, const float* const* cmasks, float* l
   }
   const WslSrc last = act_src(c, P.wdec[k].blk[3].y2, P.wdec[k].blk[3].st2, kFt[0], P.H[0] * P.W[0], nullptr, 1.f, nullptr);
   const ConvRef& oc = P.dec[k].out;
-  return wsl_conv2d_fwd(&last, nullptr, c.params + oc.w, c.params + oc.b, logits, (int64_t)oc.Co * P.H[0] * P.W[0], N, P.H[0],
-                        P.W[0], oc.Co, 3, 0, nullptr, nullptr, c.stream);
+  return conv_any(c, oc, 0, &last, nullptr, c.params + oc.b, logits, (int64_t)oc.Co * P.H[0] * P.W[0], P.H[0], P.W[0], nullptr,
+                  nullptr);
 }
 
 static int decoder_bwd(const Ctx& c, int k, const float* const* cmasks, const float* dlogits) {
@@ -259,8 +291,7 @@ static int decoder_bwd(const Ctx& c, int k, const float* const* cmasks, const fl
   WSL_TRY(wsl_conv2d_wgrad(&last, nullptr, dlogits, (int64_t)oc.Co * H0 * W0, c.grads + oc.w, c.grads + oc.b, N, H0, W0,
                            oc.Co, 3, c.ws + P.wg_ws, P.wg_bytes, c.stream));
   const WslSrc dl = raw_src(dlogits, oc.Co, (int64_t)oc.Co * H0 * W0);
-  WSL_TRY(wsl_conv2d_fwd(&dl, nullptr, c.params + oc.w, nullptr, g, (int64_t)kFt[0] * H0 * W0, N, H0, W0, kFt[0], 3, 1,
-                         nullptr, nullptr, c.stream));
+  WSL_TRY(conv_any(c, oc, 1, &dl, nullptr, nullptr, g, (int64_t)kFt[0] * H0 * W0, H0, W0, nullptr, nullptr));
   for (int i = 3; i >= 0; --i) {
     const int l = 3 - i, c1 = kFt[l + 1], c2 = kFt[l];
     const int h = P.H[l + 1], w = P.W[l + 1], H = P.H[l], W = P.W[l];
@@ -278,8 +309,7 @@ static int decoder_bwd(const Ctx& c, int k, const float* const* cmasks, const fl
                              c.ws + P.wg_ws, P.wg_bytes, c.stream));
     const WslSrc dus = raw_src(du, c2, (int64_t)c2 * h * w);
     float* glow = i == 0 ? c.ws + P.wdec[k].glow4 : g;
-    WSL_TRY(wsl_conv2d_fwd(&dus, nullptr, c.params + cv.w, nullptr, glow, (int64_t)c1 * h * w, N, h, w, c1, 1, 1, nullptr,
-                           nullptr, c.stream));
+    WSL_TRY(conv_any(c, cv, 1, &dus, nullptr, nullptr, glow, (int64_t)c1 * h * w, h, w, nullptr, nullptr));
   }
   return WSL_OK;
 }
@@ -411,6 +441,8 @@ extern "C" int wsl_net_forward(const WslNetDesc* d, const float* params, float* 
   }
   Ctx c{P, params, buffers, nbt, nullptr, static_cast<float*>(ws), stream, training};
   const int N = d->N;
+  WSL_TRY(pack_all(c, 0));
+  if (training) WSL_TRY(pack_all(c, 1));   // the data-gradient images the backward of this step will read
   for (int l = 0; l < 5; ++l) {
     const int H = P.H[l], W = P.W[l];
     WslSrc in;
