@@ -517,17 +517,32 @@ def gen_curve_and_ddp():
 
     # G8 DDP-equivalent: two shards, per-shard BN stats/loss normalisation, gradients averaged.
     out = {}
-    torch.manual_seed(8)
     random.seed(8)
-    x = torch.rand(4, 1, 32, 32)
     lab = scribble_labels(4, 32, 32, seed=9)
     beta = random.random() + 1e-10
-    shard_grads = []
+    for attempt in range(200):       # both shards clear of gradient discontinuities (see KinkMargins)
+        torch.manual_seed(8 + 1000 * attempt)
+        x = torch.rand(4, 1, 32, 32)
+        ok = True
+        state = torch.get_rng_state()
+        for r in range(2):
+            model = UNet_CCT(1, 4).train()
+            load_det(model, 9)
+            with torch.no_grad(), DropoutRecorder(), KinkMargins() as km:
+                model(x[2 * r:2 * r + 2])
+            ok = ok and km.leaky > 4e-6 and km.pool > 1e-6
+        if ok:
+            torch.set_rng_state(state)
+            break
+    else:
+        raise RuntimeError("g8: no well-separated input found")
+    shard_grads, margins = [], []
     for r in range(2):
         model = UNet_CCT(1, 4).train()
         load_det(model, 9)
-        with DropoutRecorder() as rec:
+        with DropoutRecorder() as rec, KinkMargins() as km:
             o1, o2 = model(x[2 * r:2 * r + 2])
+        margins.append([km.leaky, km.pool])
         res = ours_proposed_loss(o1, o2, torch.from_numpy(lab[2 * r:2 * r + 2]), beta)
         res["loss"].backward()
         shard_grads.append({k: p.grad.detach().numpy().astype(np.float64) for k, p in model.named_parameters()})
@@ -536,6 +551,8 @@ def gen_curve_and_ddp():
         for i, cm in enumerate(rec.chan):
             out[f"r{r}_cmask{i}"] = cm
         out[f"r{r}_loss"] = np.float32(res["loss"].item())
+    print(f"    g8: attempt {attempt}, margins {margins}")
+    out["margins"] = np.min(np.array(margins), axis=0)
     for k in shard_grads[0]:
         g = (0.5 * (shard_grads[0][k] + shard_grads[1][k])).ravel()
         idx = sample_index(g.size)

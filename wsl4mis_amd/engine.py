@@ -76,6 +76,12 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ one optimiser step
     def step(self, x, label_u8, beta):
+        """One optimiser step: forward, loss, backward (+ gradient all-reduce), SGD, poly-LR update."""
+        self.forward_backward(x, label_u8, beta)
+        self.optimizer_step()
+
+    def forward_backward(self, x, label_u8, beta):
+        """Everything up to (and including) the gradient all-reduce; flat_grads() then holds the SUM over ranks."""
         m = self.model
         x = rt.f32c(x, "image batch")
         N, _, H, W = x.shape
@@ -110,6 +116,9 @@ class TrainEngine:
                 torch.cuda.current_stream().wait_stream(self.comm)
         else:
             m._run_backward(x, g, phase=0)
+
+    def optimizer_step(self):
+        m = self.model
         rt.call("wsl_sgd_step", rt.ptr(m._param_arena), rt.ptr(m._grad_arena), rt.ptr(self.mom), self.n, float(self.lr),
                 self.mu, self.wd, int(self.it == 0), 1.0 / self.world, None, 0.0, rt.stream())
         self.lr = self.base_lr * (1.0 - self.it / self.max_it) ** 0.9      # takes effect at the NEXT step
