@@ -186,6 +186,12 @@ int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* loss, float* 
 int wsl_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float wd, int first,
                  float grad_scale, float* ema, float ema_alpha, void* stream);
 
+/* Bernoulli masks for nn.Dropout / F.dropout2d in ONE launch (Philox4x32-10, counter-based: reproducible per seed).
+ * Mask i: is_f32[i] == 0 -> uint8 keep mask (1 with probability keep_probs[i]); == 1 -> float multiplier
+ * (scales[i] with probability keep_probs[i], else 0).  uint8 outputs must be 4-byte aligned.  n_masks <= 12. */
+int wsl_draw_masks(int n_masks, void* const* outs, const int64_t* numels, const float* keep_probs, const float* scales,
+                   const int* is_f32, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ network
  * UNet / UNet_CCT (ref: networks/unet.py:286-303, 327-346; factory: networks/net_factory.py:6-22) over a flat fp32
  * parameter arena whose entry order is the reference module's parameters() order and whose names are its

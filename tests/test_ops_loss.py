@@ -157,3 +157,25 @@ def test_sgd_ema_golden(be):
     be.call("wsl_sgd_step", be.ptr(p2) + 4, be.ptr(g2) + 4, be.ptr(b2) + 4, 999, 0.01, 0.9, 1e-4, 1, 1.0, None, 0.0, be.stream)
     ref = g["p0"][1:1000] - 0.01 * (g["grads"][0][1:1000] + 1e-4 * g["p0"][1:1000])
     assert rel_err(be.np(p2)[1:1000], ref) < 1e-6 and be.np(p2)[0] == g["p0"][0] and be.np(p2)[1000] == g["p0"][1000]
+
+
+def test_draw_masks_statistics_and_determinism(be):
+    import ctypes as C
+    sizes = [100003, 4096, 7, 64 * 16]
+    probs, scales, isf = [0.95, 0.5, 0.7, 0.5], [1.0, 1.0, 1.0, 2.0], [0, 0, 0, 1]
+
+    def draw(seed):
+        outs = [be.zeros((n,), np.float32 if f else np.uint8) for n, f in zip(sizes, isf)]
+        arr = (C.c_void_p * 4)(*[be.ptr(o) for o in outs])
+        be.call("wsl_draw_masks", 4, arr, (C.c_int64 * 4)(*sizes), (C.c_float * 4)(*probs), (C.c_float * 4)(*scales),
+                (C.c_int * 4)(*isf), C.c_uint64(seed), be.stream)
+        return [be.np(o).copy() for o in outs]
+
+    a, b, c = draw(1234), draw(1234), draw(99)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)                       # same seed -> same masks
+    assert not np.array_equal(a[0], c[0])                 # other seed -> other masks
+    assert set(np.unique(a[0])) <= {0, 1} and abs(a[0].mean() - 0.95) < 4 * np.sqrt(0.95 * 0.05 / sizes[0])
+    assert abs(a[1].mean() - 0.5) < 4 * np.sqrt(0.25 / sizes[1])
+    assert set(np.unique(a[3])) <= {0.0, 2.0} and abs((a[3] > 0).mean() - 0.5) < 4 * np.sqrt(0.25 / sizes[3])
+    assert not np.array_equal(a[1][:7], a[2])             # masks of one call use distinct counter streams

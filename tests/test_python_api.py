@@ -102,6 +102,30 @@ def test_module_autograd_matches_reference_script_composition(mode):
         model(x.clone().requires_grad_())
 
 
+def test_masks_are_drawn_reproducibly_from_torch_seed(mode):
+    from wsl4mis_amd.networks.net_factory import net_factory
+    m = net_factory("unet_cct", 1, 4)
+    x = torch.rand(2, 1, 16, 16).to(dev())
+    m.train()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        m(x)
+    em1, cm1 = [t.clone() for t in m._last_masks[0]], [t.clone() for t in m._last_masks[1]]
+    torch.manual_seed(5)
+    with torch.no_grad():
+        m(x)
+    assert all(torch.equal(a, b) for a, b in zip(em1, m._last_masks[0]))
+    assert all(torch.equal(a, b) for a, b in zip(cm1, m._last_masks[1]))
+    with torch.no_grad():
+        m(x)                                                   # next draw differs
+    assert not torch.equal(em1[0], m._last_masks[0][0])
+    assert abs(em1[0].float().mean().item() - 0.95) < 0.02 and set(cm1[0].unique().tolist()) <= {0.0, 2.0}
+    m.eval()                                                   # eval: no elementwise dropout, aux dropout2d still drawn
+    with torch.no_grad():
+        m(x)
+    assert m._last_masks[0] is None and m._last_masks[1] is not None
+
+
 def test_eval_and_state_dict_roundtrip(mode):
     from wsl4mis_amd.networks.net_factory import net_factory
     g = golden("g2_unet32")

@@ -64,7 +64,12 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
   float* sh_l = sc_l + C::MAXC;      // [Ci] shift
   float* cm_l = sh_l + C::MAXC;      // [Ci] channel multiplier of this sample (1 if none)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order (speed only): workgroup b is observed to run on XCD b % 8, each XCD has its own L2.  Give
+  // every XCD a contiguous run of spatial tiles so vertically adjacent tiles share their halo rows in one L2.
   int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int tile_id = bid;     // index of the per-block BatchNorm partials
   const int tx_i = bid % p.tiles_x;
   bid /= p.tiles_x;
   const int ty_i = bid % p.tiles_y;
@@ -277,12 +282,12 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
       for (int j = 0; j < C::NT; ++j) {
         const int col = j * 16 + lane, co = co0 + col;
         if (co < p.Co) {
-          float* dst = p.stat_part + ((int64_t)blockIdx.x * p.Co + co) * 2;
+          float* dst = p.stat_part + ((int64_t)tile_id * p.Co + co) * 2;
           dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
           dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
         }
       }
-      if (lane == 0 && blockIdx.y == 0) p.stat_cnt[blockIdx.x] = cnt;
+      if (lane == 0 && blockIdx.y == 0) p.stat_cnt[tile_id] = cnt;
     }
   }
 }
@@ -296,6 +301,27 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float
     const int ci = (int)(r % Ci), tap = (int)(r / Ci);
     wp[e] = wmode == 0 ? w[((int64_t)co * Ci + ci) * KK + tap] : w[((int64_t)ci * Co + co) * KK + (KK - 1 - tap)];
   }
+}
+
+// every conv layer of a network in ONE launch: blockIdx.y = layer, blockIdx.z = 0 forward image / 1 data-gradient image
+__global__ __launch_bounds__(256) void pack_table_kernel(PackTable t, const float* params, float* packf, float* packd) {
+  const PackEntry e = t.e[blockIdx.y];
+  const int dgrad = blockIdx.z;
+  const int Co = dgrad ? e.Ci : e.Co, Ci = dgrad ? e.Co : e.Ci, KK = e.KK;   // GEMM-out / GEMM-in of this image
+  const float* w = params + e.w;
+  float* wp = (dgrad ? packd : packf) + e.w;
+  const int64_t total = (int64_t)KK * Ci * Co;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int co = (int)(i % Co);
+    const int64_t r = i / Co;
+    const int ci = (int)(r % Ci), tap = (int)(r / Ci);
+    wp[i] = dgrad ? w[((int64_t)ci * Co + co) * KK + (KK - 1 - tap)] : w[((int64_t)co * Ci + ci) * KK + tap];
+  }
+}
+
+int conv2_pack_table(const PackTable& t, const float* params, float* packf, float* packd, int with_dgrad, void* stream) {
+  WSL_LAUNCH(pack_table_kernel, dim3(32, t.n, with_dgrad ? 2 : 1), dim3(kThreads), 0, stream, t, params, packf, packd);
+  return check_launch("pack_table_kernel");
 }
 
 template <int KS, int TH, int TW, int CO_T>

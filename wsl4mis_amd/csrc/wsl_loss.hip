@@ -344,6 +344,8 @@ __global__ __launch_bounds__(256) void gatedcrf_fwd_kernel(CrfP q, float* part) 
   const int r = q.r, TS = 16 + 2 * r, C = q.C;
   float* yt = reinterpret_cast<float*>(smem);   // [C][TS*TS]
   float* it = yt + C * TS * TS;                 // [TS*TS] image / sigma_rgb, 0 outside
+  float* fxt = it + TS * TS;                    // [TS] column feature x / sigma_xy (0 outside the image)
+  float* fyt = fxt + TS;                        // [TS] row feature
   int bid = blockIdx.x;
   const int tx_i = bid % q.tiles_x;
   bid /= q.tiles_x;
@@ -356,24 +358,31 @@ __global__ __launch_bounds__(256) void gatedcrf_fwd_kernel(CrfP q, float* part) 
     it[e] = in ? q.img[n * HW + (int64_t)gy * q.W + gx] / q.srgb : 0.f;
     for (int c = 0; c < C; ++c) yt[c * TS * TS + e] = in ? q.y[((int64_t)n * C + c) * HW + (int64_t)gy * q.W + gx] : 0.f;
   }
+  if ((int)threadIdx.x < TS) {
+    const int gx = x0 + (int)threadIdx.x - r, gy = y0 + (int)threadIdx.x - r;
+    fxt[threadIdx.x] = (gx >= 0 && gx < q.W) ? (float)gx / q.sxy : 0.f;
+    fyt[threadIdx.x] = (gy >= 0 && gy < q.H) ? (float)gy / q.sxy : 0.f;
+  }
   __syncthreads();
   const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15, gy = y0 + ly, gx = x0 + lx;
   float v[2] = {0.f, 0.f};
   if (gy < q.H && gx < q.W) {
     const int ce = (ly + r) * TS + lx + r;
-    const float fpx = (float)gx / q.sxy, fpy = (float)gy / q.sxy, fpi = it[ce];
+    const float fpx = fxt[lx + r], fpy = fyt[ly + r], fpi = it[ce];
     float m[kMaxC];
     for (int c = 0; c < C; ++c) m[c] = 0.f;
     float ks = 0.f;
     for (int dy = -r; dy <= r; ++dy) {
       const int qy = gy + dy;
       const bool iny = qy >= 0 && qy < q.H;
+      const float rowf = fyt[ly + r + dy];
       for (int dx = -r; dx <= r; ++dx) {
         if (dy == 0 && dx == 0) continue;
         const int qx = gx + dx;
         const bool in = iny && qx >= 0 && qx < q.W;
         const int te = ce + dy * TS + dx;
-        const float fqx = in ? (float)qx / q.sxy : 0.f, fqy = in ? (float)qy / q.sxy : 0.f, fqi = it[te];
+        // a tap outside the image sees the all-zero feature vector of the zero-padded unfold (gate_crf_loss.py:184-188)
+        const float fqx = in ? fxt[lx + r + dx] : 0.f, fqy = in ? rowf : 0.f, fqi = it[te];
         const float ddx = fqx - fpx, ddy = fqy - fpy, ddi = fqi - fpi;
         const float e = (-0.5f * (ddx * ddx)) + (-0.5f * (ddy * ddy)) + (-0.5f * (ddi * ddi));
         const float k = q.weight * expf(e);
@@ -742,7 +751,7 @@ extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, fl
   CrfP q{y, img, msg, N, C, H, W, radius, sigma_xy, sigma_rgb, weight, cdiv(W, 16), cdiv(H, 16)};
   const int nb = N * q.tiles_x * q.tiles_y;
   const int TS = 16 + 2 * radius;
-  const size_t smem = sizeof(float) * (size_t)(C + 1) * TS * TS;
+  const size_t smem = sizeof(float) * ((size_t)(C + 1) * TS * TS + 2 * TS);
   float* part = static_cast<float*>(ws);
   void* tok = prof_begin(4, 0.0, 4.0 * (double)N * H * W * (2 * C + 1), stream);
   WSL_LAUNCH(gatedcrf_fwd_kernel, dim3(nb), dim3(kThreads), smem, stream, q, part);

@@ -176,26 +176,17 @@ static int conv_any(const Ctx& c, const ConvRef& cv, int dgrad, const WslSrc* a,
   return wsl_conv2d_fwd(a, b, c.params + cv.w, bias, y, y_bs, N, H, W, Co, cv.ks, dgrad, stp, stc, c.stream);
 }
 
-static int pack_all(const Ctx& c, int dgrad) {
+static int pack_all(const Ctx& c, int with_dgrad) {
   const Plan& P = c.P;
-  float* dst = c.ws + (dgrad ? P.packd : P.packf);
-  auto one = [&](const ConvRef& cv) {
-    return wsl_conv2d_pack_weights(c.params + cv.w, dst + cv.w, dgrad ? cv.Ci : cv.Co, dgrad ? cv.Co : cv.Ci, cv.ks, dgrad,
-                                   c.stream);
-  };
-  for (int l = 0; l < 5; ++l) {
-    WSL_TRY(one(P.enc[l].c1));
-    WSL_TRY(one(P.enc[l].c2));
-  }
+  PackTable t;
+  t.n = 0;
+  auto one = [&](const ConvRef& cv) { t.e[t.n++] = PackEntry{cv.w, cv.Co, cv.Ci, cv.ks * cv.ks, 0}; };
+  for (int l = 0; l < 5; ++l) one(P.enc[l].c1), one(P.enc[l].c2);
   for (int k = 0; k < P.d.n_dec; ++k) {
-    for (int i = 0; i < 4; ++i) {
-      WSL_TRY(one(P.dec[k].c1x1[i]));
-      WSL_TRY(one(P.dec[k].blk[i].c1));
-      WSL_TRY(one(P.dec[k].blk[i].c2));
-    }
-    WSL_TRY(one(P.dec[k].out));
+    for (int i = 0; i < 4; ++i) one(P.dec[k].c1x1[i]), one(P.dec[k].blk[i].c1), one(P.dec[k].blk[i].c2);
+    one(P.dec[k].out);
   }
-  return WSL_OK;
+  return conv2_pack_table(t, c.params, c.ws + P.packf, c.ws + P.packd, with_dgrad, c.stream);
 }
 
 // conv + (train: batch statistics -> BN coefficients | eval: running statistics)
@@ -441,8 +432,7 @@ extern "C" int wsl_net_forward(const WslNetDesc* d, const float* params, float* 
   }
   Ctx c{P, params, buffers, nbt, nullptr, static_cast<float*>(ws), stream, training};
   const int N = d->N;
-  WSL_TRY(pack_all(c, 0));
-  if (training) WSL_TRY(pack_all(c, 1));   // the data-gradient images the backward of this step will read
+  WSL_TRY(pack_all(c, training));   // packed weight images; training also builds the data-gradient ones for the backward
   for (int l = 0; l < 5; ++l) {
     const int H = P.H[l], W = P.W[l];
     WslSrc in;

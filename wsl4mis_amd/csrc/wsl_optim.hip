@@ -47,9 +47,80 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dropout masks
+// Philox4x32-10 counter-based generator (Salmon et al. 2011): 4 x 32 random bits per (key, counter); element e of mask
+// m uses counter (e / 4, m) -- reproducible for a given seed, independent of grid shape.
+__device__ __forceinline__ void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                        uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1, c3 = (uint32_t)p0, c0 = n0, c2 = n2;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+struct MaskTable {
+  int n;
+  struct {
+    void* out;        // uint8 keep mask (is_f32 == 0) or float multiplier (is_f32 == 1)
+    int64_t numel;
+    uint32_t thresh;  // keep iff u32 < thresh  (thresh = keep_prob * 2^32)
+    float scale;      // multiplier written for kept entries of a float mask
+    int is_f32, _pad;
+  } e[12];
+};
+
+__global__ __launch_bounds__(256) void masks_kernel(MaskTable t, uint32_t k0, uint32_t k1) {
+  const int m = blockIdx.y;
+  const int64_t n4 = (t.e[m].numel + 3) >> 2;
+  const uint32_t th = t.e[m].thresh;
+  for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < n4; q += (int64_t)gridDim.x * kThreads) {
+    uint32_t r[4];
+    philox4(k0, k1, (uint32_t)q, (uint32_t)(q >> 32), (uint32_t)m, 0x57534c34u, r);
+    const int64_t e = q << 2;
+    if (t.e[m].is_f32) {
+      float* o = static_cast<float*>(t.e[m].out);
+      for (int k = 0; k < 4; ++k)
+        if (e + k < t.e[m].numel) o[e + k] = r[k] < th ? t.e[m].scale : 0.f;
+    } else {
+      uint8_t* o = static_cast<uint8_t*>(t.e[m].out);
+      if (e + 3 < t.e[m].numel) {
+        *reinterpret_cast<uchar4*>(o + e) = make_uchar4(r[0] < th, r[1] < th, r[2] < th, r[3] < th);
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (e + k < t.e[m].numel) o[e + k] = r[k] < th;
+      }
+    }
+  }
+}
+
 }  // namespace wsl
 
 using namespace wsl;
+
+extern "C" int wsl_draw_masks(int n_masks, void* const* outs, const int64_t* numels, const float* keep_probs,
+                              const float* scales, const int* is_f32, uint64_t seed, void* stream) {
+  WSL_REQUIRE(n_masks > 0 && n_masks <= 12 && outs && numels && keep_probs && scales && is_f32, "draw_masks: bad args");
+  MaskTable t;
+  t.n = n_masks;
+  int64_t biggest = 1;
+  for (int i = 0; i < n_masks; ++i) {
+    WSL_REQUIRE(outs[i] && numels[i] > 0 && keep_probs[i] >= 0.f && keep_probs[i] <= 1.f, "draw_masks: bad mask %d", i);
+    const double th = (double)keep_probs[i] * 4294967296.0;
+    t.e[i].out = outs[i], t.e[i].numel = numels[i], t.e[i].scale = scales[i], t.e[i].is_f32 = is_f32[i], t.e[i]._pad = 0;
+    t.e[i].thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    if (numels[i] > biggest) biggest = numels[i];
+  }
+  int64_t blocks = (biggest / 4 + kThreads - 1) / kThreads;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  WSL_LAUNCH(masks_kernel, dim3((unsigned)blocks, n_masks), dim3(kThreads), 0, stream, t, (uint32_t)seed,
+             (uint32_t)(seed >> 32));
+  return check_launch("masks_kernel");
+}
 
 extern "C" int wsl_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float wd,
                             int first, float grad_scale, float* ema, float ema_alpha, void* stream) {

@@ -77,4 +77,16 @@ __device__ __forceinline__ float src_value(const WslSrc& s, int n, int c, int64_
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// table of the conv layers of one network (kernel argument of pack_table_kernel, wsl_conv2.hip)
+struct PackEntry {
+  int64_t w;       // offset of the raw [Co][Ci][ks][ks] weight in the parameter arena (= offset of its packed images)
+  int Co, Ci, KK;
+  int _pad;
+};
+struct PackTable {
+  int n;
+  PackEntry e[40];
+};
+int conv2_pack_table(const PackTable& t, const float* params, float* packf, float* packd, int with_dgrad, void* stream);
+
 }  // namespace wsl

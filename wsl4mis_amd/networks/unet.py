@@ -140,10 +140,32 @@ class _HipUNet(nn.Module):
             em, cm = self._forced_masks
         else:
             em = cm = None
-        if training and em is None:
-            em = [(torch.rand((N, _FT[l], H >> l, W >> l), device=dev) >= _DROP[l]).to(torch.uint8) for l in range(5)]
-        if self._n_dec == 2 and cm is None:     # F.dropout2d(x, 0.5) is active in eval mode too (unet.py:254-256,344)
-            cm = [(torch.rand((N, _FT[l]), device=dev) >= 0.5).to(torch.float32) * 2.0 for l in range(5)]
+        want_e = training and em is None
+        want_c = self._n_dec == 2 and cm is None     # F.dropout2d(x, 0.5) is active in eval mode too (unet.py:254-256,344)
+        if want_e or want_c:
+            key = (N, H, W)
+            if getattr(self, "_mask_key", None) != key:     # persistent mask buffers, refilled in place every forward
+                self._mask_e = [torch.empty((N, _FT[l], H >> l, W >> l), dtype=torch.uint8, device=dev) for l in range(5)]
+                self._mask_c = [torch.empty((N, _FT[l]), dtype=torch.float32, device=dev) for l in range(5)]
+                self._mask_key = key
+            outs, probs, scales, isf = [], [], [], []
+            if want_e:
+                em = self._mask_e
+                outs += em
+                probs += [1.0 - p for p in _DROP]
+                scales += [1.0] * 5
+                isf += [0] * 5
+            if want_c:
+                cm = self._mask_c
+                outs += cm
+                probs += [0.5] * 5
+                scales += [2.0] * 5
+                isf += [1] * 5
+            n = len(outs)
+            # the seed comes from torch's (CPU) generator: torch.manual_seed() keeps runs reproducible, no device sync
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            rt.call("wsl_draw_masks", n, rt.ptr_array(outs), (C.c_int64 * n)(*[t.numel() for t in outs]),
+                    (C.c_float * n)(*probs), (C.c_float * n)(*scales), (C.c_int * n)(*isf), C.c_uint64(seed), rt.stream())
         return em, cm
 
     # ------------------------------------------------------------------ execution
