@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Times one conv layer through the C ABI (packed fast path) with HIP events on the launch stream.
+   python tools/microbench_conv.py N Ci Co H W [ks] [dgrad]      (WSL_CONV_ABLATE=1|2|4 for phase ablations)"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wsl4mis_amd import _lib  # noqa: E402
+
+N, Ci, Co, H, W = (int(a) for a in sys.argv[1:6])
+ks = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+L = _lib.lib()
+dev = torch.device("cuda:0")
+x = torch.randn(N, Ci, H, W, device=dev)
+w = torch.randn(Co, Ci, ks, ks, device=dev) * 0.05
+wp = torch.empty(ks * ks * Ci * Co, device=dev)
+y = torch.empty(N, Co, H, W, device=dev)
+scale, shift = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.1
+s = _lib.WslSrc()
+s.x, s.bs, s.C, s.scale, s.shift, s.emask_scale = x.data_ptr(), Ci * H * W, Ci, scale.data_ptr(), shift.data_ptr(), 1.0
+nblk = L.wsl_conv2d_stat_blocks(N, H, W, Ci, Co, ks)
+part, cnt = torch.empty(nblk * Co * 2, device=dev), torch.empty(nblk, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+_lib.check(L.wsl_conv2d_pack_weights(w.data_ptr(), wp.data_ptr(), Co, Ci, ks, 0, st))
+
+
+def run():
+    _lib.check(L.wsl_conv2d_fwd(C.byref(s), None, wp.data_ptr(), None, y.data_ptr(), Co * H * W, N, H, W, Co, ks, 2,
+                                part.data_ptr(), cnt.data_ptr(), st))
+
+
+for _ in range(3):
+    run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+R = 20
+for _ in range(R):
+    run()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / R
+fl = 2.0 * N * H * W * Co * Ci * ks * ks
+print(f"ablate={os.environ.get('WSL_CONV_ABLATE','0')} N={N} {Ci}->{Co} {H}x{W} k{ks}: {us:8.1f} us  {fl/us/1e6:7.1f} TFLOP/s  "
+      f"in+out {4.0*N*H*W*(Ci+Co)/us/1e3:7.1f} GB/s")

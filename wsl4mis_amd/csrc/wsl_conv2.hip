@@ -10,6 +10,8 @@
 //     contiguous rows copied with float4 loads instead of a 4-byte gather;
 //   * the producer's BN scale/shift live in LDS for the whole workgroup.
 // Requires W % 4 == 0 and 16-byte aligned tensors / batch strides; anything else takes the v1 kernels.
+#include <stdlib.h>
+
 #include "wsl_rt.h"
 
 namespace wsl {
@@ -34,6 +36,7 @@ struct Conv2P {
   int N, H, W, Ci, Co, tiles_x, tiles_y;
   float* stat_part;
   float* stat_cnt;
+  int ablate;   // debug (env WSL_CONV_ABLATE): 1 skip MFMA, 2 skip staging after the first chunk, 4 skip epilogue
 };
 
 template <int KS, int TH, int TW, int CO_T, int KC>
@@ -53,6 +56,30 @@ struct Conv2Cfg {
   static_assert(POS <= 256 && G >= 1, "one float4 position per thread");
   static_assert(MT_TOTAL % 4 == 0 && KC % 4 == 0 && (8 * CO_T) <= IN_FLOATS, "tile shape");
 };
+
+template <typename C, int KS, int KC, int NG>
+__device__ __forceinline__ void conv2_mfma_stages(const float* in_t, const float* w_t, const int (&abase)[C::MT], int bbase,
+                                                   v4f (&acc)[C::MT][C::NT]) {
+  constexpr int NS = KS * KS * NG;   // stages
+  float av[2][C::MT], bv[2][C::NT];
+  auto load = [&](int s, int buf) {
+    const int tap = s / NG, cg = s % NG, ky = tap / KS, kx = tap % KS;
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) bv[buf][j] = w_t[(tap * KC + cg * 4) * C::CSTR + j * 16 + bbase];
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i) av[buf][i] = in_t[cg * 4 * C::PLANE + ky * C::ROWP + kx + abase[i]];
+  };
+  load(0, 0);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (s + 1 < NS) load(s + 1, (s + 1) & 1);
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) acc[i][j] = WSL_MFMA16(av[s & 1][i], bv[s & 1][j], acc[i][j]);
+    WSL_SCHED_BARRIER();
+  }
+}
 
 template <int KS, int TH, int TW, int CO_T, int KC>
 __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void conv_mfma2_kernel(Conv2P p) {
@@ -114,18 +141,26 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
   float4 prw[C::NWL];
   const bool co_vec = (p.Co & 3) == 0;
 
+  // Addresses = workgroup-uniform channel base (scalar registers) + ONE per-thread 32-bit element offset: a 64-bit
+  // address pair per in-flight load made the allocator spill, and a spill reload's vmcnt(0) drains the prefetch.
+  const uint32_t toff = (uint32_t)(grp * (int)HW + (int)goff);   // valid threads only; < 2^31 elements per sample
   auto issue = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
-      const int c = grp + i * C::G, cg = c0 + c;
+      const int cb = c0 + i * C::G;            // uniform: first channel of this load instruction
+      const int cg = cb + grp;
       pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       prm[i] = make_uchar4(1, 1, 1, 1);
-      if (pvalid && c < KC && cg < Ci) {
-        const bool ina = cg < p.a.C;
+      if (cb < Ci) {                           // uniform branch
+        const bool ina = cb < p.a.C;           // uniform (eligibility: a.C % G == 0 when two sources are present)
         const Src2& s = ina ? p.a : p.b;
-        const int ch = ina ? cg : cg - p.a.C;
-        pre[i] = *reinterpret_cast<const float4*>(s.x + n * s.bs + ch * HW + goff);
-        if (s.emask) prm[i] = *reinterpret_cast<const uchar4*>(s.emask + ((int64_t)n * s.C + ch) * HW + goff);
+        const int chb = ina ? cb : cb - p.a.C;
+        const float* xb = s.x + n * s.bs + (int64_t)chb * HW;
+        const uint8_t* mb = s.emask ? s.emask + ((int64_t)n * s.C + chb) * HW : nullptr;
+        if (pvalid && i * C::G + grp < KC && cg < Ci) {
+          pre[i] = *reinterpret_cast<const float4*>(xb + toff);
+          if (mb) prm[i] = *reinterpret_cast<const uchar4*>(mb + toff);
+        }
       }
     }
 #pragma unroll
@@ -191,36 +226,25 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
   issue(0);
   __syncthreads();  // BN tables visible
   for (int c0 = 0; c0 < Ci; c0 += KC) {
-    commit(c0);
+    if (!(p.ablate & 2) || c0 == 0) commit(c0);
     __syncthreads();
-    if (c0 + KC < Ci) issue(c0 + KC);  // prefetch: in flight during the MFMA loop below
-    const int ngroups = (Ci - c0 >= KC) ? KC / 4 : (Ci - c0 + 3) / 4;
-#pragma unroll 1
-    for (int ky = 0; ky < KS; ++ky) {   // rolled: keeps the scheduler from hoisting a whole chunk's LDS reads
-      const float* in_r = in_t + ky * C::ROWP;
-      const float* w_r = w_t + ky * KS * KC * C::CSTR;
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-#pragma unroll
-        for (int cg = 0; cg < KC / 4; ++cg) {
-          if (cg < ngroups) {
-            float bv[C::NT];
-#pragma unroll
-            for (int j = 0; j < C::NT; ++j) bv[j] = w_r[(kx * KC + cg * 4) * C::CSTR + j * 16 + bbase];
-#pragma unroll
-            for (int i = 0; i < C::MT; ++i) {
-              const float av = in_r[cg * 4 * C::PLANE + kx + abase[i]];
-#pragma unroll
-              for (int j = 0; j < C::NT; ++j) acc[i][j] = WSL_MFMA16(av, bv[j], acc[i][j]);
-            }
-          }
-        }
-      }
+    if (c0 + KC < Ci && !(p.ablate & 2)) issue(c0 + KC);  // prefetch: in flight during the MFMA loop below
+    // MFMA loop.  Stages = (tap, channel group); the A/B operands of stage s+1 are read from LDS before the MFMAs of
+    // stage s are issued (explicit one-stage software pipeline: profiles/r1b showed ds_read -> waitcnt -> mfma chains).
+    // Channels past Ci were staged as zeros, so a short last chunk needs no branch here; a chunk holding <= 4 channels
+    // (Ci = 1 or 4 layers) runs the single-group variant.
+    if (!(p.ablate & 1)) {
+      if (Ci - c0 > 4) conv2_mfma_stages<C, KS, KC, KC / 4>(in_t, w_t, abase, bbase, acc);
+      else conv2_mfma_stages<C, KS, KC, 1>(in_t, w_t, abase, bbase, acc);
     }
     __syncthreads();
   }
 
   // ---- epilogue (identical to v1): bias, float4 stores, BatchNorm partial statistics
+  if (p.ablate & 4) {
+    if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;   // keep the accumulators live
+    return;
+  }
   float bsum[C::NT];
 #pragma unroll
   for (int j = 0; j < C::NT; ++j) {
@@ -349,6 +373,7 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 
 bool conv2_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_bs, int W, int Ci) {
   if ((W & 3) || Ci > 512) return false;
+  if (b && b->C > 0 && (a.C & 3)) return false;   // a channel group of one load never straddles the two sources
   if (!aligned16(a.x) || (a.bs & 3) || (a.emask && (reinterpret_cast<uintptr_t>(a.emask) & 3))) return false;
   if (b && b->C > 0 && (!aligned16(b->x) || (b->bs & 3) || (b->emask && (reinterpret_cast<uintptr_t>(b->emask) & 3))))
     return false;
@@ -373,6 +398,8 @@ int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = cdiv(W, tw), p.tiles_y = cdiv(H, th);
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
+  static const int ablate = getenv("WSL_CONV_ABLATE") ? atoi(getenv("WSL_CONV_ABLATE")) : 0;
+  p.ablate = ablate;
 #define WSL_CASE(KS_, TH_, TW_, CO_) \
   if (ks == KS_ && th == TH_ && tw == TW_ && co_t == CO_) return launch_conv2<KS_, TH_, TW_, CO_>(p, is_dgrad, stream);
   WSL_CASE(3, 8, 64, 16) WSL_CASE(3, 8, 64, 32) WSL_CASE(3, 8, 32, 16) WSL_CASE(3, 8, 32, 32) WSL_CASE(3, 8, 32, 64)
@@ -471,31 +498,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2_kernel(Wgrad2P p) {
     {
       const int gy = y0 + dty, gx = x0 + dtx;
       const bool ok = gd < C::GD && gy < H && gx < W;
+      const uint32_t toff = (uint32_t)(gd * (int)HW + gy * W + gx);
 #pragma unroll
       for (int i = 0; i < C::ND; ++i) {
-        const int c = gd + i * C::GD, co = co0 + c;
+        const int cbu = co0 + i * C::GD;        // uniform channel base of this load instruction
         prd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && c < CB && co < p.Co)
-          prd[i] = *reinterpret_cast<const float4*>(p.dy + n * p.dy_bs + co * HW + (int64_t)gy * W + gx);
+        if (cbu < p.Co) {
+          const float* db = p.dy + n * p.dy_bs + (int64_t)cbu * HW;
+          if (ok && i * C::GD + gd < CB && cbu + gd < p.Co) prd[i] = *reinterpret_cast<const float4*>(db + toff);
+        }
       }
     }
     {
       const int gy = y0 + aty - C::P, gx = x0 + atx4 * 4 - C::PADL;
       pr_aok = ga < C::GA && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const int64_t goff = (int64_t)gy * W + gx;
+      const uint32_t toff = (uint32_t)(ga * (int)HW + gy * W + gx);
 #pragma unroll
       for (int i = 0; i < C::NA; ++i) {
-        const int c = ga + i * C::GA, cg = ci0 + c;
+        const int cbu = ci0 + i * C::GA, cg = cbu + ga;
         pra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         prm[i] = make_uchar4(1, 1, 1, 1);
         prc[i] = 1.f;
-        if (pr_aok && c < IB && cg < Ci) {
-          const bool ina = cg < p.a.C;
+        if (cbu < Ci) {
+          const bool ina = cbu < p.a.C;
           const Src2& s = ina ? p.a : p.b;
-          const int ch = ina ? cg : cg - p.a.C;
-          pra[i] = *reinterpret_cast<const float4*>(s.x + n * s.bs + ch * HW + goff);
-          if (s.emask) prm[i] = *reinterpret_cast<const uchar4*>(s.emask + ((int64_t)n * s.C + ch) * HW + goff);
-          if (s.cmask) prc[i] = s.cmask[(int64_t)n * s.C + ch];
+          const int chb = ina ? cbu : cbu - p.a.C;
+          const float* xb = s.x + n * s.bs + (int64_t)chb * HW;
+          const uint8_t* mb = s.emask ? s.emask + ((int64_t)n * s.C + chb) * HW : nullptr;
+          if (pr_aok && i * C::GA + ga < IB && cg < Ci) {
+            pra[i] = *reinterpret_cast<const float4*>(xb + toff);
+            if (mb) prm[i] = *reinterpret_cast<const uchar4*>(mb + toff);
+            if (s.cmask) prc[i] = s.cmask[(int64_t)n * s.C + chb + ga];
+          }
         }
       }
     }
@@ -542,25 +576,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2_kernel(Wgrad2P p) {
     commit();
     __syncthreads();
     if (item + 1 < it1) issue(item + 1);   // prefetch the next tile; in flight during the MFMA loop
-    constexpr int RW = TH / WK;
-#pragma unroll 1
-    for (int r = wk * RW; r < wk * RW + RW; ++r) {
-#pragma unroll 1
-      for (int x4 = 0; x4 < TW / 4; ++x4) {
-        const int pix = r * TW + x4 * 4 + (lane >> 4);
-        const int apix = r * C::ROWP + x4 * 4 + (lane >> 4) + (C::PADL - C::P);
+    constexpr int RW = TH / WK, NX = TW / 4, NSTEP = RW * NX;
+    static_assert(C::PP == 1, "one channel pair per wave");
+    const int cot = wp_ / C::IBT, cit = wp_ % C::IBT;
+    const float* dyp = dy_t + (cot * 16 + (lane & 15)) * C::PLD + (lane >> 4);
+    const float* ap = a_t + (cit * 16 + (lane & 15)) * C::PLA + (lane >> 4) + (C::PADL - C::P);
+    float avv[2], bvv[2][C::KK];
+    auto load = [&](int st, int buf) {   // step st = (row, group of 4 pixels)
+      const int r = wk * RW + st / NX, x4 = st % NX;
+      avv[buf] = dyp[r * TW + x4 * 4];
 #pragma unroll
-        for (int j = 0; j < C::PP; ++j) {
-          const int pr = wp_ * C::PP + j, cot = pr / C::IBT, cit = pr % C::IBT;
-          const float av = dy_t[(cot * 16 + (lane & 15)) * C::PLD + pix];
-          if (want_db && cit == 0) accb[j] = WSL_MFMA16(av, 1.0f, accb[j]);
+      for (int t = 0; t < C::KK; ++t) bvv[buf][t] = ap[(r + t / KS) * C::ROWP + x4 * 4 + (t % KS)];
+    };
+    load(0, 0);
+    const bool dbw = want_db && cit == 0;
+#pragma unroll 2
+    for (int st = 0; st < NSTEP; ++st) {   // operands of step st+1 are read before the MFMAs of step st issue
+      const int cur = st & 1;
+      if (st + 1 < NSTEP) load(st + 1, cur ^ 1);
+      if (dbw) accb[0] = WSL_MFMA16(avv[cur], 1.0f, accb[0]);
 #pragma unroll
-          for (int t = 0; t < C::KK; ++t) {
-            const float bv = a_t[(cit * 16 + (lane & 15)) * C::PLA + apix + (t / KS) * C::ROWP + (t % KS)];
-            acc[j][t] = WSL_MFMA16(av, bv, acc[j][t]);
-          }
-        }
-      }
+      for (int t = 0; t < C::KK; ++t) acc[0][t] = WSL_MFMA16(avv[cur], bvv[cur][t], acc[0][t]);
+      WSL_SCHED_BARRIER();
     }
     __syncthreads();
   }
