@@ -82,6 +82,9 @@ int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int ks);
  * aligned float4 loads and prefetches the next channel chunk during the MFMA loop. */
 int wsl_conv2d_pack_weights(const float* w, float* packed, int Co, int Ci, int ks, int wmode_raw, void* stream);
 int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int W);
+/* Debug / experiments: which packed-path kernel wsl_conv2d_fwd(wmode 2|3) launches: 2 = lock-step workgroups with a
+ * register prefetch (default, fastest measured), 3 = wave-specialised persistent workgroups (wsl_conv3.hip). */
+int wsl_debug_conv_variant(int v);
 
 /* dw[Co][Ci][ks][ks] = sum_{n,y,x} dy[n,co,y,x] * in[n,ci,y+ky-p,x+kx-p];  db[Co] = sum dy  (db may be NULL).
  * Split over pixels into partials in `ws`, then an order-fixed second stage. */

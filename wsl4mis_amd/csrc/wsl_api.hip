@@ -27,6 +27,21 @@ int check_launch(const char* what) {
   return WSL_OK;
 }
 
+int device_cu_count() {
+#ifdef WSL_HOST_EMUL
+  return 1;   // few workgroups: the emulator tests then exercise the multi-tile (persistent) path
+#else
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+#endif
+}
+
 }  // namespace wsl
 
 // ---------------------------------------------------------------------------------------------- opt-in profiling

@@ -29,8 +29,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, con
   const int c = blockIdx.x;
   double n = 0, s = 0;
   for (int b = threadIdx.x; b < nblk; b += kThreads) {
-    n += cnt[b];
-    s += part[((int64_t)b * C + c) * 2];
+    if (cnt[b] > 0.f) {   // empty slots (count 0) carry no data
+      n += cnt[b];
+      s += part[((int64_t)b * C + c) * 2];
+    }
   }
   n = block_sum_d(n, red);
   s = block_sum_d(s, red);

@@ -201,12 +201,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
       for (int j = 0; j < C::NT; ++j) {
         const int col = j * 16 + lane, co = co0 + col;
         if (co < p.Co) {
-          float* dst = p.stat_part + ((int64_t)blockIdx.x * p.Co + co) * 2;
+          float* dst = p.stat_part + ((int64_t)blockIdx.x * 4 * p.Co + co) * 2;   // slot 0 of this tile's 4
           dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
           dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
         }
       }
-      if (lane == 0 && blockIdx.y == 0) p.stat_cnt[blockIdx.x] = cnt;
+      if (lane < 4 && blockIdx.y == 0) p.stat_cnt[blockIdx.x * 4 + lane] = lane == 0 ? cnt : 0.f;
     }
     (void)m2;
   }
@@ -504,6 +504,12 @@ int conv2_pack(const float* w, float* wp, int Co, int Ci, int ks, int wmode, voi
 int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
               int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
               void* stream);
+// wsl_conv3.hip
+bool conv3_enabled();
+void conv_set_variant(int v);
+int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
+              int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
+              void* stream);
 bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, int W);
 int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                   int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
@@ -511,6 +517,12 @@ int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_
 }  // namespace wsl
 
 using namespace wsl;
+
+extern "C" int wsl_debug_conv_variant(int v) {
+  WSL_REQUIRE(v == 2 || v == 3, "debug_conv_variant: 2 (lock-step, default) or 3 (wave-specialised, experimental)");
+  conv_set_variant(v);
+  return WSL_OK;
+}
 
 extern "C" int wsl_conv2d_pack_weights(const float* w, float* packed, int Co, int Ci, int ks, int wmode_raw, void* stream) {
   WSL_REQUIRE(w && packed && Co > 0 && Ci > 0 && (ks == 1 || ks == 3) && (wmode_raw == 0 || wmode_raw == 1),
@@ -529,7 +541,7 @@ extern "C" int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int k
   (void)ks;
   if (N <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
   const FwdPlan f = fwd_plan(W, Co);
-  return N * cdiv(H, f.th) * cdiv(W, f.tw);
+  return 4 * N * cdiv(H, f.th) * cdiv(W, f.tw);   // four slots per tile: the wave-specialised kernel emits per-wave partials
 }
 
 extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y,
@@ -559,6 +571,9 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
       set_error("conv2d_fwd: packed weights (wmode %d) need W %% 4 == 0 and 16-byte aligned tensors", wmode);
       return WSL_EINVAL;
     }
+    if (conv3_enabled() && p.in.Ci <= 256)   // wave-specialised persistent kernel (wsl_conv3.hip)
+      return conv3_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
+                       stat_cnt, stream);
     return conv2_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
                      stat_cnt, stream);
   }

@@ -306,12 +306,12 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
       for (int j = 0; j < C::NT; ++j) {
         const int col = j * 16 + lane, co = co0 + col;
         if (co < p.Co) {
-          float* dst = p.stat_part + ((int64_t)tile_id * p.Co + co) * 2;
+          float* dst = p.stat_part + ((int64_t)tile_id * 4 * p.Co + co) * 2;   // slot 0 of this tile's 4
           dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
           dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
         }
       }
-      if (lane == 0 && blockIdx.y == 0) p.stat_cnt[tile_id] = cnt;
+      if (lane < 4 && blockIdx.y == 0) p.stat_cnt[tile_id * 4 + lane] = lane == 0 ? cnt : 0.f;
     }
   }
 }

@@ -37,6 +37,7 @@ void set_error(const char* fmt, ...);
 void* prof_begin(int fam, double flops, double bytes, void* stream);
 void prof_end(void* tok, void* stream);
 int check_launch(const char* what);
+int device_cu_count();   // compute units of the current device (cached)
 
 #define WSL_REQUIRE(cond, ...)     \
   do {                             \
