@@ -38,7 +38,7 @@ struct ConvP {
   const float* bias;
   float* y;
   int64_t y_bs;
-  int N, Co, wmode, tiles_x, tiles_y, vec_ok;
+  int N, Co, wmode, tiles_x, tiles_y, vec_ok, slots;
   float* stat_part;
   float* stat_cnt;
 };
@@ -201,12 +201,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
       for (int j = 0; j < C::NT; ++j) {
         const int col = j * 16 + lane, co = co0 + col;
         if (co < p.Co) {
-          float* dst = p.stat_part + ((int64_t)blockIdx.x * 4 * p.Co + co) * 2;   // slot 0 of this tile's 4
+          float* dst = p.stat_part + ((int64_t)blockIdx.x * p.slots * p.Co + co) * 2;   // slot 0 of this tile's slots
           dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
           dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
         }
       }
-      if (lane < 4 && blockIdx.y == 0) p.stat_cnt[blockIdx.x * 4 + lane] = lane == 0 ? cnt : 0.f;
+      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[blockIdx.x * p.slots + lane] = lane == 0 ? cnt : 0.f;
     }
     (void)m2;
   }
@@ -503,7 +503,7 @@ bool conv2_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_
 int conv2_pack(const float* w, float* wp, int Co, int Ci, int ks, int wmode, void* stream);
 int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
               int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
-              void* stream);
+              int slots, void* stream);
 // wsl_conv3.hip
 bool conv3_enabled();
 void conv_set_variant(int v);
@@ -541,7 +541,8 @@ extern "C" int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int k
   (void)ks;
   if (N <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
   const FwdPlan f = fwd_plan(W, Co);
-  return 4 * N * cdiv(H, f.th) * cdiv(W, f.tw);   // four slots per tile: the wave-specialised kernel emits per-wave partials
+  // one partial per tile; the (opt-in) wave-specialised kernel emits one per MFMA wave = four slots per tile
+  return (conv3_enabled() ? 4 : 1) * N * cdiv(H, f.th) * cdiv(W, f.tw);
 }
 
 extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y,
@@ -565,6 +566,7 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
   WSL_REQUIRE(y_bs >= (int64_t)Co * H * W, "conv2d_fwd: y batch stride too small");
   p.w = w, p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.Co = Co, p.wmode = wmode;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
+  p.slots = conv3_enabled() ? 4 : 1;
   const FwdPlan f = fwd_plan(W, Co);
   if (wmode >= 2) {
     if (!conv2_eligible(p.in.a, &p.in.b, y, y_bs, W, p.in.Ci)) {
@@ -575,7 +577,7 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
       return conv3_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
                        stat_cnt, stream);
     return conv2_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
-                     stat_cnt, stream);
+                     stat_cnt, p.slots, stream);
   }
   p.tiles_x = cdiv(W, f.tw), p.tiles_y = cdiv(H, f.th);
   p.vec_ok = (W % 4 == 0) && (y_bs % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);

@@ -36,6 +36,7 @@ struct Conv2P {
   int N, H, W, Ci, Co, tiles_x, tiles_y;
   float* stat_part;
   float* stat_cnt;
+  int slots;    // BatchNorm partial slots per tile (1; 4 when the wave-specialised variant is active)
   int ablate;   // debug (env WSL_CONV_ABLATE): 1 skip MFMA, 2 skip staging after the first chunk, 4 skip epilogue
 };
 
@@ -306,12 +307,12 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
       for (int j = 0; j < C::NT; ++j) {
         const int col = j * 16 + lane, co = co0 + col;
         if (co < p.Co) {
-          float* dst = p.stat_part + ((int64_t)tile_id * 4 * p.Co + co) * 2;   // slot 0 of this tile's 4
+          float* dst = p.stat_part + ((int64_t)tile_id * p.slots * p.Co + co) * 2;   // slot 0 of this tile's slots
           dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
           dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
         }
       }
-      if (lane < 4 && blockIdx.y == 0) p.stat_cnt[tile_id * 4 + lane] = lane == 0 ? cnt : 0.f;
+      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
     }
   }
 }
@@ -390,8 +391,9 @@ int conv2_pack(const float* w, float* wp, int Co, int Ci, int ks, int wmode, voi
 
 int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
               int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
-              void* stream) {
+              int slots, void* stream) {
   Conv2P p;
+  p.slots = slots;
   p.a = to_src2(a);
   p.b = (b && b->C > 0) ? to_src2(*b) : Src2{};
   p.wp = wp, p.bias = bias, p.y = y, p.y_bs = y_bs;

@@ -222,11 +222,13 @@ struct HeadP {
   float bf, omb;
 };
 
+// CT > 0: class count fixed at compile time (loops unroll, per-class arrays live in registers); CT == 0: generic
+template <int CT>
 __global__ __launch_bounds__(256) void head_reduce_kernel(HeadP h, int64_t* pseudo, float* part) {
   __shared__ float red[4];
   float v[3 + 5 * kMaxC];
   for (int k = 0; k < 3 + 5 * kMaxC; ++k) v[k] = 0.f;
-  const int C = h.C;
+  const int C = CT > 0 ? CT : h.C;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < h.P; i += (int64_t)gridDim.x * kThreads) {
     const int64_t n = i / h.HW, p = i - n * h.HW, base = n * C * h.HW + p;
     const int l = h.label[i];
@@ -303,8 +305,9 @@ __device__ __forceinline__ void head_branch_bwd(const float* s, int C, int t, in
   }
 }
 
+template <int CT>
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadP h, const float* scal, float gscale, float* dz1, float* dz2) {
-  const int C = h.C;
+  const int C = CT > 0 ? CT : h.C;
   const bool dual = h.z2 != nullptr;
   const float kce = scal[0] * (dual ? 0.5f : 1.f);
   float ca1[kMaxC], cb1[kMaxC], ca2[kMaxC], cb2[kMaxC];
@@ -338,39 +341,52 @@ struct CrfP {
   int tiles_x, tiles_y;
 };
 
+// 32 x 8 pixels per workgroup: a wave covers two full 32-pixel rows, so its ds_read_b32 of a tap (two groups of 32
+// consecutive floats) is bank-conflict free for any row pitch (the 16 x 16 layout measured a 0.48 conflict ratio).
+constexpr int kCrfTW = 32, kCrfTH = 8;
+// CT > 0: class count known at compile time (per-class accumulators stay in registers, loops unroll); CT == 0: generic
+template <int CT>
 __global__ __launch_bounds__(256) void gatedcrf_fwd_kernel(CrfP q, float* part) {
   WSL_DYN_SMEM(smem);
   __shared__ float red[4];
-  const int r = q.r, TS = 16 + 2 * r, C = q.C;
-  float* yt = reinterpret_cast<float*>(smem);   // [C][TS*TS]
-  float* it = yt + C * TS * TS;                 // [TS*TS] image / sigma_rgb, 0 outside
-  float* fxt = it + TS * TS;                    // [TS] column feature x / sigma_xy (0 outside the image)
-  float* fyt = fxt + TS;                        // [TS] row feature
+  const int r = q.r, TSX = kCrfTW + 2 * r, TSY = kCrfTH + 2 * r, TSS = TSX * TSY;
+  const int C = CT > 0 ? CT : q.C;
+  constexpr int MC = CT > 0 ? CT : kMaxC;
+  float* yt = reinterpret_cast<float*>(smem);   // [C][TSY*TSX]
+  float* it = yt + C * TSS;                     // [TSY*TSX] image / sigma_rgb, 0 outside
+  float* fxt = it + TSS;                        // [TSX] column feature x / sigma_xy (0 outside the image)
+  float* fyt = fxt + TSX;                       // [TSY] row feature
   int bid = blockIdx.x;
   const int tx_i = bid % q.tiles_x;
   bid /= q.tiles_x;
   const int ty_i = bid % q.tiles_y, n = bid / q.tiles_y;
-  const int y0 = ty_i * 16, x0 = tx_i * 16;
+  const int y0 = ty_i * kCrfTH, x0 = tx_i * kCrfTW;
   const int64_t HW = (int64_t)q.H * q.W;
-  for (int e = threadIdx.x; e < TS * TS; e += kThreads) {
-    const int ty = e / TS, tx = e - ty * TS, gy = y0 + ty - r, gx = x0 + tx - r;
+  for (int e = threadIdx.x; e < TSS; e += kThreads) {
+    const int ty = e / TSX, tx = e - ty * TSX, gy = y0 + ty - r, gx = x0 + tx - r;
     const bool in = gy >= 0 && gy < q.H && gx >= 0 && gx < q.W;
     it[e] = in ? q.img[n * HW + (int64_t)gy * q.W + gx] / q.srgb : 0.f;
-    for (int c = 0; c < C; ++c) yt[c * TS * TS + e] = in ? q.y[((int64_t)n * C + c) * HW + (int64_t)gy * q.W + gx] : 0.f;
+    for (int c = 0; c < C; ++c) yt[c * TSS + e] = in ? q.y[((int64_t)n * C + c) * HW + (int64_t)gy * q.W + gx] : 0.f;
   }
-  if ((int)threadIdx.x < TS) {
-    const int gx = x0 + (int)threadIdx.x - r, gy = y0 + (int)threadIdx.x - r;
+  if ((int)threadIdx.x < TSX) {
+    const int gx = x0 + (int)threadIdx.x - r;
     fxt[threadIdx.x] = (gx >= 0 && gx < q.W) ? (float)gx / q.sxy : 0.f;
+  }
+  if ((int)threadIdx.x < TSY) {
+    const int gy = y0 + (int)threadIdx.x - r;
     fyt[threadIdx.x] = (gy >= 0 && gy < q.H) ? (float)gy / q.sxy : 0.f;
   }
   __syncthreads();
-  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15, gy = y0 + ly, gx = x0 + lx;
+  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31, gy = y0 + ly, gx = x0 + lx;
+  // every tap of every pixel of this tile inside the image?  (uniform; true for ~70 % of the tiles of a 256^2 slice)
+  const bool interior = y0 - r >= 0 && y0 + kCrfTH + r <= q.H && x0 - r >= 0 && x0 + kCrfTW + r <= q.W;
   float v[2] = {0.f, 0.f};
   if (gy < q.H && gx < q.W) {
-    const int ce = (ly + r) * TS + lx + r;
+    const int ce = (ly + r) * TSX + lx + r;
     const float fpx = fxt[lx + r], fpy = fyt[ly + r], fpi = it[ce];
-    float m[kMaxC];
-    for (int c = 0; c < C; ++c) m[c] = 0.f;
+    float m[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) m[c] = 0.f;
     float ks = 0.f;
     for (int dy = -r; dy <= r; ++dy) {
       const int qy = gy + dy;
@@ -378,22 +394,30 @@ __global__ __launch_bounds__(256) void gatedcrf_fwd_kernel(CrfP q, float* part) 
       const float rowf = fyt[ly + r + dy];
       for (int dx = -r; dx <= r; ++dx) {
         if (dy == 0 && dx == 0) continue;
-        const int qx = gx + dx;
-        const bool in = iny && qx >= 0 && qx < q.W;
-        const int te = ce + dy * TS + dx;
-        // a tap outside the image sees the all-zero feature vector of the zero-padded unfold (gate_crf_loss.py:184-188)
-        const float fqx = in ? fxt[lx + r + dx] : 0.f, fqy = in ? rowf : 0.f, fqi = it[te];
-        const float ddx = fqx - fpx, ddy = fqy - fpy, ddi = fqi - fpi;
+        const int te = ce + dy * TSX + dx;
+        float fqx = fxt[lx + r + dx], fqy = rowf;
+        if (!interior) {
+          // a tap outside the image sees the all-zero feature vector of the zero-padded unfold (gate_crf_loss.py:184-188)
+          const int qx = gx + dx;
+          const bool in = iny && qx >= 0 && qx < q.W;
+          fqx = in ? fqx : 0.f, fqy = in ? fqy : 0.f;
+        }
+        const float ddx = fqx - fpx, ddy = fqy - fpy, ddi = it[te] - fpi;
         const float e = (-0.5f * (ddx * ddx)) + (-0.5f * (ddy * ddy)) + (-0.5f * (ddi * ddi));
         const float k = q.weight * expf(e);
         ks += k;
-        for (int c = 0; c < C; ++c) m[c] = fmaf(k, yt[c * TS * TS + te], m[c]);
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+          if (c < C) m[c] = fmaf(k, yt[c * TSS + te], m[c]);
       }
     }
     float ym = 0.f;
-    for (int c = 0; c < C; ++c) {
-      q.msg[((int64_t)n * C + c) * HW + (int64_t)gy * q.W + gx] = m[c];
-      ym = fmaf(m[c], yt[c * TS * TS + ce], ym);
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      if (c < C) {
+        q.msg[((int64_t)n * C + c) * HW + (int64_t)gy * q.W + gx] = m[c];
+        ym = fmaf(m[c], yt[c * TSS + ce], ym);
+      }
     }
     v[0] = ks, v[1] = ym;
   }
@@ -602,8 +626,10 @@ __global__ __launch_bounds__(256) void softmax_mse_kernel(const float* a, const 
 // ------------------------------------------------------------------------------------------------ mixed probabilities
 // y = beta*softmax(z1) + (1-beta)*softmax(z2): the prediction the dual-branch + GatedCRF composition regularises
 // (ref: train_ACDC_scribblevc.py:171-206).  z2 == NULL: y = softmax(z1).
+template <int CT>
 __global__ __launch_bounds__(256) void mixprob_fwd_kernel(const float* z1, const float* z2, float bf, float omb, float* y,
-                                                          int C, int HW, int64_t P) {
+                                                          int C_, int HW, int64_t P) {
+  const int C = CT > 0 ? CT : C_;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
     const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
     float s1[kMaxC], s2[kMaxC];
@@ -618,9 +644,11 @@ __global__ __launch_bounds__(256) void mixprob_fwd_kernel(const float* z1, const
 }
 
 // dz_k (+)= softmax_bwd(s_k, w_k * k * dy)   with w_1 = beta, w_2 = 1-beta
+template <int CT>
 __global__ __launch_bounds__(256) void mixprob_bwd_kernel(const float* z1, const float* z2, float bf, float omb,
                                                           const float* dy, float k, float* dz1, float* dz2, int accumulate,
-                                                          int C, int HW, int64_t P) {
+                                                          int C_, int HW, int64_t P) {
+  const int C = CT > 0 ? CT : C_;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
     const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
     float g[kMaxC], s[kMaxC];
@@ -732,9 +760,11 @@ extern "C" int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t*
   const int nb = grid_for(h.P);
   float* part = static_cast<float*>(ws);
   float* scal = part + (size_t)kMaxBlocks * kMaxK;
-  WSL_LAUNCH(head_reduce_kernel, dim3(nb), dim3(kThreads), 0, stream, h, pseudo, part);
+  if (C == 4) WSL_LAUNCH((head_reduce_kernel<4>), dim3(nb), dim3(kThreads), 0, stream, h, pseudo, part);
+  else WSL_LAUNCH((head_reduce_kernel<0>), dim3(nb), dim3(kThreads), 0, stream, h, pseudo, part);
   WSL_LAUNCH(head_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, C, N, z2 ? 1 : 0, w_pse, out, scal);
-  if (dz1) WSL_LAUNCH(head_bwd_kernel, dim3(nb), dim3(kThreads), 0, stream, h, scal, gscale, dz1, dz2);
+  if (dz1 && C == 4) WSL_LAUNCH((head_bwd_kernel<4>), dim3(nb), dim3(kThreads), 0, stream, h, scal, gscale, dz1, dz2);
+  else if (dz1) WSL_LAUNCH((head_bwd_kernel<0>), dim3(nb), dim3(kThreads), 0, stream, h, scal, gscale, dz1, dz2);
   return check_launch("head_fwd_bwd");
 }
 
@@ -748,13 +778,15 @@ extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, fl
   }
   const int HW_ = H * W;
   WSL_WS_OK("gatedcrf_fwd");
-  CrfP q{y, img, msg, N, C, H, W, radius, sigma_xy, sigma_rgb, weight, cdiv(W, 16), cdiv(H, 16)};
+  CrfP q{y, img, msg, N, C, H, W, radius, sigma_xy, sigma_rgb, weight, cdiv(W, kCrfTW), cdiv(H, kCrfTH)};
   const int nb = N * q.tiles_x * q.tiles_y;
-  const int TS = 16 + 2 * radius;
-  const size_t smem = sizeof(float) * ((size_t)(C + 1) * TS * TS + 2 * TS);
+  const int TSX = kCrfTW + 2 * radius, TSY = kCrfTH + 2 * radius;
+  const size_t smem = sizeof(float) * ((size_t)(C + 1) * TSX * TSY + TSX + TSY);
   float* part = static_cast<float*>(ws);
   void* tok = prof_begin(4, 0.0, 4.0 * (double)N * H * W * (2 * C + 1), stream);
-  WSL_LAUNCH(gatedcrf_fwd_kernel, dim3(nb), dim3(kThreads), smem, stream, q, part);
+  if (C == 4) WSL_LAUNCH((gatedcrf_fwd_kernel<4>), dim3(nb), dim3(kThreads), smem, stream, q, part);
+  else if (C == 2) WSL_LAUNCH((gatedcrf_fwd_kernel<2>), dim3(nb), dim3(kThreads), smem, stream, q, part);
+  else WSL_LAUNCH((gatedcrf_fwd_kernel<0>), dim3(nb), dim3(kThreads), smem, stream, q, part);
   prof_end(tok, stream);
   WSL_LAUNCH(gatedcrf_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, (double)N * H * W, loss);
   return check_launch("gatedcrf_fwd");
@@ -818,8 +850,8 @@ extern "C" int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* lo
 extern "C" int wsl_mixprob_fwd(const float* z1, const float* z2, double beta, float* y, int N, int C, int HW, void* stream) {
   WSL_REQUIRE(z1 && y && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "mixprob_fwd: bad args");
   const int64_t P = (int64_t)N * HW;
-  WSL_LAUNCH(mixprob_fwd_kernel, dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), y,
-             C, HW, P);
+  if (C == 4) WSL_LAUNCH((mixprob_fwd_kernel<4>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), y, C, HW, P);
+  else WSL_LAUNCH((mixprob_fwd_kernel<0>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), y, C, HW, P);
   return check_launch("mixprob_fwd_kernel");
 }
 
@@ -827,7 +859,7 @@ extern "C" int wsl_mixprob_bwd(const float* z1, const float* z2, double beta, co
                                float* dz2, int accumulate, int N, int C, int HW, void* stream) {
   WSL_REQUIRE(z1 && dy && dz1 && (!z2 || dz2) && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "mixprob_bwd: bad args");
   const int64_t P = (int64_t)N * HW;
-  WSL_LAUNCH(mixprob_bwd_kernel, dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta),
-             dy, k, dz1, dz2, accumulate, C, HW, P);
+  if (C == 4) WSL_LAUNCH((mixprob_bwd_kernel<4>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), dy, k, dz1, dz2, accumulate, C, HW, P);
+  else WSL_LAUNCH((mixprob_bwd_kernel<0>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), dy, k, dz1, dz2, accumulate, C, HW, P);
   return check_launch("mixprob_bwd_kernel");
 }
