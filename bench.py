@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce"])
+    ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce", "mean_teacher"])
     ap.add_argument("--crf-radius", type=int, default=5, help="reference default 5 (11x11); 2 = the 5x5 of BASELINE.json")
     ap.add_argument("--net", default="unet_cct", choices=["unet_cct", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,8 +72,8 @@ def cpu_baseline(args):
     em = [(torch.rand((B, 16 << l, S >> l, S >> l), generator=g) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
     cm = [(torch.rand((B, 16 << l), generator=g) >= 0.5).float() * 2 for l in range(5)]
     crf = args.crf_radius if args.loss == "pce_gatedcrf" else None
-    if args.loss == "pce":
-        raise SystemExit("cpu baseline for --loss pce: use ours_proposed or pce_gatedcrf")
+    if args.loss in ("pce", "mean_teacher"):
+        raise SystemExit("cpu baseline is built for ours_proposed and pce_gatedcrf")
     tr.step(x, lab, 0.4, em, cm, crf)                      # warm-up (thread pool, oneDNN primitives)
     iters, t0 = 0, time.perf_counter()
     while iters < max(2, args.cpu_iters) or (time.perf_counter() - t0 < 15.0 and iters < 12):   # ~15-30 s of CPU work
@@ -104,6 +104,8 @@ def cpu_baseline_subprocess(args):
 
 def main():
     args = parse()
+    if args.loss == "mean_teacher":
+        args.net, args.no_cpu_baseline = "unet", True      # config 4: single-decoder student + EMA teacher
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
         return
@@ -167,14 +169,26 @@ def main():
             name, grp = max(((k, v) for k, v in kern.items() if v), key=lambda kv: sum(r.ms for r in kv[1]))
             ms, fl, calls = sum(r.ms for r in grp), sum(r.flops for r in grp), sum(r.calls for r in grp)
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = None     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
+            try:               # (FETCH_SIZE / WRITE_SIZE, separate runs of this same command -- profiles/r1_pmc_traffic.json)
+                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+                    tj = json.load(fh)["kernels"]
+                key = "conv_mfma2_kernel" if name.startswith("conv_mfma2") else "wgrad_mfma2_kernel"
+                traffic = {"hbm_bytes_per_launch": tj[key]["hbm_bytes_per_launch"],
+                           "algorithmic_bytes_per_launch": sum(r.bytes for r in grp) / calls,
+                           "source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "launches": int(calls), "avg_launch_us": round(1e3 * ms / calls, 2),
                     "flops_per_launch": fl / calls,
                     "all_mfma_kernels_tflops": round(sum(r.flops for r in conv) / (sum(r.ms for r in conv) * 1e-3) / 1e12, 2),
                     "all_mfma_kernels_ms_per_step": round(sum(r.ms for r in conv) / args.steps, 3)}
     if rank == 0:
         gflop = 28.98 if args.net == "unet_cct" else 17.68     # conv-stack training GFLOP/slice
+        if args.loss == "mean_teacher":
+            gflop += 5.899                                     # + the teacher's forward
         value = args.batch * world * args.steps / dt
         out = {"metric": "training slices/sec (256x256, bs64, unet_cct pCE+GatedCRF)", "value": round(value, 2),
                "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

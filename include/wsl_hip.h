@@ -182,6 +182,9 @@ int wsl_mumford_shah_fwd_bwd(const float* img, const float* p, float* loss, floa
 int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* loss, float* da, float gscale, int N, int C, int HW,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* dst += k * src (sums the logit-gradients of several loss terms). */
+int wsl_axpy(float* dst, const float* src, float k, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ optimiser
  * torch.optim.SGD(momentum, weight_decay) over a flat arena (ref: ...pCE_ours_proposed.py:89-90,126-132):
  *   g = grad*grad_scale + wd*p; buf = first ? g : mu*buf + g; p -= lr*buf;

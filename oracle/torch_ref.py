@@ -241,6 +241,27 @@ def ema_update(ema, params, alpha, step):
         e.mul_(a).add_(p, alpha=1 - a)
 
 
+def sigmoid_rampup(current, rampup_length):
+    """utils/ramps.py:19-26."""
+    if rampup_length == 0:
+        return 1.0
+    cur = min(max(float(current), 0.0), float(rampup_length))
+    return float(math.exp(-5.0 * (1.0 - cur / rampup_length) ** 2))
+
+
+def mean_teacher_loss(z_s, z_t, label_u8, it):
+    """Config 4 of BASELINE.json as defined in SURVEY 8d (a composition; no single reference script holds it):
+    pCE(student) (pCE_2D.py:100) + 1e-2 * tv_loss(softmax(student)[1:]) (pCE_TV_2D.py:113-114) +
+    w(it) * mean((softmax(student) - softmax(teacher))**2) (train_mean_teacher_2D.py:147-171,
+    w = 0.1 * sigmoid_rampup(it // 300, 200), :73-75)."""
+    s = torch.softmax(z_s, 1)
+    ce = ce_ignore(z_s, label_u8)
+    tv = tv_loss(s[1:])
+    w = 0.1 * sigmoid_rampup(it // 300, 200.0)
+    cons = torch.mean(softmax_mse(z_s, z_t.detach()))
+    return ce + 1e-2 * tv + w * cons, ce, tv, cons
+
+
 # --------------------------------------------------------------------------- whole step (CPU baseline)
 class RefTrainer:
     """One process' training loop of ours_proposed (or pCE+GatedCRF) in stock torch CPU ops, used as the

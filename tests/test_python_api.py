@@ -67,7 +67,7 @@ def test_module_autograd_matches_reference_script_composition(mode):
     drop-in modules; gradients land in p.grad through ordinary autograd; torch.optim.SGD updates the arena views."""
     from wsl4mis_amd.networks.net_factory import net_factory
     from wsl4mis_amd.utils import losses
-    g = golden("g2_cct32")
+    g = golden("g2_cct16" if mode == "emul" else "g2_cct32")     # the emulator gets the small fixture (CPU time)
     model = net_factory("unet_cct", 1, 4)
     load_det(model, 2022)
     model.train()
@@ -216,17 +216,63 @@ def run_curve(steps):
 
 def test_engine_loss_curve_start(mode):
     """first optimiser steps of the fused engine vs the reference loop (SGD + poly LR incl. its one-step lag)."""
-    steps = 2 if mode == "emul" else 12
+    steps = 1 if mode == "emul" else 12
     got, g, eng = run_curve(steps)
     ref = g["losses"][:steps]
     rel = np.abs(got - ref) / np.abs(ref)
     # the first optimiser steps pin the arithmetic (forward, loss, backward, SGD, poly LR) tightly; further along, the
     # trajectories of two fp32 implementations drift apart through LeakyReLU / max-pool / arg-max flips (bs 4, 32x32 nets
     # are twitchy), so the tail is only required to stay close
-    assert np.max(rel[:2]) < 1e-4, (got, ref)
+    assert np.max(rel[:min(2, steps)]) < 1e-4, (got, ref)
     assert np.max(rel) < 3e-2, (got, ref)
     if steps == 12:
         sd = eng.model.state_dict()
         for k in ("encoder.in_conv.conv_conv.0.weight", "main_decoder.out_conv.weight", "aux_decoder1.up1.conv1x1.bias",
                   "encoder.down4.maxpool_conv.1.conv_conv.5.running_var"):
             assert rel_err(sd[k].cpu().numpy().ravel()[:256], g[f"final.{k}"]) < 5e-2, k
+
+
+def test_mean_teacher_step_against_oracle(mode):
+    """SURVEY 8d config 4 (student unet + EMA teacher; pCE + TV + consistency): one engine step vs the oracle's
+    composition of the pinned pieces -- losses, student parameters after SGD, teacher parameters after the EMA."""
+    from oracle import torch_ref as R
+    from wsl4mis_amd.engine import TrainEngine
+    from wsl4mis_amd.synthetic import scribble_labels
+    N, S, it0 = 3, 16, 30000
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand((N, 1, S, S), generator=gen)
+    lab = torch.from_numpy(scribble_labels(N, S, S, 4, share=0.08))
+    noise = torch.clamp(torch.randn((N, 1, S, S), generator=gen) * 0.1, -0.2, 0.2)
+    masks = [[(torch.rand((N, 16 << l, S >> l, S >> l), generator=gen) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
+             for _ in range(2)]
+    eng = TrainEngine("unet", 1, 4, base_lr=0.01, loss="mean_teacher")
+    load_det(eng.model, 21)
+    load_det(eng.teacher, 22)            # a teacher that differs from the student, so the EMA is visible
+    eng.it = it0
+    eng.model.set_dropout_masks([T(m) for m in masks[0]])
+    eng.teacher.set_dropout_masks([T(m) for m in masks[1]])
+    # ---- oracle
+    sd_s = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in det_state(
+        {k: tuple(v.shape) for k, v in eng.model.state_dict().items()}, 21).items()}
+    sd_t = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in det_state(
+        {k: tuple(v.shape) for k, v in eng.teacher.state_dict().items()}, 22).items()}
+    pk = [k for k in sd_s if R.is_param(k)]
+    for k in pk:
+        sd_s[k].requires_grad_(True)
+    z_s = R.net_forward(sd_s, x, "unet", masks[0], None, True)
+    with torch.no_grad():
+        z_t = R.net_forward(sd_t, x + noise, "unet", masks[1], None, True)
+    loss, ce, tv, cons = R.mean_teacher_loss(z_s, z_t, lab, it0)
+    loss.backward()
+    with torch.no_grad():
+        ps = [sd_s[k] for k in pk]
+        R.sgd_step(ps, [p.grad for p in ps], [torch.zeros_like(p) for p in ps], 0.01, first=False)
+        R.ema_update([sd_t[k] for k in pk], ps, 0.99, it0)
+    # ---- engine
+    eng.step(T(x.numpy()), T(lab.numpy()), noise=T(noise.numpy()))
+    o = eng.losses()
+    assert rel_err([o["loss"], o["ce"], o["tv"], o["cons"]], [loss.item(), ce.item(), tv.item(), cons.item()]) < 1e-4
+    got_s, got_t = eng.model.state_dict(), eng.teacher.state_dict()
+    for k in pk:
+        assert rel_err(got_s[k].detach().cpu(), sd_s[k].detach()) < 1e-4, k
+        assert rel_err(got_t[k].detach().cpu(), sd_t[k].detach()) < 1e-4, k

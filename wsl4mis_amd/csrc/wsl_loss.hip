@@ -435,6 +435,11 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* x, const float*
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) out[i] = s * x[i];
 }
 
+__global__ __launch_bounds__(256) void axpy_kernel(float* dst, const float* src, float k, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+    dst[i] = fmaf(k, src[i], dst[i]);
+}
+
 // ------------------------------------------------------------------------------------------------ tv_loss
 // 16x16 outputs of one (n, c) plane per workgroup.  Regions (halo): p +4, erosion e +3 (with arg-min), dilation +2
 // (contour flag + arg-max), ge +1, dp +0.  Windows ignore out-of-image taps (max_pool2d pads with -inf); extrema take
@@ -862,4 +867,10 @@ extern "C" int wsl_mixprob_bwd(const float* z1, const float* z2, double beta, co
   if (C == 4) WSL_LAUNCH((mixprob_bwd_kernel<4>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), dy, k, dz1, dz2, accumulate, C, HW, P);
   else WSL_LAUNCH((mixprob_bwd_kernel<0>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), dy, k, dz1, dz2, accumulate, C, HW, P);
   return check_launch("mixprob_bwd_kernel");
+}
+
+extern "C" int wsl_axpy(float* dst, const float* src, float k, int64_t n, void* stream) {
+  WSL_REQUIRE(dst && src && n > 0, "axpy: bad args");
+  WSL_LAUNCH(axpy_kernel, dim3(grid_for(n / 4 + 1)), dim3(kThreads), 0, stream, dst, src, k, n);
+  return check_launch("axpy_kernel");
 }

@@ -6,6 +6,9 @@ Steps reproduced (reference file:line, all under code/):
   'pce'             train_weakly_supervised_pCE_2D.py:96-108 (unet) / dual-branch 0.5*(ce1+ce2) (unet_cct, config 1)
   'pce_gatedcrf'    train_weakly_supervised_pCE_GatedCRFLoss_2D.py:108-130 (unet);  unet_cct: 0.5*(ce1+ce2) +
                     0.1*GatedCRF(beta*s1+(1-beta)*s2) as in train_ACDC_scribblevc.py:171-206
+  'mean_teacher'    SURVEY 8d config 4 (unet student + EMA teacher): pCE + 1e-2*tv_loss(softmax[1:]) (pCE_TV_2D.py:113-114)
+                    + w(t)*mean((softmax(s)-softmax(teacher(x+noise)))^2) (train_mean_teacher_2D.py:147-171); teacher =
+                    EMA of the student every step (train_weakly_supervised_ustm_2D.py:61-65,163), kept in train mode
 Optimiser: SGD(lr, momentum 0.9, wd 1e-4) with the poly schedule applied one step late (ours_proposed.py:126-132).
 
 Data parallel (DDP-equivalent semantics): one process per GPU, per-rank BatchNorm statistics and loss
@@ -27,7 +30,7 @@ class TrainEngine:
     def __init__(self, net_type="unet_cct", in_chns=1, class_num=4, base_lr=0.01, max_iterations=60000, momentum=0.9,
                  weight_decay=1e-4, loss="ours_proposed", w_pse=0.5, crf_radius=5, crf_weight=0.1,
                  crf_desc=None, ignore_index=4, model=None):
-        if loss not in ("ours_proposed", "pce", "pce_gatedcrf"):
+        if loss not in ("ours_proposed", "pce", "pce_gatedcrf", "mean_teacher"):
             raise NotImplementedError(f"loss composition '{loss}'")
         self.model = model if model is not None else net_factory(net_type, in_chns, class_num)
         if self.model is None:
@@ -51,6 +54,16 @@ class TrainEngine:
             dist.broadcast(self.model._param_arena, src=0)
             dist.broadcast(self.model._buf_arena, src=0)
         self._bufs = {}
+        self.teacher = None
+        if loss == "mean_teacher":
+            if self.dual:
+                raise _lib.WslError("'mean_teacher' is defined for the single-decoder unet")
+            self.teacher = net_factory(net_type, in_chns, class_num)
+            self.teacher.train()                          # the reference never puts the EMA model in eval()
+            with torch.no_grad():
+                self.teacher._param_arena.copy_(self.model._param_arena)
+                self.teacher._buf_arena.copy_(self.model._buf_arena)
+            self.tv_weight, self.cons_max, self.ema_decay = 1e-2, 0.1, 0.99
 
     # ------------------------------------------------------------------ helpers
     def _tensors(self, N, H, W):
@@ -61,6 +74,8 @@ class TrainEngine:
             t = {"dz1": mk(), "dz2": mk() if self.dual else None}
             if self.loss_kind == "pce_gatedcrf":
                 t["y"], t["msg"] = mk(), mk()
+            if self.loss_kind == "mean_teacher":
+                t["s"], t["ds"], t["dzx"] = mk(), mk(), mk()
             self._bufs = {key: t}
         return self._bufs[key]
 
@@ -75,12 +90,36 @@ class TrainEngine:
             dist.all_reduce(flat)
 
     # ------------------------------------------------------------------ one optimiser step
-    def step(self, x, label_u8, beta):
-        """One optimiser step: forward, loss, backward (+ gradient all-reduce), SGD, poly-LR update."""
-        self.forward_backward(x, label_u8, beta)
+    def step(self, x, label_u8, beta=0.5, noise=None):
+        """One optimiser step: forward, loss, backward (+ gradient all-reduce), SGD (+EMA teacher), poly-LR update."""
+        self.forward_backward(x, label_u8, beta, noise)
         self.optimizer_step()
 
-    def forward_backward(self, x, label_u8, beta):
+    def _mean_teacher_losses(self, x, label_u8, z, t, noise):
+        """dz of pCE + tv + consistency for the student logits z; teacher logits from x + noise (no gradient)."""
+        m, N, H, W = self.model, x.shape[0], x.shape[2], x.shape[3]
+        HW, C_ = H * W, self.model.class_num
+        if noise is None:                                  # ustm_2D.py:125-127 / train_mean_teacher_2D.py:147-149
+            noise = torch.clamp(torch.randn_like(x) * 0.1, -0.2, 0.2)
+        with torch.no_grad():
+            zt = self.teacher._run_forward(x + noise)[0]
+        nl = rt.L().wsl_loss_ws_bytes(N, C_, HW)
+        lws = rt.workspace("loss", nl)
+        lo = self.loss_out
+        rt.call("wsl_head_fwd_bwd", rt.ptr(z), None, rt.ptr(label_u8), self.ignore, 0.0, 0.0, 1.0, rt.ptr(lo), None,
+                rt.ptr(t["dz1"]), None, N, C_, HW, rt.ptr(lws), nl, rt.stream())
+        rt.call("wsl_softmax_fwd", rt.ptr(z), rt.ptr(t["s"]), N, C_, HW, rt.stream())
+        rt.call("wsl_tv_fwd_bwd", rt.ptr(t["s"]), 1, rt.ptr(lo[4:]), rt.ptr(t["ds"]), self.tv_weight, N, C_, H, W, rt.ptr(lws),
+                nl, rt.stream())
+        rt.call("wsl_softmax_bwd", rt.ptr(t["s"]), rt.ptr(t["ds"]), rt.ptr(t["dzx"]), N, C_, HW, rt.stream())
+        rt.call("wsl_axpy", rt.ptr(t["dz1"]), rt.ptr(t["dzx"]), 1.0, N * C_ * HW, rt.stream())
+        from .utils.ramps import sigmoid_rampup
+        self._cons_w = self.cons_max * sigmoid_rampup(self.it // 300, 200.0)
+        rt.call("wsl_softmax_mse_fwd_bwd", rt.ptr(z), rt.ptr(zt), rt.ptr(lo[5:]), rt.ptr(t["dzx"]), self._cons_w, N, C_, HW,
+                rt.ptr(lws), nl, rt.stream())
+        rt.call("wsl_axpy", rt.ptr(t["dz1"]), rt.ptr(t["dzx"]), 1.0, N * C_ * HW, rt.stream())
+
+    def forward_backward(self, x, label_u8, beta, noise=None):
         """Everything up to (and including) the gradient all-reduce; flat_grads() then holds the SUM over ranks."""
         m = self.model
         x = rt.f32c(x, "image batch")
@@ -93,6 +132,10 @@ class TrainEngine:
         L = rt.L()
         nl = L.wsl_loss_ws_bytes(N, m.class_num, HW)
         lws = rt.workspace("loss", nl)
+        if self.loss_kind == "mean_teacher":
+            self._mean_teacher_losses(x, label_u8, z1, t, noise)
+            self._finish_backward(x, t)
+            return
         w_pse = self.w_pse if self.loss_kind == "ours_proposed" else 0.0
         rt.call("wsl_head_fwd_bwd", rt.ptr(z1), rt.ptr(z2), rt.ptr(label_u8), self.ignore, float(beta), w_pse, 1.0,
                 rt.ptr(self.loss_out), None, rt.ptr(t["dz1"]), rt.ptr(t["dz2"]), N, m.class_num, HW, rt.ptr(lws), nl,
@@ -105,6 +148,10 @@ class TrainEngine:
             k = -2.0 * self.crf_weight / (N * HW)          # d(crf_weight*loss)/dy = -2*w*msg/(N*H*W)
             rt.call("wsl_mixprob_bwd", rt.ptr(z1), rt.ptr(z2), float(beta), rt.ptr(t["msg"]), k, rt.ptr(t["dz1"]),
                     rt.ptr(t["dz2"]), 1, N, m.class_num, HW, rt.stream())
+        self._finish_backward(x, t)
+
+    def _finish_backward(self, x, t):
+        m = self.model
         g = [t["dz1"], t["dz2"]]
         flat_g = m.flat_grads()
         if self.world > 1:
@@ -119,8 +166,11 @@ class TrainEngine:
 
     def optimizer_step(self):
         m = self.model
+        ema, alpha = None, 0.0
+        if self.teacher is not None:      # update_ema_variables(model, ema_model, 0.99, iter_num), iter before increment
+            ema, alpha = self.teacher._param_arena, min(1.0 - 1.0 / (self.it + 1), self.ema_decay)
         rt.call("wsl_sgd_step", rt.ptr(m._param_arena), rt.ptr(m._grad_arena), rt.ptr(self.mom), self.n, float(self.lr),
-                self.mu, self.wd, int(self.it == 0), 1.0 / self.world, None, 0.0, rt.stream())
+                self.mu, self.wd, int(self.it == 0), 1.0 / self.world, rt.ptr(ema), alpha, rt.stream())
         self.lr = self.base_lr * (1.0 - self.it / self.max_it) ** 0.9      # takes effect at the NEXT step
         self.it += 1
 
@@ -129,4 +179,7 @@ class TrainEngine:
         o = self.loss_out.tolist()
         if self.loss_kind == "pce_gatedcrf":
             return {"loss": o[1] + self.crf_weight * o[4], "ce": o[1], "crf": o[4], "n_valid": o[3]}
+        if self.loss_kind == "mean_teacher":   # tv / cons are the raw (unweighted) terms
+            return {"loss": o[1] + self.tv_weight * o[4] + self._cons_w * o[5], "ce": o[1], "tv": o[4], "cons": o[5],
+                    "n_valid": o[3]}
         return {"loss": o[0], "ce": o[1], "pse": o[2], "n_valid": o[3]}
