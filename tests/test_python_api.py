@@ -276,3 +276,35 @@ def test_mean_teacher_step_against_oracle(mode):
     for k in pk:
         assert rel_err(got_s[k].detach().cpu(), sd_s[k].detach()) < 1e-4, k
         assert rel_err(got_t[k].detach().cpu(), sd_t[k].detach()) < 1e-4, k
+
+
+def test_validation_volume_label_maps(mode):
+    """val_2D-style per-volume inference: label maps of the HIP eval forward vs the oracle's (bit-exact argmax is pinned
+    at op level; end to end we report the near-tie mismatch rate) and the in-house Dice."""
+    from oracle import torch_ref as R
+    from wsl4mis_amd import val_2D
+    from wsl4mis_amd.networks.net_factory import net_factory
+    rng = np.random.default_rng(3)
+    D, H, W, P = 2, 20, 24, (16, 16)
+    vol = rng.random((D, H, W)).astype(np.float32)
+    lab = rng.integers(0, 4, (D, H, W)).astype(np.uint8)
+    m = net_factory("unet_cct", 1, 4)
+    load_det(m, 5)
+    got = val_2D.test_single_volume_cct(torch.from_numpy(vol)[None], torch.from_numpy(lab)[None], m, classes=4, patch_size=P)
+    assert len(got) == 3 and all(0.0 <= d <= 1.0 and np.isnan(h) for d, h in got)
+    # oracle label maps for the same slices
+    from scipy.ndimage import zoom
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in det_state(
+        {k: tuple(v.shape) for k, v in m.state_dict().items()}, 5).items()}
+    pred = val_2D._predict_volume(vol, m, P, first_output=True)
+    mism = 0
+    for i in range(D):
+        inp = torch.from_numpy(zoom(vol[i], (P[0] / H, P[1] / W), order=0))[None, None]
+        with torch.no_grad():
+            z = R.net_forward(sd, inp, "unet_cct", None, [torch.ones(1, 16 << l) for l in range(5)], False)[0]
+        ref = zoom(torch.argmax(z, 1)[0].numpy().astype(np.uint8), (H / P[0], W / P[1]), order=0)
+        mism += int((ref != pred[i]).sum())
+    assert mism <= 0.01 * pred.size, mism
+    assert val_2D.dice_percase(np.array([1, 1, 0]), np.array([1, 0, 0])) == pytest.approx(2 / 3)
+    with pytest.raises(NotImplementedError):
+        val_2D.test_single_volume(torch.from_numpy(vol[0]), torch.from_numpy(lab[0]), m, 4)
