@@ -127,6 +127,8 @@ static inline T __shfl(T v, int src, int = 64) { return wsl_emu_shfl(v, src); }
 
 struct alignas(16) float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct alignas(8) float2 { float x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 struct alignas(4) uchar4 { unsigned char x, y, z, w; };
 static inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return uchar4{x, y, z, w}; }
 typedef float wsl_v4f __attribute__((ext_vector_type(4)));

@@ -36,6 +36,13 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
     (1, 16, 64, 9, 0, 12, 1, True),
     (3, 16, 32, 8, 8, 16, 3, True),
     (4, 8, 16, 4, 0, 40, 3, True),
+    # shapes the lean kernel takes (full tiles, Ci % 8 == 0, Co a multiple of the channel block)
+    (2, 16, 16, 16, 16, 32, 3, True),
+    (1, 8, 64, 8, 0, 16, 1, True),
+    (1, 16, 64, 24, 8, 32, 3, True),
+    (2, 8, 32, 8, 0, 64, 3, False),
+    (1, 16, 16, 16, 0, 64, 1, True),
+    (1, 16, 128, 8, 8, 16, 3, True),
 ]
 
 

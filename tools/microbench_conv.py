@@ -22,7 +22,7 @@ scale, shift = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0
 s = _lib.WslSrc()
 s.x, s.bs, s.C, s.scale, s.shift, s.emask_scale = x.data_ptr(), Ci * H * W, Ci, scale.data_ptr(), shift.data_ptr(), 1.0
 nblk = L.wsl_conv2d_stat_blocks(N, H, W, Ci, Co, ks)
-part, cnt = torch.empty(nblk * Co * 2, device=dev), torch.empty(nblk, device=dev)
+part, cnt = torch.zeros(max(nblk * Co * 2, nblk * 64), device=dev), torch.empty(nblk, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 _lib.check(L.wsl_conv2d_pack_weights(w.data_ptr(), wp.data_ptr(), Co, Ci, ks, 0, st))
 
@@ -45,3 +45,32 @@ us = e0.elapsed_time(e1) * 1e3 / R
 fl = 2.0 * N * H * W * Co * Ci * ks * ks
 print(f"ablate={os.environ.get('WSL_CONV_ABLATE','0')} N={N} {Ci}->{Co} {H}x{W} k{ks}: {us:8.1f} us  {fl/us/1e6:7.1f} TFLOP/s  "
       f"in+out {4.0*N*H*W*(Ci+Co)/us/1e3:7.1f} GB/s")
+
+if int(os.environ.get('WSL_CONV_ABLATE', '0')) & 64:
+    la = cnt.view(torch.int32).cpu().numpy().astype('uint32')
+    hw = part.view(torch.int32).cpu().numpy().astype('uint32')[::Co * 2][:len(la)]
+    import collections
+    print('LDS_ALLOC values:', collections.Counter(hex(v) for v in la).most_common(8))
+    print('HW_ID wave slots:', collections.Counter(int(v & 0xf) for v in hw).most_common(8))
+    print('HW_ID simd:', collections.Counter(int((v >> 4) & 3) for v in hw).most_common(8))
+    print('first 16 hw ids:', [hex(v) for v in hw[:16]])
+
+if int(os.environ.get('WSL_CONV_ABLATE', '0')) & 128:
+    import numpy as np
+    t = part.view(torch.int64).cpu().numpy()[:nblk * 32].reshape(nblk, 32)
+    ok = t[:, 0] > 0
+    ids = np.where(ok)[0]
+    t = t[ok]
+    hw = t[:, 28]
+    f = ((t[:, 26] - t[:, 0]) / ((t[:, 30] - t[:, 29]) / 100.0)).mean()   # shader-clock ticks per us
+    rt0 = t[:, 29].min()
+    print(f'{len(t)} workgroups stamped; shader clock {f:.0f} MHz; kernel span {(t[:, 30].max() - rt0) / 100.0:.1f} us')
+    nch = min((Ci + 7) // 8, 4)
+    names = ['prologue(issue0+tables)'] + sum([[f'c{c}:wait-data', f'c{c}:commit', f'c{c}:barrier', f'c{c}:issue', f'c{c}:mfma', f'c{c}:barrier2'] for c in range(nch)], []) + ['epilogue']
+    idx = [0, 1] + sum([[2 + 6 * c + j for j in range(6)] for c in range(nch)], []) + [26]
+    d = np.diff(t[:, idx], axis=1)
+    slot = hw & 0xf
+    print('mean phase durations (shader cycles): all | by wave slot')
+    for j, nm in enumerate(names):
+        print(f'   {nm:28s} {d[:, j].mean():8.0f} | ' + ' '.join(f'{d[slot == sl, j].mean():8.0f}' for sl in sorted(set(slot))))
+    print(f'   total per workgroup          {(t[:, 26] - t[:, 0]).mean():8.0f}')

@@ -317,6 +317,256 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
   }
 }
 
+// ------------------------------------------------------------------------------------------------ lean variant
+// Same tiling, LDS layout and MFMA stages as conv_mfma2_kernel, for the shapes every layer of the training step has:
+// Ci % KC == 0 (a chunk never straddles the two sources), Co % CO_T == 0, H % TH == 0 and W % TW == 0.  The per-workgroup
+// timeline (WSL_CONV_ABLATE=128, profiles/r1g_conv_timeline.md) showed the generic kernel's waves spending more cycles
+// ISSUING the staging code (scalar 64-bit address chains, per-element source selects, bounds tests) than in the MFMA
+// stream, with memory latency fully hidden.  Here the staging is cut to the minimum instruction count:
+//   * one workgroup-uniform source select and base pointer per chunk, per-load addresses = scalar base + i * stride
+//     + ONE per-thread 32-bit offset; threads outside the image load a valid dummy address and never write LDS (their
+//     LDS slots are zeroed once), so no load sits under a divergent branch;
+//   * BN scale/shift as one LDS float2 per channel, LeakyReLU as max(z, slope z), keep-mask bytes (0/1) applied as a
+//     float factor; the whole transform under a single exec region;
+//   * epilogue without bounds tests, store offsets folded into immediates / scalar adds.
+template <int KS, int TH, int TW, int CO_T, int KC>
+__global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void conv_mfma2l_kernel(Conv2P p) {
+  using C = Conv2Cfg<KS, TH, TW, CO_T, KC>;
+  static_assert(KC % C::G == 0 && C::MT % C::SEGS == 0, "lean staging shape");
+  WSL_DYN_SMEM(smem);
+  float* in_t = reinterpret_cast<float*>(smem);
+  float* w_t = in_t + C::IN_FLOATS;
+  float2* tab = reinterpret_cast<float2*>(w_t + C::W_FLOATS);   // [Ci] {scale, shift}  (2 * MAXC floats)
+  float* cm_l = w_t + C::W_FLOATS + 2 * C::MAXC;                // [Ci] channel multiplier of this sample
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD-aware tile order, as conv_mfma2_kernel
+  const int tile_id = bid;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = blockIdx.y * CO_T;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
+  const int HW = H * W;
+
+  // ---- this thread's staging position (fixed for the whole kernel)
+  const int grp = tid / C::POS, pos = tid - grp * C::POS;
+  const int pty = pos / C::ROWP4, ptx4 = pos - pty * C::ROWP4;
+  const int gy = y0 + pty - C::P, gx = x0 + ptx4 * 4 - C::PADL;
+  const bool owner = grp < C::G;                                   // owns LDS slots (pos, grp + i * G)
+  const bool pvalid = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
+  const uint32_t toff = pvalid ? (uint32_t)(grp * HW + gy * W + gx) : 0u;   // element offset inside a chunk's channels
+  const int loff = grp * C::PLANE + pty * C::ROWP + ptx4 * 4;
+  const int64_t gstride = (int64_t)C::G * HW;                      // elements between consecutive loads of a thread
+  const float* xa_n = p.a.x + n * p.a.bs;
+  const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
+  const uint8_t* ma_n = p.a.emask ? p.a.emask + (int64_t)n * p.a.C * HW : nullptr;
+  const uint8_t* mb_n = (p.b.C && p.b.emask) ? p.b.emask + (int64_t)n * p.b.C * HW : nullptr;
+
+  // weights of a chunk: row = (tap, c) of the packed image, this thread copies float4 #(tid + i * 256)
+  uint32_t woff[C::NWL];
+  int wl[C::NWL];
+#pragma unroll
+  for (int i = 0; i < C::NWL; ++i) {
+    const int f = tid + i * kThreads;
+    const int row = f / C::WQ, q = f - row * C::WQ;
+    const int tap = row / KC, c = row - tap * KC;
+    woff[i] = f < C::WF4 ? (uint32_t)((tap * Ci + c) * Co + q * 4) : 0u;   // threads past the image copy nothing
+    wl[i] = row * C::CSTR + q * 4;
+  }
+  const float* w_n = p.wp + co0;
+
+  float4 pre[C::NLD];
+  uint32_t prm[C::NLD];
+  v4f prw[C::NWL];   // a native vector: a float4 struct copied global -> private -> LDS stays a memcpy pair in scratch
+
+  auto issue = [&](int c0) __attribute__((always_inline)) {
+    const bool ina = c0 < p.a.C;                                   // uniform
+    const int chb = ina ? c0 : c0 - p.a.C;
+    const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
+    const uint8_t* mb = ina ? ma_n : mb_n;
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + i * gstride + toff);
+    if (mb) {
+      mb += (int64_t)chb * HW;
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * gstride + toff);
+    }
+    const float* wb = w_n + (int64_t)c0 * Co;
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) prw[i] = *reinterpret_cast<const v4f*>(wb + woff[i]);   // unconditional
+  };
+
+  auto commit = [&](int c0) __attribute__((always_inline)) {
+    if (pvalid) {
+      const bool ina = c0 < p.a.C;
+      const bool has_scale = (ina ? p.a.scale : p.b.scale) != nullptr;
+      const bool has_mask = (ina ? p.a.emask : p.b.emask) != nullptr;
+      const bool has_cm = (ina ? p.a.cmask : p.b.cmask) != nullptr;
+      const float es = ina ? p.a.es : p.b.es;
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) {
+        float4 v = pre[i];
+        const int c = c0 + grp + i * C::G;
+        if (has_scale) {
+          const float2 t = tab[c];
+          v.x = fmaf(v.x, t.x, t.y), v.y = fmaf(v.y, t.x, t.y), v.z = fmaf(v.z, t.x, t.y), v.w = fmaf(v.w, t.x, t.y);
+          v.x = fmaxf(v.x, WSL_LEAKY_SLOPE * v.x), v.y = fmaxf(v.y, WSL_LEAKY_SLOPE * v.y);
+          v.z = fmaxf(v.z, WSL_LEAKY_SLOPE * v.z), v.w = fmaxf(v.w, WSL_LEAKY_SLOPE * v.w);
+        }
+        if (has_mask) {   // keep-mask bytes are 0 or 1
+          const uint32_t m = prm[i];
+          v.x *= es * (float)(m & 0xffu), v.y *= es * (float)((m >> 8) & 0xffu);
+          v.z *= es * (float)((m >> 16) & 0xffu), v.w *= es * (float)(m >> 24);
+        }
+        if (has_cm) {
+          const float cm = cm_l[c];
+          v.x *= cm, v.y *= cm, v.z *= cm, v.w *= cm;
+        }
+        *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i)
+      if ((i + 1) * kThreads <= C::WF4 || tid + i * kThreads < C::WF4) *reinterpret_cast<v4f*>(w_t + wl[i]) = prw[i];
+  };
+
+#ifndef WSL_HOST_EMUL
+  // debug timeline (WSL_CONV_ABLATE & 128): thread 0 stamps s_memtime at the phase boundaries of this workgroup
+  uint64_t* tl = (p.ablate & 128) ? reinterpret_cast<uint64_t*>(p.stat_part) + (int64_t)tile_id * 32 : nullptr;
+#define WSL_MARK(k) do { if (tl && tid == 0) tl[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  if (tl && tid == 0) tl[29] = __builtin_amdgcn_s_memrealtime(), tl[28] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#else
+#define WSL_MARK(k)
+#endif
+  WSL_MARK(0);
+  issue(0);
+  // tables and the one-time zero fill of this thread's LDS slots (positions outside the image stay zero for good)
+  for (int c = tid; c < Ci; c += kThreads) {
+    const bool ina = c < p.a.C;
+    const Src2& s = ina ? p.a : p.b;
+    const int ch = ina ? c : c - p.a.C;
+    tab[c] = s.scale ? make_float2(s.scale[ch], s.shift[ch]) : make_float2(1.f, 0.f);
+    cm_l[c] = s.cmask ? s.cmask[(int64_t)n * s.C + ch] : 1.f;
+  }
+  if (owner && !pvalid) {
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i)
+      *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  v4f acc[C::MT][C::NT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  int abase[C::MT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i) {
+    const int mt = wave * C::MT + i;
+    abase[i] = (lane >> 4) * C::PLANE + (mt / C::SEGS) * C::ROWP + (mt % C::SEGS) * 16 + (lane & 15) + (C::PADL - C::P);
+  }
+  const int bbase = (lane >> 4) * C::CSTR + (lane & 15);
+  __syncthreads();  // tables visible
+  WSL_MARK(1);
+  for (int c0 = 0; c0 < Ci; c0 += KC) {
+#ifndef WSL_HOST_EMUL
+    const int mk = 2 + 6 * (c0 / KC < 4 ? c0 / KC : 3);
+    if (tl) __builtin_amdgcn_s_waitcnt(0);   // prefetched data has arrived
+#endif
+    WSL_MARK(mk);
+    if (!(p.ablate & 2) || c0 == 0) commit(c0);
+    WSL_MARK(mk + 1);
+    __syncthreads();
+    WSL_MARK(mk + 2);
+    if (c0 + KC < Ci && !(p.ablate & 2)) issue(c0 + KC);   // in flight during the MFMA loop below
+    WSL_MARK(mk + 3);
+    if (!(p.ablate & 1)) conv2_mfma_stages<C, KS, KC, KC / 4>(in_t, w_t, abase, bbase, acc);
+    WSL_MARK(mk + 4);
+    __syncthreads();
+    WSL_MARK(mk + 5);
+  }
+
+  // ---- epilogue: bias, float4 stores, BatchNorm partial statistics (tile and channel block are full by eligibility)
+  if (p.ablate & 4) {
+    if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;   // keep the accumulators live
+    return;
+  }
+  float bsum[C::NT];
+  {
+    constexpr int RPW = C::MT / C::SEGS;   // output rows per wave
+    float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
+      float* yj = yb + (int64_t)j * 16 * HW;
+      float bs = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i) {
+        v4f v = acc[i][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bias;
+        acc[i][j] = v;
+        *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16) = make_float4(v[0], v[1], v[2], v[3]);
+        bs += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      bsum[j] = bs;
+    }
+  }
+#ifndef WSL_HOST_EMUL
+  if (tl) {
+    __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
+    WSL_MARK(26);
+    if (tid == 0) tl[30] = __builtin_amdgcn_s_memrealtime();
+    return;
+  }
+#endif
+  if (p.stat_part) {
+    float* red1 = in_t;
+    float* red2 = in_t + 4 * CO_T;
+    constexpr float cnt = (float)(TH * TW);
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int col = j * 16 + (lane & 15);
+      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][j][r] - mean_b;
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) {
+        const int col = j * 16 + lane, co = co0 + col;
+        float* dst = p.stat_part + ((int64_t)tile_id * p.slots * Co + co) * 2;   // slot 0 of this tile's slots
+        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+      }
+      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
+    }
+  }
+}
+#undef WSL_MARK
+
 // packed[tap][ci][co] = wmode 0: w[co][ci][tap]   |   wmode 1 (data gradient): w[ci][co][KK-1-tap]
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* wp, int Co, int Ci, int KK, int wmode) {
   const int64_t total = (int64_t)KK * Ci * Co;
@@ -350,8 +600,31 @@ int conv2_pack_table(const PackTable& t, const float* params, float* packf, floa
 }
 
 template <int KS, int TH, int TW, int CO_T>
+static int launch_conv2l(Conv2P& p, int wmode_for_prof, void* stream) {
+  using C = Conv2Cfg<KS, TH, TW, CO_T, 8>;
+  auto kern = conv_mfma2l_kernel<KS, TH, TW, CO_T, 8>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_mfma2l_kernel");
+}
+
+template <int KS, int TH, int TW, int CO_T>
 static int launch_conv2(Conv2P& p, int wmode_for_prof, void* stream) {
   using C = Conv2Cfg<KS, TH, TW, CO_T, 8>;
+  // the lean kernel takes every shape it is eligible for (WSL_CONV_LEAN=0 forces the generic one, for A/B timing)
+  static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
+  const int64_t span = (int64_t)(p.a.C > p.b.C ? p.a.C : p.b.C) * p.H * p.W;
+  if (lean_on && p.Ci % 8 == 0 && (p.b.C == 0 || p.a.C % 8 == 0) && p.Co % CO_T == 0 && p.H % TH == 0 && p.W % TW == 0 &&
+      span < (int64_t(1) << 31) && (int64_t)KS * KS * p.Ci * p.Co < (int64_t(1) << 31))
+    return launch_conv2l<KS, TH, TW, CO_T>(p, wmode_for_prof, stream);
   auto kern = conv_mfma2_kernel<KS, TH, TW, CO_T, 8>;
   static bool attr_done = false;
   if (!attr_done) {
