@@ -43,6 +43,10 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
     (2, 8, 32, 8, 0, 64, 3, False),
     (1, 16, 16, 16, 0, 64, 1, True),
     (1, 16, 128, 8, 8, 16, 3, True),
+    # ... and the lean weight-gradient kernel (channel blocks inside one source)
+    (2, 16, 16, 16, 16, 16, 3, True),
+    (1, 8, 32, 32, 32, 32, 3, True),
+    (1, 8, 64, 16, 0, 16, 3, True),
 ]
 
 

@@ -924,9 +924,216 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2_kernel(Wgrad2P p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ lean weight gradient
+// wgrad_mfma2_kernel for the shapes of the training step (Ci % IB == 0, Co % CB == 0, full tiles, a channel block that
+// lies inside one source), with the staging rebuilt like conv_mfma2l_kernel: the source of the block is chosen once per
+// workgroup, addresses are a scalar base + one per-thread offset, no load sits under a divergent branch (threads
+// outside the image read a valid dummy element and stage zeros), LDS writes are 8-byte pairs.
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma2l_kernel(Wgrad2P p) {
+  using C = Wgrad2Cfg<KS, TH, TW, CB, IB, WK>;
+  static_assert(CB % C::GD == 0 && IB % C::GA == 0 && C::PP == 1, "lean wgrad staging shape");
+  WSL_DYN_SMEM(smem);
+  float* dy_t = reinterpret_cast<float*>(smem);
+  float* a_t = dy_t + C::DY_FLOATS;
+  float2* tab = reinterpret_cast<float2*>(dy_t + C::MAIN_FLOATS);   // [IB] {scale, shift} of this block's channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = blockIdx.x % p.co_blocks, ib = blockIdx.x / p.co_blocks, split = blockIdx.y;
+  const int co0 = cb * CB, ci0 = ib * IB;
+  const int wp_ = wave % C::WP, wk = wave / C::WP;
+  const int H = p.H, W = p.W, Ci = p.Ci;
+  const int HW = H * W;
+
+  // the source this block of input channels comes from (uniform for the whole workgroup)
+  const bool ina = ci0 < p.a.C;
+  const Src2& s = ina ? p.a : p.b;
+  const int chb0 = ina ? ci0 : ci0 - p.a.C;
+  const bool has_scale = s.scale != nullptr, has_mask = s.emask != nullptr, has_cm = s.cmask != nullptr;
+  const float es = s.es;
+  for (int c = tid; c < IB; c += kThreads) tab[c] = has_scale ? make_float2(s.scale[chb0 + c], s.shift[chb0 + c]) : make_float2(1.f, 0.f);
+
+  // fixed staging positions of this thread
+  const int gd = tid / C::PD, pd = tid - gd * C::PD;             // dy: float4 index pd inside the TH x TW tile
+  const int dty = (pd * 4) / TW, dtx = (pd * 4) - dty * TW;
+  const bool owner_d = gd < C::GD;
+  const uint32_t tdoff = owner_d ? (uint32_t)(gd * HW + dty * W + dtx) : 0u;
+  const int dloff = gd * C::PLD + pd * 4;
+  const int ga = tid / C::PA, pa = tid - ga * C::PA;             // input: float4 index inside the halo tile
+  const int aty = pa / C::ROWP4, atx4 = pa - aty * C::ROWP4;
+  const bool owner_a = ga < C::GA;
+  const int aloff = ga * C::PLA + aty * C::ROWP + atx4 * 4;
+  const int64_t dstride = (int64_t)C::GD * HW, astride = (int64_t)C::GA * HW;
+
+  v4f acc[C::KK];
+  v4f accb = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < C::KK; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  const bool want_db = (ib == 0) && (p.part_db != nullptr);
+  const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
+
+  float4 prd[C::ND], pra[C::NA];
+  uint32_t prm[C::NA];
+  float prc[C::NA];
+  bool pr_aok = false;   // the prefetched input position lies inside the image
+  int nx_tx, nx_ty, nx_n;   // tile the next issue() fetches
+  {
+    int q = it0;
+    nx_tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    nx_ty = q % p.tiles_y;
+    nx_n = q / p.tiles_y;
+  }
+
+  auto issue = [&]() __attribute__((always_inline)) {
+    const int n = nx_n, y0 = nx_ty * TH, x0 = nx_tx * TW;
+    if (++nx_tx == p.tiles_x) {
+      nx_tx = 0;
+      if (++nx_ty == p.tiles_y) nx_ty = 0, ++nx_n;
+    }
+    const float* dyb = p.dy + n * p.dy_bs + (int64_t)co0 * HW + y0 * W + x0;
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) prd[i] = *reinterpret_cast<const float4*>(dyb + i * dstride + tdoff);
+    const int gy = y0 + aty - C::P, gx = x0 + atx4 * 4 - C::PADL;
+    pr_aok = owner_a && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const uint32_t taoff = pr_aok ? (uint32_t)(ga * HW + gy * W + gx) : 0u;
+    const float* xb = s.x + n * s.bs + (int64_t)chb0 * HW;
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i) pra[i] = *reinterpret_cast<const float4*>(xb + i * astride + taoff);
+    if (has_mask) {
+      const uint8_t* mb = s.emask + ((int64_t)n * s.C + chb0) * HW;
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * astride + taoff);
+    }
+    if (has_cm) {
+      const float* cmb = s.cmask + (int64_t)n * s.C + chb0 + (owner_a ? ga : 0);
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) prc[i] = cmb[i * C::GA];
+    }
+  };
+
+  auto commit = [&]() __attribute__((always_inline)) {
+    if (owner_d) {
+#pragma unroll
+      for (int i = 0; i < C::ND; ++i) {
+        float* dst = dy_t + i * (C::GD * C::PLD) + dloff;   // plane stride == 2 (mod 32): 8-byte aligned, not 16
+        *reinterpret_cast<float2*>(dst) = make_float2(prd[i].x, prd[i].y);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(prd[i].z, prd[i].w);
+      }
+    }
+    if (owner_a) {
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) {
+        float4 v = pra[i];
+        if (has_scale) {
+          const float2 t = tab[ga + i * C::GA];
+          v.x = fmaf(v.x, t.x, t.y), v.y = fmaf(v.y, t.x, t.y), v.z = fmaf(v.z, t.x, t.y), v.w = fmaf(v.w, t.x, t.y);
+          v.x = fmaxf(v.x, WSL_LEAKY_SLOPE * v.x), v.y = fmaxf(v.y, WSL_LEAKY_SLOPE * v.y);
+          v.z = fmaxf(v.z, WSL_LEAKY_SLOPE * v.z), v.w = fmaxf(v.w, WSL_LEAKY_SLOPE * v.w);
+        }
+        if (has_mask) {   // keep-mask bytes are 0 or 1
+          const uint32_t m = prm[i];
+          v.x *= es * (float)(m & 0xffu), v.y *= es * (float)((m >> 8) & 0xffu);
+          v.z *= es * (float)((m >> 16) & 0xffu), v.w *= es * (float)(m >> 24);
+        }
+        if (has_cm) v.x *= prc[i], v.y *= prc[i], v.z *= prc[i], v.w *= prc[i];
+        if (!pr_aok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* dst = a_t + i * (C::GA * C::PLA) + aloff;
+        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+      }
+    }
+  };
+
+  if (it0 < it1) issue();
+  __syncthreads();  // BN table visible
+  const int cot = wp_ / C::IBT, cit = wp_ % C::IBT;
+  const float* dyp = dy_t + (cot * 16 + (lane & 15)) * C::PLD + (lane >> 4);
+  const float* ap = a_t + (cit * 16 + (lane & 15)) * C::PLA + (lane >> 4) + (C::PADL - C::P);
+  const bool dbw = want_db && cit == 0;
+  for (int item = it0; item < it1; ++item) {
+    commit();
+    __syncthreads();
+    if (item + 1 < it1) issue();   // prefetch the next tile; in flight during the MFMA loop
+    constexpr int RW = TH / WK, NX = TW / 4, NSTEP = RW * NX;
+    float avv[2], bvv[2][C::KK];
+    auto load = [&](int st, int buf) {   // step st = (row, group of 4 pixels)
+      const int r = wk * RW + st / NX, x4 = st % NX;
+      avv[buf] = dyp[r * TW + x4 * 4];
+#pragma unroll
+      for (int t = 0; t < C::KK; ++t) bvv[buf][t] = ap[(r + t / KS) * C::ROWP + x4 * 4 + (t % KS)];
+    };
+    load(0, 0);
+#pragma unroll 2
+    for (int st = 0; st < NSTEP; ++st) {   // operands of step st+1 are read before the MFMAs of step st issue
+      const int cur = st & 1;
+      if (st + 1 < NSTEP) load(st + 1, cur ^ 1);
+      if (dbw) accb = WSL_MFMA16(avv[cur], 1.0f, accb);
+#pragma unroll
+      for (int t = 0; t < C::KK; ++t) acc[t] = WSL_MFMA16(avv[cur], bvv[cur][t], acc[t]);
+      WSL_SCHED_BARRIER();
+    }
+    __syncthreads();
+  }
+  // ---- merge the WK row-groups (fixed order) and store partials
+  if (WK > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int PER = (C::KK + 1) * 4;
+    float* mine = red + (wave * 64 + lane) * PER;
+#pragma unroll
+    for (int t = 0; t < C::KK; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[t * 4 + r] = acc[t][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[C::KK * 4 + r] = accb[r];
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int t = 0; t <= C::KK; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sum = 0.f;
+          for (int k = 0; k < WK; ++k) sum += red[((k * C::WP + wp_) * 64 + lane) * PER + t * 4 + r];
+          if (t < C::KK) acc[t][r] = sum; else accb[r] = sum;
+        }
+    }
+  }
+  if (wk == 0) {
+    const int ci = ci0 + cit * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + cot * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+      for (int t = 0; t < C::KK; ++t) p.part_dw[(((int64_t)split * C::KK + t) * p.Co + co) * Ci + ci] = acc[t][r];
+      if (dbw && (lane & 15) == 0) p.part_db[(int64_t)split * p.Co + co] = accb[r];
+    }
+  }
+}
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+static int launch_wgrad2l(Wgrad2P& p, int ci_blocks, void* stream) {
+  using C = Wgrad2Cfg<KS, TH, TW, CB, IB, WK>;
+  auto kern = wgrad_mfma2l_kernel<KS, TH, TW, CB, IB, WK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("wgrad_mfma2l_kernel");
+}
+
 template <int KS, int TH, int TW, int CB, int IB, int WK>
 static int launch_wgrad2(Wgrad2P& p, int ci_blocks, void* stream) {
   using C = Wgrad2Cfg<KS, TH, TW, CB, IB, WK>;
+  static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
+  const int64_t span = (int64_t)(p.a.C > p.b.C ? p.a.C : p.b.C) * p.H * p.W;
+  if (lean_on && p.Ci % IB == 0 && p.Co % CB == 0 && (p.b.C == 0 || p.a.C % IB == 0) && p.H % TH == 0 && p.W % TW == 0 &&
+      span < (int64_t(1) << 31) && (int64_t)p.Co * p.H * p.W < (int64_t(1) << 31))
+    return launch_wgrad2l<KS, TH, TW, CB, IB, WK>(p, ci_blocks, stream);
   auto kern = wgrad_mfma2_kernel<KS, TH, TW, CB, IB, WK>;
   static bool attr_done = false;
   if (!attr_done) {
