@@ -89,6 +89,24 @@ def test_bilinear_golden(be):
         assert rel_err(be.np(du), g[f"{tag}_dx"]) < 1e-5, tag
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (1, 2, 24, 32), (1, 2, 8, 128), (1, 1, 40, 64), (2, 2, 5, 7), (1, 2, 6, 12)])
+def test_bilinear_fast_and_fallback_shapes(be, shape):
+    """power-of-two widths >= 16 take the float4 / LDS-tile kernels, anything else the reference kernels"""
+    N, C, h, w = shape
+    rng = np.random.default_rng(h * 131 + w)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).requires_grad_()
+    r = rng.standard_normal((N, C, 2 * h, 2 * w)).astype(np.float32)
+    y = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    (y * torch.from_numpy(r)).sum().backward()
+    dx_, dr = be.arr(x.detach().numpy()), be.arr(r)
+    out, du = be.zeros((N, C, 2 * h, 2 * w)), be.zeros(shape)
+    be.call("wsl_bilinear_up2_fwd", be.ptr(dx_), be.ptr(out), C * 4 * h * w, N, C, h, w, be.stream)
+    be.call("wsl_bilinear_up2_bwd", be.ptr(dr), C * 4 * h * w, be.ptr(du), N, C, h, w, be.stream)
+    # fp32: the source coordinate scale*x carries ~1e-5 absolute rounding at x ~ 255, and the device contracts a*b+c
+    assert rel_err(be.np(out), y.detach().numpy()) < 2e-5
+    assert rel_err(be.np(du), x.grad.numpy()) < 1e-5
+
+
 def test_src_materialize_and_eval_affine(be):
     rng = np.random.default_rng(9)
     N, C, H, W = 2, 4, 6, 5

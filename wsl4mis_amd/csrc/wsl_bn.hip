@@ -286,6 +286,110 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const float* dout
   }
 }
 
+// ---- fast variants for power-of-two widths >= 16 and 16-byte aligned planes (every level of the network): four outputs
+// per thread with the column coordinates / weights hoisted out of the row loop and float4 stores (forward); an LDS tile
+// of the output gradient filled with aligned float4 loads (transpose).  Same expressions, same summation order.
+__global__ __launch_bounds__(256) void bilinear_up2_fwd4_kernel(const float* u, float* out, int64_t out_bs, int C, int h,
+                                                                int w, int lc, int rows_per_wg) {
+  const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
+  const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+  const float* src = u + ((int64_t)n * C + c) * h * w;
+  float* dst = out + n * out_bs + (int64_t)c * Ho * Wo;
+  const int col = threadIdx.x & ((1 << lc) - 1), r0 = threadIdx.x >> lc, rstep = kThreads >> lc;
+  int x0[4], x1[4];
+  float lx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lerp_coord(col * 4 + k, sx, w, &x0[k], &x1[k], &lx[k]);
+  const int base = blockIdx.x * rows_per_wg;
+  const int end = base + rows_per_wg < Ho ? base + rows_per_wg : Ho;
+  for (int oy = base + r0; oy < end; oy += rstep) {
+    int y0, y1;
+    float ly;
+    lerp_coord(oy, sy, h, &y0, &y1, &ly);
+    const float* s0 = src + y0 * w;
+    const float* s1 = src + y1 * w;
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float top = (1.f - lx[k]) * s0[x0[k]] + lx[k] * s0[x1[k]];
+      const float bot = (1.f - lx[k]) * s1[x0[k]] + lx[k] * s1[x1[k]];
+      o[k] = (1.f - ly) * top + ly * bot;
+    }
+    *reinterpret_cast<float4*>(dst + (int64_t)oy * Wo + col * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+constexpr int kUpTI = 16;                    // input rows per workgroup of the transpose kernel
+constexpr int kUpRows = 2 * kUpTI + 3;       // output-gradient rows its stencils touch
+constexpr int kUpMaxPitch = 2 * 64 + 8;
+
+__global__ __launch_bounds__(256) void bilinear_up2_bwd4_kernel(const float* dout, int64_t dout_bs, float* du, int C, int h,
+                                                                int w, int ltj) {
+  __shared__ __attribute__((aligned(16))) float tile[kUpRows * kUpMaxPitch];
+  const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
+  const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+  const float* g = dout + n * dout_bs + (int64_t)c * Ho * Wo;
+  const int TJ = 1 << ltj, tiles_j = w >> ltj;
+  const int j0 = (blockIdx.x % tiles_j) << ltj, i0 = (blockIdx.x / tiles_j) * kUpTI;
+  const int pitch = 2 * TJ + 8, nf4 = pitch >> 2;
+  const int Y0 = 2 * i0 - 2, X0 = 2 * j0 - 4;   // X0 is a multiple of 4: rows are fetched as aligned float4
+  for (int e = threadIdx.x; e < kUpRows * nf4; e += kThreads) {
+    const int row = e / nf4, q = e - row * nf4;
+    const int Y = Y0 + row, X = X0 + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (Y >= 0 && Y < Ho && X >= 0 && X < Wo) v = *reinterpret_cast<const float4*>(g + (int64_t)Y * Wo + X);
+    *reinterpret_cast<float4*>(tile + row * pitch + 4 * q) = v;
+  }
+  const int tj = threadIdx.x & (TJ - 1), ty = threadIdx.x >> ltj, tstep = kThreads >> ltj;
+  const int j = j0 + tj;
+  float wx[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int X = 2 * j - 2 + k;
+    wx[k] = 0.f;
+    if (X >= 0 && X < Wo) {
+      int a, b;
+      float l;
+      lerp_coord(X, sx, w, &a, &b, &l);
+      wx[k] = (a == j ? 1.f - l : 0.f) + (b == j ? l : 0.f);
+    }
+  }
+  __syncthreads();
+  for (int ti = ty; ti < kUpTI && i0 + ti < h; ti += tstep) {
+    const int i = i0 + ti;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      const int Y = 2 * i - 2 + ky;
+      float wy = 0.f;
+      if (Y >= 0 && Y < Ho) {
+        int a, b;
+        float l;
+        lerp_coord(Y, sy, h, &a, &b, &l);
+        wy = (a == i ? 1.f - l : 0.f) + (b == i ? l : 0.f);
+      }
+      if (wy != 0.f) {   // same skipping and order as the reference kernel above
+        const float* tr = tile + (2 * ti + ky) * pitch + 2 * tj + 2;
+        float row = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx)
+          if (wx[kx] != 0.f) row = fmaf(wx[kx], tr[kx], row);
+        acc = fmaf(wy, row, acc);
+      }
+    }
+    du[((int64_t)n * C + c) * h * w + (int64_t)i * w + j] = acc;
+  }
+}
+
+static inline bool up2_fast_ok(const void* big, int64_t big_bs, int w) {
+  return w >= 16 && (w & (w - 1)) == 0 && (reinterpret_cast<uintptr_t>(big) & 15) == 0 && (big_bs & 3) == 0;
+}
+static inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
 }  // namespace wsl
 
 using namespace wsl;
@@ -360,6 +464,14 @@ extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const
 extern "C" int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream) {
   WSL_REQUIRE(u && out && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_fwd: bad args");
   WSL_REQUIRE(out_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_fwd: out batch stride too small");
+  if (up2_fast_ok(out, out_bs, w)) {
+    const int lc = ilog2(2 * w / 4);                                // float4 columns of an output row
+    int rows = 16384 / (2 * w);                                     // ~16K outputs per workgroup
+    if (rows < (kThreads >> lc)) rows = kThreads >> lc;
+    WSL_LAUNCH(bilinear_up2_fwd4_kernel, dim3(cdiv(2 * h, rows), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C, h, w,
+               lc, rows);
+    return check_launch("bilinear_up2_fwd4_kernel");
+  }
   WSL_LAUNCH(bilinear_up2_fwd_kernel, dim3(cdiv(4 * h * w, kChunk), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C,
              h, w);
   return check_launch("bilinear_up2_fwd_kernel");
@@ -369,6 +481,12 @@ extern "C" int wsl_bilinear_up2_bwd(const float* dout, int64_t dout_bs, float* d
                                     void* stream) {
   WSL_REQUIRE(dout && du && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_bwd: bad args");
   WSL_REQUIRE(dout_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_bwd: dout batch stride too small");
+  if (up2_fast_ok(dout, dout_bs, w)) {
+    const int ltj = ilog2(w < 64 ? w : 64);
+    WSL_LAUNCH(bilinear_up2_bwd4_kernel, dim3((w >> ltj) * cdiv(h, kUpTI), C, N), dim3(kThreads), 0, stream, dout, dout_bs,
+               du, C, h, w, ltj);
+    return check_launch("bilinear_up2_bwd4_kernel");
+  }
   WSL_LAUNCH(bilinear_up2_bwd_kernel, dim3(cdiv(h * w, kChunk), C, N), dim3(kThreads), 0, stream, dout, dout_bs, du, C,
              h, w);
   return check_launch("bilinear_up2_bwd_kernel");

@@ -11,6 +11,8 @@
 //   weight-gradient:  M = 16 output channels, N = 16 input channels, K = 4 pixels; nine accumulators (one per
 //       tap) per 16x16 channel pair; split over pixels into partials, second stage order-fixed.
 //       db comes from one extra MFMA against a ones operand.
+#include <stdlib.h>
+
 #include "wsl_rt.h"
 
 namespace wsl {
@@ -458,7 +460,8 @@ static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co, bool v2 = false) {
   g.tiles_x = cdiv(W, g.tw), g.tiles_y = cdiv(H, g.th);
   g.items = N * g.tiles_x * g.tiles_y;
   g.co_blocks = cdiv(Co, g.cb), g.ci_blocks = cdiv(Ci, g.ib);
-  int want = 1024 / (g.co_blocks * g.ci_blocks);
+  static const int wgs = getenv("WSL_WGRAD_WGS") ? atoi(getenv("WSL_WGRAD_WGS")) : 768;   // 3 resident workgroups x 256 CUs
+  int want = wgs / (g.co_blocks * g.ci_blocks);
   if (want < 1) want = 1;
   g.nsplit = g.items < want ? g.items : want;
   return g;

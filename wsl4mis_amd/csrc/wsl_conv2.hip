@@ -54,6 +54,7 @@ struct Conv2Cfg {
   static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + W_FLOATS + 3 * MAXC);
   // workgroups per CU the register allocator must leave room for (2nd __launch_bounds__ argument = waves per SIMD)
   static constexpr int MINW = (MT * NT * 4 <= 32) ? 3 : 2;
+  static constexpr int MINWL = (MT * NT * 4 <= 64) ? 3 : 2;   // lean kernel: its staging state is smaller
   static_assert(POS <= 256 && G >= 1, "one float4 position per thread");
   static_assert(MT_TOTAL % 4 == 0 && KC % 4 == 0 && (8 * CO_T) <= IN_FLOATS, "tile shape");
 };
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
 //     float factor; the whole transform under a single exec region;
 //   * epilogue without bounds tests, store offsets folded into immediates / scalar adds.
 template <int KS, int TH, int TW, int CO_T, int KC>
-__global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void conv_mfma2l_kernel(Conv2P p) {
+__global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINWL)) void conv_mfma2l_kernel(Conv2P p) {
   using C = Conv2Cfg<KS, TH, TW, CO_T, KC>;
   static_assert(KC % C::G == 0 && C::MT % C::SEGS == 0, "lean staging shape");
   WSL_DYN_SMEM(smem);
@@ -694,6 +695,7 @@ struct Wgrad2P {
   float* part_dw;  // [nsplit][KK][Co][Ci]
   float* part_db;  // [nsplit][Co]
   int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, co_blocks;
+  int ablate;   // debug (env WSL_WGRAD_ABLATE): 1 skip MFMA, 2 skip staging after the first tile, 8 MFMA without LDS reads
 };
 
 template <int KS, int TH, int TW, int CB, int IB, int WK>
@@ -1051,9 +1053,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2l_kernel(Wgrad2P p) {
   const float* ap = a_t + (cit * 16 + (lane & 15)) * C::PLA + (lane >> 4) + (C::PADL - C::P);
   const bool dbw = want_db && cit == 0;
   for (int item = it0; item < it1; ++item) {
-    commit();
+    if (!(p.ablate & 2) || item == it0) commit();
     __syncthreads();
-    if (item + 1 < it1) issue();   // prefetch the next tile; in flight during the MFMA loop
+    if (item + 1 < it1 && !(p.ablate & 2)) issue();   // prefetch the next tile; in flight during the MFMA loop
     constexpr int RW = TH / WK, NX = TW / 4, NSTEP = RW * NX;
     float avv[2], bvv[2][C::KK];
     auto load = [&](int st, int buf) {   // step st = (row, group of 4 pixels)
@@ -1063,10 +1065,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2l_kernel(Wgrad2P p) {
       for (int t = 0; t < C::KK; ++t) bvv[buf][t] = ap[(r + t / KS) * C::ROWP + x4 * 4 + (t % KS)];
     };
     load(0, 0);
+    if (p.ablate & 1) continue;
 #pragma unroll 2
     for (int st = 0; st < NSTEP; ++st) {   // operands of step st+1 are read before the MFMAs of step st issue
       const int cur = st & 1;
-      if (st + 1 < NSTEP) load(st + 1, cur ^ 1);
+      if (st + 1 < NSTEP && !(p.ablate & 8)) load(st + 1, cur ^ 1);
       if (dbw) accb = WSL_MFMA16(avv[cur], 1.0f, accb);
 #pragma unroll
       for (int t = 0; t < C::KK; ++t) acc[t] = WSL_MFMA16(avv[cur], bvv[cur][t], acc[t]);
@@ -1161,6 +1164,8 @@ int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_
   p.dy = dy, p.dy_bs = dy_bs, p.part_dw = part_dw, p.part_db = part_db;
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
+  static const int ablate = getenv("WSL_WGRAD_ABLATE") ? atoi(getenv("WSL_WGRAD_ABLATE")) : 0;
+  p.ablate = ablate;
 #define WSL_CASE(KS_, TH_, TW_, CB_, IB_, WK_) \
   if (ks == KS_ && th == TH_ && tw == TW_ && cb == CB_ && ib == IB_)  \
     return launch_wgrad2<KS_, TH_, TW_, CB_, IB_, WK_>(p, ci_blocks, stream);
