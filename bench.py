@@ -163,21 +163,25 @@ def main():
                                          "algo_GBps": round(r.bytes / (r.ms * 1e-3) / 1e9, 1)}
         conv = [r for r in rows if r.calls and r.flops > 0]
         if conv:
-            # families 0 and 1 are ONE kernel template (conv_mfma2_kernel: forward and data-gradient mode)
-            kern = {"conv_mfma2_kernel (fwd + data-gradient launches)": [r for r in rows[:2] if r.calls],
-                    "wgrad_mfma2_kernel": [r for r in rows[2:3] if r.calls]}
+            # families 0 and 1 are ONE kernel template (conv_mfma2l_kernel: forward and data-gradient mode; the few
+            # layers outside its shape contract -- first conv, 4-channel classifiers -- run conv_mfma2_kernel)
+            kern = {"conv_mfma2l_kernel (fwd + data-gradient launches)": [r for r in rows[:2] if r.calls],
+                    "wgrad_mfma2l_kernel": [r for r in rows[2:3] if r.calls]}
             name, grp = max(((k, v) for k, v in kern.items() if v), key=lambda kv: sum(r.ms for r in kv[1]))
             ms, fl, calls = sum(r.ms for r in grp), sum(r.flops for r in grp), sum(r.calls for r in grp)
             ach = fl / (ms * 1e-3) / 1e12
-            traffic = None     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
-            try:               # (FETCH_SIZE / WRITE_SIZE, separate runs of this same command -- profiles/r1_pmc_traffic.json)
-                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+            traffic = None     # HBM bytes per launch of that kernel family from the committed rocprofv3 PMC passes
+            try:               # (FETCH_SIZE / WRITE_SIZE, separate runs of this same command -- tools/pmc_traffic.py)
+                with open(os.path.join(ROOT, "profiles", "r1h_pmc_traffic.json")) as fh:
                     tj = json.load(fh)["kernels"]
-                key = "conv_mfma2_kernel" if name.startswith("conv_mfma2") else "wgrad_mfma2_kernel"
-                traffic = {"hbm_bytes_per_launch": tj[key]["hbm_bytes_per_launch"],
+                keys = ("conv_mfma2l_kernel", "conv_mfma2_kernel") if name.startswith("conv") else \
+                       ("wgrad_mfma2l_kernel", "wgrad_mfma2_kernel")
+                nl = sum(tj[k]["launches_sampled"] for k in keys if k in tj)
+                traffic = {"hbm_bytes_per_launch": sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["launches_sampled"]
+                                                       for k in keys if k in tj) / nl,
                            "algorithmic_bytes_per_launch": sum(r.bytes for r in grp) / calls,
-                           "source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
-            except (OSError, KeyError, ValueError):
+                           "source": "profiles/r1h_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+            except (OSError, KeyError, ValueError, ZeroDivisionError):
                 pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

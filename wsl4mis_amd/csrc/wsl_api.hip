@@ -53,7 +53,7 @@ namespace wsl {
 struct ProfRec { int fam; double flops, bytes; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
-static const char* kFamNames[WSL_PROF_FAMILIES] = {"conv_mfma_kernel(fwd)", "conv_mfma_kernel(dgrad)", "wgrad_mfma_kernel",
+static const char* kFamNames[WSL_PROF_FAMILIES] = {"conv_mfma2l_kernel(fwd)", "conv_mfma2l_kernel(dgrad)", "wgrad_mfma2l_kernel",
                                                    "wgrad_reduce_kernel", "gatedcrf_fwd_kernel", "other"};
 void* prof_begin(int fam, double flops, double bytes, void* stream) {
   if (!g_prof_on) return nullptr;

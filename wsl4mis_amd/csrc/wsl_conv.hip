@@ -219,7 +219,10 @@ struct FwdPlan {
 };
 static FwdPlan fwd_plan(int W, int Co) {
   FwdPlan f;
-  if (W >= 64) {
+  static const int wide64 = getenv("WSL_CONV_WIDE64") ? atoi(getenv("WSL_CONV_WIDE64")) : 1;
+  if (W >= 64 && Co >= 64 && wide64) {
+    f.th = 8, f.tw = 32, f.co_t = 64;   // all 64 output channels of a tile in one workgroup: half the staging per MFMA
+  } else if (W >= 64) {
     f.th = 8, f.tw = 64, f.co_t = Co <= 16 ? 16 : 32;
   } else if (W >= 32) {
     f.th = 8, f.tw = 32, f.co_t = Co <= 16 ? 16 : (Co <= 32 ? 32 : 64);
