@@ -410,24 +410,18 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINWL)) void 
       const float es = ina ? p.a.es : p.b.es;
 #pragma unroll
       for (int i = 0; i < C::NLD; ++i) {
-        float4 v = pre[i];
+        wsl_v2f lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
         const int c = c0 + grp + i * C::G;
         if (has_scale) {
           const float2 t = tab[c];
-          v.x = fmaf(v.x, t.x, t.y), v.y = fmaf(v.y, t.x, t.y), v.z = fmaf(v.z, t.x, t.y), v.w = fmaf(v.w, t.x, t.y);
-          v.x = fmaxf(v.x, WSL_LEAKY_SLOPE * v.x), v.y = fmaxf(v.y, WSL_LEAKY_SLOPE * v.y);
-          v.z = fmaxf(v.z, WSL_LEAKY_SLOPE * v.z), v.w = fmaxf(v.w, WSL_LEAKY_SLOPE * v.w);
+          xform_bn_leaky(lo, hi, t.x, t.y);
         }
-        if (has_mask) {   // keep-mask bytes are 0 or 1
-          const uint32_t m = prm[i];
-          v.x *= es * (float)(m & 0xffu), v.y *= es * (float)((m >> 8) & 0xffu);
-          v.z *= es * (float)((m >> 16) & 0xffu), v.w *= es * (float)(m >> 24);
-        }
+        if (has_mask) xform_mask(lo, hi, prm[i], es);   // keep-mask bytes are 0 or 1
         if (has_cm) {
           const float cm = cm_l[c];
-          v.x *= cm, v.y *= cm, v.z *= cm, v.w *= cm;
+          lo = lo * cm, hi = hi * cm;
         }
-        *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = v;
+        *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
       }
     }
 #pragma unroll
@@ -1025,23 +1019,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2l_kernel(Wgrad2P p) {
     if (owner_a) {
 #pragma unroll
       for (int i = 0; i < C::NA; ++i) {
-        float4 v = pra[i];
+        wsl_v2f lo = {pra[i].x, pra[i].y}, hi = {pra[i].z, pra[i].w};
         if (has_scale) {
           const float2 t = tab[ga + i * C::GA];
-          v.x = fmaf(v.x, t.x, t.y), v.y = fmaf(v.y, t.x, t.y), v.z = fmaf(v.z, t.x, t.y), v.w = fmaf(v.w, t.x, t.y);
-          v.x = fmaxf(v.x, WSL_LEAKY_SLOPE * v.x), v.y = fmaxf(v.y, WSL_LEAKY_SLOPE * v.y);
-          v.z = fmaxf(v.z, WSL_LEAKY_SLOPE * v.z), v.w = fmaxf(v.w, WSL_LEAKY_SLOPE * v.w);
+          xform_bn_leaky(lo, hi, t.x, t.y);
         }
-        if (has_mask) {   // keep-mask bytes are 0 or 1
-          const uint32_t m = prm[i];
-          v.x *= es * (float)(m & 0xffu), v.y *= es * (float)((m >> 8) & 0xffu);
-          v.z *= es * (float)((m >> 16) & 0xffu), v.w *= es * (float)(m >> 24);
-        }
-        if (has_cm) v.x *= prc[i], v.y *= prc[i], v.z *= prc[i], v.w *= prc[i];
-        if (!pr_aok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_mask) xform_mask(lo, hi, prm[i], es);   // keep-mask bytes are 0 or 1
+        if (has_cm) lo = lo * prc[i], hi = hi * prc[i];
+        if (!pr_aok) lo = wsl_v2f{0.f, 0.f}, hi = wsl_v2f{0.f, 0.f};
         float* dst = a_t + i * (C::GA * C::PLA) + aloff;
-        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+        *reinterpret_cast<float2*>(dst) = make_float2(lo[0], lo[1]);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(hi[0], hi[1]);
       }
     }
   };

@@ -52,6 +52,21 @@ constexpr int kThreads = 256;  // every kernel in this library uses 4-wave workg
 
 __device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : WSL_LEAKY_SLOPE * z; }
 
+// The loader transform on one float4, written on 2-wide native vectors so the compiler emits packed f32 math
+// (v_pk_fma_f32 / v_pk_mul_f32): BN affine, LeakyReLU as max(z, slope*z) (bit-identical to leaky()), keep mask bytes
+// (0 or 1) and scale as float factors.  `m` is the uchar4 of keep bytes read as one 32-bit word.
+typedef float wsl_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void xform_bn_leaky(wsl_v2f& lo, wsl_v2f& hi, float sc, float sh) {
+  const wsl_v2f sc2 = {sc, sc}, sh2 = {sh, sh};
+  lo = __builtin_elementwise_fma(lo, sc2, sh2), hi = __builtin_elementwise_fma(hi, sc2, sh2);
+  const wsl_v2f l2 = lo * WSL_LEAKY_SLOPE, h2 = hi * WSL_LEAKY_SLOPE;
+  lo = __builtin_elementwise_max(lo, l2), hi = __builtin_elementwise_max(hi, h2);
+}
+__device__ __forceinline__ void xform_mask(wsl_v2f& lo, wsl_v2f& hi, uint32_t m, float es) {
+  const wsl_v2f m01 = {(float)(m & 0xffu), (float)((m >> 8) & 0xffu)}, m23 = {(float)((m >> 16) & 0xffu), (float)(m >> 24)};
+  lo = (lo * es) * m01, hi = (hi * es) * m23;
+}
+
 // Sum over the 64 lanes of a wave; every lane gets the total.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
