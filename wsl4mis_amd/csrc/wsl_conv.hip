@@ -11,6 +11,7 @@
 //   weight-gradient:  M = 16 output channels, N = 16 input channels, K = 4 pixels; nine accumulators (one per
 //       tap) per 16x16 channel pair; split over pixels into partials, second stage order-fixed.
 //       db comes from one extra MFMA against a ones operand.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "wsl_rt.h"
@@ -217,18 +218,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 struct FwdPlan {
   int th, tw, co_t;
 };
-static FwdPlan fwd_plan(int W, int Co) {
+// Tile shape of one layer.  Table from tools/sweep_conv_plans.py on MI355X (batch 64; profiles/r1g_conv_timeline.md):
+// 64-pixel-wide tiles only pay for <= 16 output channels; wider layers take 8x32 pixels x as many channels as one
+// workgroup can hold (halves the staging per MFMA); at 16x16 resolution the channel block shrinks until the launch
+// has >= 2 workgroups per CU (a 128-workgroup launch leaves half the chip idle).
+static FwdPlan fwd_plan(int N, int H, int W, int Co) {
   FwdPlan f;
-  static const int wide64 = getenv("WSL_CONV_WIDE64") ? atoi(getenv("WSL_CONV_WIDE64")) : 1;
-  if (W >= 64 && Co >= 64 && wide64) {
-    f.th = 8, f.tw = 32, f.co_t = 64;   // all 64 output channels of a tile in one workgroup: half the staging per MFMA
-  } else if (W >= 64) {
-    f.th = 8, f.tw = 64, f.co_t = Co <= 16 ? 16 : 32;
-  } else if (W >= 32) {
-    f.th = 8, f.tw = 32, f.co_t = Co <= 16 ? 16 : (Co <= 32 ? 32 : 64);
-  } else {
-    f.th = 16, f.tw = 16, f.co_t = Co <= 16 ? 16 : (Co <= 32 ? 32 : 64);
+  // tuning aid: WSL_CONV_PLAN=th,tw,co_t forces one tile shape wherever it divides the layer (tools/sweep_conv_plans.py)
+  static const char* forced = getenv("WSL_CONV_PLAN");
+  if (forced) {
+    int th = 0, tw = 0, ct = 0;
+    if (sscanf(forced, "%d,%d,%d", &th, &tw, &ct) == 3 && tw > 0 && W % tw == 0 && ct > 0 && Co % ct == 0) {
+      f.th = th, f.tw = tw, f.co_t = ct;
+      return f;
+    }
   }
+  if (Co <= 16) {
+    f.co_t = 16;
+    if (W >= 64) f.th = 8, f.tw = 64; else if (W >= 32) f.th = 8, f.tw = 32; else f.th = 16, f.tw = 16;
+    return f;
+  }
+  if (W >= 32) f.th = 8, f.tw = 32; else f.th = 16, f.tw = 16;
+  const int64_t tiles = (int64_t)N * cdiv(H, f.th) * cdiv(W, f.tw);
+  const int64_t enough = 2 * (int64_t)device_cu_count();
+  f.co_t = Co <= 32 ? 32 : 64;
+  while (f.co_t > 16 && tiles * cdiv(Co, f.co_t) < enough) f.co_t >>= 1;
   return f;
 }
 
@@ -546,7 +560,7 @@ extern "C" int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int k
   (void)Ci;
   (void)ks;
   if (N <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
-  const FwdPlan f = fwd_plan(W, Co);
+  const FwdPlan f = fwd_plan(N, H, W, Co);
   // one partial per tile; the (opt-in) wave-specialised kernel emits one per MFMA wave = four slots per tile
   return (conv3_enabled() ? 4 : 1) * N * cdiv(H, f.th) * cdiv(W, f.tw);
 }
@@ -573,7 +587,7 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
   p.w = w, p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.Co = Co, p.wmode = wmode;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
   p.slots = conv3_enabled() ? 4 : 1;
-  const FwdPlan f = fwd_plan(W, Co);
+  const FwdPlan f = fwd_plan(N, H, W, Co);
   if (wmode >= 2) {
     if (!conv2_eligible(p.in.a, &p.in.b, y, y_bs, W, p.in.Ci)) {
       set_error("conv2d_fwd: packed weights (wmode %d) need W %% 4 == 0 and 16-byte aligned tensors", wmode);
