@@ -47,6 +47,10 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
     (2, 16, 16, 16, 16, 16, 3, True),
     (1, 8, 32, 32, 32, 32, 3, True),
     (1, 8, 64, 16, 0, 16, 3, True),
+    # the narrow-operand weight-gradient kernel: first convolution (1 -> 16) and 4-class classifier (16 -> 4)
+    (2, 16, 64, 1, 0, 16, 3, False),
+    (2, 8, 128, 16, 0, 4, 3, False),
+    (1, 16, 64, 16, 0, 4, 3, 'bn'),
 ]
 
 
@@ -72,6 +76,7 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
     if tr:
         scale = (rng.standard_normal(Ca) * 0.5 + 1).astype(np.float32)
         shift = (rng.standard_normal(Ca) * 0.3).astype(np.float32)
+    if tr is True:
         emask = (rng.random((N, Ca, H, W)) > 0.3).astype(np.uint8)
         es = float(np.float32(1 / 0.7))
         cmask = ((rng.random((N, Ca)) > 0.5) * 2.0).astype(np.float32)

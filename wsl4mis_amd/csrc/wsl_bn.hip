@@ -286,20 +286,21 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const float* dout
   }
 }
 
-// ---- fast variants for power-of-two widths >= 16 and 16-byte aligned planes (every level of the network): four outputs
-// per thread with the column coordinates / weights hoisted out of the row loop and float4 stores (forward); an LDS tile
-// of the output gradient filled with aligned float4 loads (transpose).  Same expressions, same summation order.
-__global__ __launch_bounds__(256) void bilinear_up2_fwd4_kernel(const float* u, float* out, int64_t out_bs, int C, int h,
-                                                                int w, int lc, int rows_per_wg) {
+// ---- fast variants for power-of-two widths 16..128 and 16-byte aligned planes (every level of the network): a fixed
+// output column per thread with its coordinates / weights hoisted out of the row loop (forward); an LDS tile of the
+// output gradient filled with aligned float4 loads (transpose).  Same expressions, same summation order.
+__global__ __launch_bounds__(256) void bilinear_up2_fwdc_kernel(const float* u, float* out, int64_t out_bs, int C, int h,
+                                                                int w, int lw, int rows_per_wg) {
+  // one output column per thread (column coordinates / weights computed once), rows strided over the workgroup:
+  // adjacent lanes read the same or the next source element, a wave writes 256 contiguous bytes
   const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
   const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
   const float* src = u + ((int64_t)n * C + c) * h * w;
   float* dst = out + n * out_bs + (int64_t)c * Ho * Wo;
-  const int col = threadIdx.x & ((1 << lc) - 1), r0 = threadIdx.x >> lc, rstep = kThreads >> lc;
-  int x0[4], x1[4];
-  float lx[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) lerp_coord(col * 4 + k, sx, w, &x0[k], &x1[k], &lx[k]);
+  const int ox = threadIdx.x & (Wo - 1), r0 = threadIdx.x >> lw, rstep = kThreads >> lw;
+  int x0, x1;
+  float lx;
+  lerp_coord(ox, sx, w, &x0, &x1, &lx);
   const int base = blockIdx.x * rows_per_wg;
   const int end = base + rows_per_wg < Ho ? base + rows_per_wg : Ho;
   for (int oy = base + r0; oy < end; oy += rstep) {
@@ -308,14 +309,9 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd4_kernel(const float* u, 
     lerp_coord(oy, sy, h, &y0, &y1, &ly);
     const float* s0 = src + y0 * w;
     const float* s1 = src + y1 * w;
-    float o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float top = (1.f - lx[k]) * s0[x0[k]] + lx[k] * s0[x1[k]];
-      const float bot = (1.f - lx[k]) * s1[x0[k]] + lx[k] * s1[x1[k]];
-      o[k] = (1.f - ly) * top + ly * bot;
-    }
-    *reinterpret_cast<float4*>(dst + (int64_t)oy * Wo + col * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    const float top = (1.f - lx) * s0[x0] + lx * s0[x1];
+    const float bot = (1.f - lx) * s1[x0] + lx * s1[x1];
+    dst[(int64_t)oy * Wo + ox] = (1.f - ly) * top + ly * bot;
   }
 }
 
@@ -382,7 +378,7 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd4_kernel(const float* dou
 }
 
 static inline bool up2_fast_ok(const void* big, int64_t big_bs, int w) {
-  return w >= 16 && (w & (w - 1)) == 0 && (reinterpret_cast<uintptr_t>(big) & 15) == 0 && (big_bs & 3) == 0;
+  return w >= 16 && w <= 128 && (w & (w - 1)) == 0 && (reinterpret_cast<uintptr_t>(big) & 15) == 0 && (big_bs & 3) == 0;
 }
 static inline int ilog2(int v) {
   int l = 0;
@@ -465,12 +461,12 @@ extern "C" int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, 
   WSL_REQUIRE(u && out && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_fwd: bad args");
   WSL_REQUIRE(out_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_fwd: out batch stride too small");
   if (up2_fast_ok(out, out_bs, w)) {
-    const int lc = ilog2(2 * w / 4);                                // float4 columns of an output row
-    int rows = 16384 / (2 * w);                                     // ~16K outputs per workgroup
-    if (rows < (kThreads >> lc)) rows = kThreads >> lc;
-    WSL_LAUNCH(bilinear_up2_fwd4_kernel, dim3(cdiv(2 * h, rows), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C, h, w,
-               lc, rows);
-    return check_launch("bilinear_up2_fwd4_kernel");
+    const int lw = ilog2(2 * w);                                    // output row width = 2^lw <= 256
+    int rows = 8192 / (2 * w);                                      // ~8K outputs per workgroup
+    if (rows < (kThreads >> lw)) rows = kThreads >> lw;
+    WSL_LAUNCH(bilinear_up2_fwdc_kernel, dim3(cdiv(2 * h, rows), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C, h, w,
+               lw, rows);
+    return check_launch("bilinear_up2_fwdc_kernel");
   }
   WSL_LAUNCH(bilinear_up2_fwd_kernel, dim3(cdiv(4 * h * w, kChunk), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C,
              h, w);

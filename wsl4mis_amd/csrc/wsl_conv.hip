@@ -525,6 +525,9 @@ int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
               int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
               int slots, void* stream);
 // wsl_conv3.hip
+int wgrad_small_kind(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks);   // wsl_conv4.hip
+int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
+                       int H, int W, int nsplit, void* stream);
 bool conv3_enabled();
 void conv_set_variant(int v);
 int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
@@ -640,7 +643,11 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   p.part_db = p.part_dw + (size_t)g.nsplit * KK * Co * Ci;
   p.tiles_x = g.tiles_x, p.tiles_y = g.tiles_y, p.items = g.items, p.nsplit = g.nsplit, p.co_blocks = g.co_blocks;
   // a ci-block beyond the first never writes db and a (co,ci) element outside the tensor is never written: no memset
-  if (v2) {
+  static const bool small_on = !(getenv("WSL_WGRAD_SMALL") && atoi(getenv("WSL_WGRAD_SMALL")) == 0);
+  const int small_kind = (v2 && small_on) ? wgrad_small_kind(p.in.a, &p.in.b, H, W, Co, ks) : 0;
+  if (small_kind) {   // first convolution / 4-class classifier: one narrow operand (wsl_conv4.hip)
+    if (int rc = wgrad_small_launch(small_kind, p.in.a, dy, dy_bs, p.part_dw, p.part_db, N, H, W, g.nsplit, stream)) return rc;
+  } else if (v2) {
     if (int rc = wgrad2_launch(p.in.a, &p.in.b, dy, dy_bs, p.part_dw, p.part_db, N, H, W, Co, ks, g.th, g.tw, g.cb, g.ib,
                                g.nsplit, g.items, g.tiles_x, g.tiles_y, g.co_blocks, g.ci_blocks, stream))
       return rc;

@@ -1,0 +1,243 @@
+// Weight gradient of the two layer shapes whose channel counts starve the 16x16 blocking of wgrad_mfma2l_kernel:
+//   * the first convolution  (Ci = 1,  Co = 16):  dw[co][0][tap]  = sum_p dy[co][p] * x[p + tap]
+//   * the 4-class classifier (Ci = 16, Co = 4):   dw[co][ci][tap] = sum_p a[ci][p] * dy[co][p - tap]
+// Both are ONE matrix product per 4 pixels if the 16 rows of the MFMA tile are the 16-channel operand ("A": dy resp. the
+// activations) and the columns enumerate (tap, narrow channel) pairs of the other operand ("B": x resp. dy), read from
+// an LDS halo tile with a per-lane shift: 1 resp. 3 MFMAs per step where the general kernel issues 9 that are 1/16 resp.
+// 1/4 full (profiles/r1f: 261 us per launch for ~0.6 GFLOP).  These launches are HBM-bound (A is a 268 MB tensor).
+// Partials go to the same [split][tap][Co][Ci] workspace, reduced by wgrad_reduce_kernel.
+#include "wsl_rt.h"
+
+namespace wsl {
+
+struct WgSmallP {
+  const float* a;        // 16-channel operand [N,16,H,W]
+  int64_t a_bs;
+  const float* a_scale;  // its BN+LeakyReLU loader transform, or null (raw)
+  const float* a_shift;
+  const float* b;        // narrow operand [N,CBN,H,W], raw
+  int64_t b_bs;
+  float* part_dw;
+  float* part_db;
+  int N, H, W, tiles_x, tiles_y, items, nsplit;
+};
+
+template <int CBN>
+struct WgSmallCfg {
+  static constexpr int TH = 8, TW = 64, ROWP = TW + 8, ROWS = TH + 2, ROWP4 = ROWP / 4, S = TH * TW;
+  static constexpr int PD = S / 4, GD = 256 / PD, ND = 16 / GD;           // A: float4 positions per channel, loads per thread
+  static constexpr int PB = ROWS * ROWP4, NBF4 = CBN * PB, NB = (NBF4 + 255) / 256;   // B float4 of a tile, loads per thread
+  static constexpr int PLA = ((S - 2 + 31) / 32) * 32 + 2;               // == 2 (mod 32): conflict-free A-operand reads
+  static constexpr int PLB = ROWS * ROWP + 4;
+  static constexpr int J = 9 * CBN, NT = (J + 15) / 16, TC = (4 * CBN) / 16;   // TC: tile holding the centre-tap columns
+  static constexpr int A_FLOATS = 16 * PLA, B_FLOATS = CBN * PLB;
+  static constexpr int RED_FLOATS = 4 * 64 * (NT + 1) * 4;
+  static constexpr int MAIN_FLOATS = A_FLOATS + B_FLOATS > RED_FLOATS ? A_FLOATS + B_FLOATS : RED_FLOATS;
+  static constexpr size_t SMEM = sizeof(float) * (MAIN_FLOATS + 32);
+  static_assert(16 % GD == 0 && (4 * CBN) / 16 == (5 * CBN - 1) / 16, "staging shape / centre columns in one tile");
+};
+
+// SGN = +1: B is read at p + tap (first convolution: A = dy, B = x);  -1: at p - tap (classifier: A = activations, B = dy)
+template <int CBN, int SGN>
+__global__ __launch_bounds__(256, 2) void wgrad_small_kernel(WgSmallP p) {
+  using C = WgSmallCfg<CBN>;
+  WSL_DYN_SMEM(smem);
+  float* a_t = reinterpret_cast<float*>(smem);
+  float* b_t = a_t + C::A_FLOATS;
+  float2* tab = reinterpret_cast<float2*>(a_t + C::MAIN_FLOATS);   // [16] {scale, shift}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int H = p.H, W = p.W, HW = H * W;
+  const bool has_scale = p.a_scale != nullptr;
+  if (tid < 16) tab[tid] = has_scale ? make_float2(p.a_scale[tid], p.a_shift[tid]) : make_float2(1.f, 0.f);
+
+  // fixed staging positions
+  const int gd = tid / C::PD, pd = tid - gd * C::PD;
+  const int dty = (pd * 4) / C::TW, dtx = pd * 4 - dty * C::TW;
+  const uint32_t taoff = (uint32_t)(gd * HW + dty * W + dtx);
+  const int aloff = gd * C::PLA + pd * 4;
+  int bch[C::NB], brow[C::NB], bcol[C::NB], bl[C::NB];
+  bool bown[C::NB];
+#pragma unroll
+  for (int i = 0; i < C::NB; ++i) {
+    const int e = tid + i * kThreads;
+    bown[i] = e < C::NBF4;
+    const int ee = bown[i] ? e : 0;
+    bch[i] = ee / C::PB;
+    const int pos = ee - bch[i] * C::PB;
+    brow[i] = pos / C::ROWP4, bcol[i] = (pos - brow[i] * C::ROWP4) * 4;
+    bl[i] = bch[i] * C::PLB + brow[i] * C::ROWP + bcol[i];
+  }
+
+  const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
+  int nx_tx, nx_ty, nx_n;
+  {
+    int q = it0;
+    nx_tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    nx_ty = q % p.tiles_y;
+    nx_n = q / p.tiles_y;
+  }
+  float4 pra[C::ND], prb[C::NB];
+  bool prok[C::NB];
+  auto issue = [&]() __attribute__((always_inline)) {
+    const int n = nx_n, y0 = nx_ty * C::TH, x0 = nx_tx * C::TW;
+    if (++nx_tx == p.tiles_x) {
+      nx_tx = 0;
+      if (++nx_ty == p.tiles_y) nx_ty = 0, ++nx_n;
+    }
+    const float* ab = p.a + n * p.a_bs + y0 * W + x0;
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) pra[i] = *reinterpret_cast<const float4*>(ab + (int64_t)i * C::GD * HW + taoff);
+    const float* bb = p.b + n * p.b_bs;
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) {
+      const int gy = y0 + brow[i] - 1, gx = x0 + bcol[i] - 4;
+      prok[i] = bown[i] && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const uint32_t off = prok[i] ? (uint32_t)(bch[i] * HW + gy * W + gx) : 0u;
+      prb[i] = *reinterpret_cast<const float4*>(bb + off);
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) {
+      wsl_v2f lo = {pra[i].x, pra[i].y}, hi = {pra[i].z, pra[i].w};
+      if (has_scale) {
+        const float2 t = tab[gd + i * C::GD];
+        xform_bn_leaky(lo, hi, t.x, t.y);
+      }
+      float* dst = a_t + i * (C::GD * C::PLA) + aloff;   // plane stride == 2 (mod 32): 8-byte aligned
+      *reinterpret_cast<float2*>(dst) = make_float2(lo[0], lo[1]);
+      *reinterpret_cast<float2*>(dst + 2) = make_float2(hi[0], hi[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i)
+      if (bown[i])
+        *reinterpret_cast<float4*>(b_t + bl[i]) = prok[i] ? prb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  // operand addresses of this lane: A row m = lane & 15, pixel k = lane >> 4; B column jj = t * 16 + (lane & 15)
+  const float* ap = a_t + (lane & 15) * C::PLA + (lane >> 4);
+  int bbase[C::NT];
+#pragma unroll
+  for (int t = 0; t < C::NT; ++t) {
+    const int jj = t * 16 + (lane & 15);
+    const int tap = jj < C::J ? jj / CBN : 4, cb = jj < C::J ? jj % CBN : 0;   // columns past J compute unused garbage
+    const int ky = tap / 3, kx = tap - ky * 3;
+    bbase[t] = cb * C::PLB + (1 + SGN * (ky - 1)) * C::ROWP + 4 + SGN * (kx - 1) + (lane >> 4);
+  }
+  v4f acc[C::NT];
+  v4f accb = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < C::NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  if (it0 < it1) issue();
+  __syncthreads();   // table visible
+  for (int item = it0; item < it1; ++item) {
+    commit();
+    __syncthreads();
+    if (item + 1 < it1) issue();   // next tile in flight during the MFMA loop
+    constexpr int RW = C::TH / 4, NX = C::TW / 4;
+#pragma unroll 4
+    for (int st = 0; st < RW * NX; ++st) {
+      const int r = wave * RW + st / NX, x4 = st % NX;
+      const float av = ap[r * C::TW + x4 * 4];
+      float bv[C::NT];
+#pragma unroll
+      for (int t = 0; t < C::NT; ++t) bv[t] = b_t[bbase[t] + r * C::ROWP + x4 * 4];
+#pragma unroll
+      for (int t = 0; t < C::NT; ++t) acc[t] = WSL_MFMA16(av, bv[t], acc[t]);
+      accb = SGN > 0 ? WSL_MFMA16(av, 1.0f, accb) : WSL_MFMA16(1.0f, bv[C::TC], accb);
+    }
+    __syncthreads();
+  }
+
+  // ---- merge the four row groups in fixed order, store this split's partials
+  float* red = reinterpret_cast<float*>(smem);
+  constexpr int PER = (C::NT + 1) * 4;
+  float* mine = red + (wave * 64 + lane) * PER;
+#pragma unroll
+  for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[t * 4 + r] = acc[t][r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mine[C::NT * 4 + r] = accb[r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t <= C::NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sum = 0.f;
+        for (int k = 0; k < 4; ++k) sum += red[(k * 64 + lane) * PER + t * 4 + r];
+        if (t < C::NT) acc[t][r] = sum; else accb[r] = sum;
+      }
+    constexpr int Co = SGN > 0 ? 16 : CBN, Ci = SGN > 0 ? CBN : 16;
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) {
+      const int jj = t * 16 + (lane & 15);
+      if (jj < C::J) {
+        const int tap = jj / CBN, cb = jj % CBN;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (lane >> 4) * 4 + r;
+          const int co = SGN > 0 ? m : cb, ci = SGN > 0 ? cb : m;
+          p.part_dw[(((int64_t)split * 9 + tap) * Co + co) * Ci + ci] = acc[t][r];
+        }
+      }
+    }
+    if (SGN > 0) {          // db[co = m]: row sums of A, identical in every column
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.part_db[(int64_t)split * 16 + (lane >> 4) * 4 + r] = accb[r];
+      }
+    } else {                // db[co = cb]: column sums of the centre-tap columns, identical in every row
+      const int jj = C::TC * 16 + lane;
+      if (lane < 16 && jj >= 4 * CBN && jj < 5 * CBN) p.part_db[(int64_t)split * CBN + (jj - 4 * CBN)] = accb[0];
+    }
+  }
+}
+
+template <int CBN, int SGN>
+static int launch_wgrad_small(WgSmallP& p, void* stream) {
+  using C = WgSmallCfg<CBN>;
+  auto kern = wgrad_small_kernel<CBN, SGN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(2, 2.0 * px * 16 * CBN * 9, 4.0 * px * (16 + CBN), stream);
+  WSL_LAUNCH(kern, dim3(p.nsplit), dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("wgrad_small_kernel");
+}
+
+// Shapes this file takes (3x3, full 8x64 tiles, aligned planes); the caller falls back to the general kernels otherwise.
+//   kind 1: Ci = 1,  Co = 16, raw input           kind 2: Ci = 16, Co = 4, input with at most the BN+LeakyReLU transform
+int wgrad_small_kind(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks) {
+  if (ks != 3 || (H % 8) || (W % 64) || (b && b->C > 0) || a.emask || a.cmask) return 0;
+  if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.bs & 3)) return 0;
+  if (a.C == 1 && Co == 16 && !a.scale) return 1;
+  if (a.C == 16 && Co == 4) return 2;
+  return 0;
+}
+
+int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
+                       int H, int W, int nsplit, void* stream) {
+  WgSmallP p;
+  p.part_dw = part_dw, p.part_db = part_db;
+  p.N = N, p.H = H, p.W = W, p.tiles_x = W / 64, p.tiles_y = H / 8;
+  p.items = N * p.tiles_x * p.tiles_y, p.nsplit = nsplit;
+  if (kind == 1) {
+    p.a = dy, p.a_bs = dy_bs, p.a_scale = nullptr, p.a_shift = nullptr;
+    p.b = a.x, p.b_bs = a.bs;
+    return launch_wgrad_small<1, 1>(p, stream);
+  }
+  p.a = a.x, p.a_bs = a.bs, p.a_scale = a.scale, p.a_shift = a.shift;
+  p.b = dy, p.b_bs = dy_bs;
+  return launch_wgrad_small<4, -1>(p, stream);
+}
+
+}  // namespace wsl
