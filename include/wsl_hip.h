@@ -85,6 +85,11 @@ int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t
 /* Debug / experiments: which packed-path kernel wsl_conv2d_fwd(wmode 2|3) launches: 2 = lock-step workgroups with a
  * register prefetch (default, fastest measured), 3 = wave-specialised persistent workgroups (wsl_conv3.hip). */
 int wsl_debug_conv_variant(int v);
+/* unet_cct runs its auxiliary decoder (forward and backward) on a library-owned side stream, forked from / joined to the
+ * caller's stream with events, so the two independent decoders fill each other's launch gaps and workgroup tails
+ * (+5 % step rate).  0 serialises everything on the caller's stream (per-launch timings then do not overlap: what
+ * bench.py's roofline segment and profiles/ use); 1 restores the default.  Env WSL_NET_CONCURRENT=0 does the same. */
+int wsl_debug_net_concurrent(int on);
 
 /* dw[Co][Ci][ks][ks] = sum_{n,y,x} dy[n,co,y,x] * in[n,ci,y+ky-p,x+kx-p];  db[Co] = sum dy  (db may be NULL).
  * Split over pixels into partials in `ws`, then an order-fixed second stage. */

@@ -1,6 +1,7 @@
 // Error reporting / version entry points of libwslhip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -41,6 +42,45 @@ int device_cu_count() {
   return cus;
 #endif
 }
+
+#ifndef WSL_HOST_EMUL
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+static int g_conc = -1;   // -1: not decided yet (environment), 0 off, 1 on
+void set_concurrent(int on) { g_conc = on ? 1 : 0; }
+void* side_stream() {
+  if (g_conc < 0) g_conc = (getenv("WSL_NET_CONCURRENT") && atoi(getenv("WSL_NET_CONCURRENT")) == 0) ? 0 : 1;
+  if (!g_conc) return nullptr;
+  if (!g_side) {
+    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
+      g_side = nullptr;
+      return nullptr;
+    }
+  }
+  return g_side;
+}
+int stream_fork(void* main, void* side) {
+  if (hipEventRecord(g_ev_fork, (hipStream_t)main) != hipSuccess || hipStreamWaitEvent((hipStream_t)side, g_ev_fork, 0) != hipSuccess) {
+    set_error("stream_fork: HIP error");
+    return WSL_EHIP;
+  }
+  return WSL_OK;
+}
+int stream_join(void* main, void* side) {
+  if (hipEventRecord(g_ev_join, (hipStream_t)side) != hipSuccess || hipStreamWaitEvent((hipStream_t)main, g_ev_join, 0) != hipSuccess) {
+    set_error("stream_join: HIP error");
+    return WSL_EHIP;
+  }
+  return WSL_OK;
+}
+#else
+void set_concurrent(int) {}
+void* side_stream() { return nullptr; }
+int stream_fork(void*, void*) { return WSL_OK; }
+int stream_join(void*, void*) { return WSL_OK; }
+#endif
 
 }  // namespace wsl
 
@@ -107,6 +147,11 @@ extern "C" int wsl_prof_report(WslProfRow* rows, int max_rows) {
   }
 #endif
   return WSL_PROF_FAMILIES;
+}
+
+extern "C" int wsl_debug_net_concurrent(int on) {
+  wsl::set_concurrent(on);
+  return WSL_OK;
 }
 
 extern "C" int wsl_version(void) { return 100; }

@@ -32,7 +32,9 @@ struct Plan {
   BlkWs wenc[5];
   size_t pooled[5];
   struct DecWs { size_t u[4], up[4], dcat[4], glow4; BlkWs blk[4]; } wdec[2];
-  size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws, packf, packd;
+  // scratch reused from layer to layer; a second set lets the two decoders of unet_cct run on two streams
+  struct Scratch { size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws; } scr[2];
+  size_t packf, packd;
   size_t wg_bytes, bn_bytes, total_floats;
 };
 
@@ -125,10 +127,14 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
     if (wb > P.wg_bytes) P.wg_bytes = wb;
   }
   const size_t big = N * kFt[0] * P.H[0] * P.W[0];  // largest activation (level 0; every deeper level is <= half)
-  P.tmp_g = B.take(big), P.tmp_g1 = B.take(big), P.tmp_dy = B.take(big);
-  P.tmp_du = B.take(big / 4), P.tmp_gpool = B.take(big / 4);
-  P.stat_part = B.take(max_stat), P.stat_cnt = B.take(max_cnt);
-  P.wg_ws = B.take((P.wg_bytes + 3) / 4), P.bn_ws = B.take((P.bn_bytes + 3) / 4);
+  for (int k = 0; k < d->n_dec; ++k) {
+    Plan::Scratch& S = P.scr[k];
+    S.tmp_g = B.take(big), S.tmp_g1 = B.take(big), S.tmp_dy = B.take(big);
+    S.tmp_du = B.take(big / 4), S.tmp_gpool = B.take(big / 4);
+    S.stat_part = B.take(max_stat), S.stat_cnt = B.take(max_cnt);
+    S.wg_ws = B.take((P.wg_bytes + 3) / 4), S.bn_ws = B.take((P.bn_bytes + 3) / 4);
+  }
+  if (d->n_dec == 1) P.scr[1] = P.scr[0];
   P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);  // packed [tap][ci][co] weight images (fwd / data-gradient)
   P.total_floats = B.off;
   return WSL_OK;
@@ -144,6 +150,8 @@ struct Ctx {
   float* ws;
   void* stream;
   int training;
+  int si = 0;   // scratch set
+  const Plan::Scratch& S() const { return P.scr[si]; }
 };
 
 static WslSrc raw_src(const float* x, int C, int64_t bs) {
@@ -194,8 +202,8 @@ static int conv_bn_fwd(const Ctx& c, const ConvRef& cv, const BnRef& bn, const W
                        size_t st, int H, int W) {
   const Plan& P = c.P;
   const int N = P.d.N, C = cv.Co;
-  float* stp = c.training ? c.ws + P.stat_part : nullptr;
-  float* stc = c.training ? c.ws + P.stat_cnt : nullptr;
+  float* stp = c.training ? c.ws + c.S().stat_part : nullptr;
+  float* stc = c.training ? c.ws + c.S().stat_cnt : nullptr;
   WSL_TRY(conv_any(c, cv, 0, a, b, c.params + cv.b, c.ws + y, (int64_t)C * H * W, H, W, stp, stc));
   float* s = c.ws + st;
   if (c.training) {
@@ -223,22 +231,22 @@ static int block_bwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslS
   const Plan& P = c.P;
   const int N = P.d.N, H = P.H[l], W = P.W[l], C = k.c1.Co;
   const int64_t CHW = (int64_t)C * H * W;
-  float* dy = c.ws + P.tmp_dy;
-  float* g1 = c.ws + P.tmp_g1;
+  float* dy = c.ws + c.S().tmp_dy;
+  float* g1 = c.ws + c.S().tmp_g1;
   const float* s1 = c.ws + w.st1;
   const float* s2 = c.ws + w.st2;
   // BN2 + LeakyReLU (no dropout after the second activation)
   WSL_TRY(wsl_bnact_bwd(g, g_bs, c.ws + w.y2, s2, s2 + C, c.params + k.b2.gamma, c.params + k.b2.beta, nullptr, 1.f, dy,
-                        c.grads + k.b2.gamma, c.grads + k.b2.beta, N, C, H, W, c.ws + P.bn_ws, P.bn_bytes, c.stream));
+                        c.grads + k.b2.gamma, c.grads + k.b2.beta, N, C, H, W, c.ws + c.S().bn_ws, P.bn_bytes, c.stream));
   const WslSrc mid = act_src(c, w.y1, w.st1, C, H * W, emask, es, nullptr);
-  WSL_TRY(wsl_conv2d_wgrad(&mid, nullptr, dy, CHW, c.grads + k.c2.w, c.grads + k.c2.b, N, H, W, C, 3, c.ws + P.wg_ws,
+  WSL_TRY(wsl_conv2d_wgrad(&mid, nullptr, dy, CHW, c.grads + k.c2.w, c.grads + k.c2.b, N, H, W, C, 3, c.ws + c.S().wg_ws,
                            P.wg_bytes, c.stream));
   const WslSrc dys = raw_src(dy, C, CHW);
   WSL_TRY(conv_any(c, k.c2, 1, &dys, nullptr, nullptr, g1, CHW, H, W, nullptr, nullptr));
   // BN1 + LeakyReLU + Dropout(p)
   WSL_TRY(wsl_bnact_bwd(g1, CHW, c.ws + w.y1, s1, s1 + C, c.params + k.b1.gamma, c.params + k.b1.beta, emask, es, dy,
-                        c.grads + k.b1.gamma, c.grads + k.b1.beta, N, C, H, W, c.ws + P.bn_ws, P.bn_bytes, c.stream));
-  WSL_TRY(wsl_conv2d_wgrad(a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, N, H, W, C, 3, c.ws + P.wg_ws, P.wg_bytes,
+                        c.grads + k.b1.gamma, c.grads + k.b1.beta, N, C, H, W, c.ws + c.S().bn_ws, P.bn_bytes, c.stream));
+  WSL_TRY(wsl_conv2d_wgrad(a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, N, H, W, C, 3, c.ws + c.S().wg_ws, P.wg_bytes,
                            c.stream));
   if (dgrad_out) {
     const WslSrc dys1 = raw_src(dy, C, CHW);
@@ -276,11 +284,11 @@ static int decoder_fwd(const Ctx& c, int k, const float* const* cmasks, float* l
 static int decoder_bwd(const Ctx& c, int k, const float* const* cmasks, const float* dlogits) {
   const Plan& P = c.P;
   const int N = P.d.N, H0 = P.H[0], W0 = P.W[0];
-  float* g = c.ws + P.tmp_g;
+  float* g = c.ws + c.S().tmp_g;
   const ConvRef& oc = P.dec[k].out;
   const WslSrc last = act_src(c, P.wdec[k].blk[3].y2, P.wdec[k].blk[3].st2, kFt[0], H0 * W0, nullptr, 1.f, nullptr);
   WSL_TRY(wsl_conv2d_wgrad(&last, nullptr, dlogits, (int64_t)oc.Co * H0 * W0, c.grads + oc.w, c.grads + oc.b, N, H0, W0,
-                           oc.Co, 3, c.ws + P.wg_ws, P.wg_bytes, c.stream));
+                           oc.Co, 3, c.ws + c.S().wg_ws, P.wg_bytes, c.stream));
   const WslSrc dl = raw_src(dlogits, oc.Co, (int64_t)oc.Co * H0 * W0);
   WSL_TRY(conv_any(c, oc, 1, &dl, nullptr, nullptr, g, (int64_t)kFt[0] * H0 * W0, H0, W0, nullptr, nullptr));
   for (int i = 3; i >= 0; --i) {
@@ -291,13 +299,13 @@ static int decoder_bwd(const Ctx& c, int k, const float* const* cmasks, const fl
     float* dcat = c.ws + P.wdec[k].dcat[i];
     WSL_TRY(block_bwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f, g, (int64_t)c2 * H * W, dcat));
     // d(up) = dcat[:, c2:]  ->  d(u)  ->  conv1x1 backward
-    float* du = c.ws + P.tmp_du;
+    float* du = c.ws + c.S().tmp_du;
     WSL_TRY(wsl_bilinear_up2_bwd(dcat + (int64_t)c2 * H * W, (int64_t)2 * c2 * H * W, du, N, c2, h, w, c.stream));
     const WslSrc low = i == 0 ? feat_src(c, 4, cmasks ? cmasks[4] : nullptr)
                               : act_src(c, P.wdec[k].blk[i - 1].y2, P.wdec[k].blk[i - 1].st2, c1, h * w, nullptr, 1.f, nullptr);
     const ConvRef& cv = P.dec[k].c1x1[i];
     WSL_TRY(wsl_conv2d_wgrad(&low, nullptr, du, (int64_t)c2 * h * w, c.grads + cv.w, c.grads + cv.b, N, h, w, c2, 1,
-                             c.ws + P.wg_ws, P.wg_bytes, c.stream));
+                             c.ws + c.S().wg_ws, P.wg_bytes, c.stream));
     const WslSrc dus = raw_src(du, c2, (int64_t)c2 * h * w);
     float* glow = i == 0 ? c.ws + P.wdec[k].glow4 : g;
     WSL_TRY(conv_any(c, cv, 1, &dus, nullptr, nullptr, glow, (int64_t)c1 * h * w, h, w, nullptr, nullptr));
@@ -309,8 +317,8 @@ static int encoder_bwd(const Ctx& c, const float* x, const uint8_t* const* emask
   const Plan& P = c.P;
   const int N = P.d.N;
   const bool dual = P.d.n_dec == 2;
-  float* g = c.ws + P.tmp_g;
-  float* gpool = c.ws + P.tmp_gpool;
+  float* g = c.ws + c.S().tmp_g;
+  float* gpool = c.ws + c.S().tmp_gpool;
   for (int l = 4; l >= 0; --l) {
     const int C = kFt[l], H = P.H[l], W = P.W[l];
     const WslSrc f = feat_src(c, l, nullptr);
@@ -445,6 +453,17 @@ extern "C" int wsl_net_forward(const WslNetDesc* d, const float* params, float* 
     }
     WSL_TRY(block_fwd(c, P.enc[l], P.wenc[l], &in, nullptr, l, training ? emasks[l] : nullptr, 1.f / (1.f - kDrop[l])));
   }
+  // the two decoders only share read-only inputs: the auxiliary one runs on the library's side stream with its own
+  // scratch set and is joined before returning (fills the other's launch gaps and workgroup tails)
+  void* side = d->n_dec == 2 ? side_stream() : nullptr;
+  if (side) {
+    Ctx c2 = c;
+    c2.stream = side, c2.si = 1;
+    WSL_TRY(stream_fork(stream, side));
+    WSL_TRY(decoder_fwd(c, 0, nullptr, logits_main));
+    WSL_TRY(decoder_fwd(c2, 1, cmasks, logits_aux));
+    return stream_join(stream, side);
+  }
   WSL_TRY(decoder_fwd(c, 0, nullptr, logits_main));
   if (d->n_dec == 2) WSL_TRY(decoder_fwd(c, 1, cmasks, logits_aux));
   return WSL_OK;
@@ -464,8 +483,18 @@ extern "C" int wsl_net_backward(const WslNetDesc* d, const float* params, const 
   }
   Ctx c{P, params, nullptr, nullptr, grads, static_cast<float*>(ws), stream, 1};
   if (phase == 0 || phase == 1) {
-    WSL_TRY(decoder_bwd(c, 0, nullptr, dlogits_main));
-    if (d->n_dec == 2) WSL_TRY(decoder_bwd(c, 1, cmasks, dlogits_aux));
+    void* side = d->n_dec == 2 ? side_stream() : nullptr;
+    if (side) {
+      Ctx c2 = c;
+      c2.stream = side, c2.si = 1;
+      WSL_TRY(stream_fork(stream, side));
+      WSL_TRY(decoder_bwd(c, 0, nullptr, dlogits_main));
+      WSL_TRY(decoder_bwd(c2, 1, cmasks, dlogits_aux));
+      WSL_TRY(stream_join(stream, side));
+    } else {
+      WSL_TRY(decoder_bwd(c, 0, nullptr, dlogits_main));
+      if (d->n_dec == 2) WSL_TRY(decoder_bwd(c, 1, cmasks, dlogits_aux));
+    }
   }
   if (phase == 0 || phase == 2) WSL_TRY(encoder_bwd(c, x, emasks, cmasks));
   return WSL_OK;

@@ -38,6 +38,13 @@ void* prof_begin(int fam, double flops, double bytes, void* stream);
 void prof_end(void* tok, void* stream);
 int check_launch(const char* what);
 int device_cu_count();   // compute units of the current device (cached)
+// Library-owned side stream for work that is independent of the caller's stream for a while (the second decoder of
+// unet_cct).  fork: side waits for everything enqueued on `main` so far; join: `main` waits for the side stream.
+// Both are event waits enqueued on the streams -- the host never blocks.  Returns null when disabled / emulated.
+void* side_stream();
+void set_concurrent(int on);
+int stream_fork(void* main, void* side);
+int stream_join(void* main, void* side);
 
 #define WSL_REQUIRE(cond, ...)     \
   do {                             \
