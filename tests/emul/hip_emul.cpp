@@ -1,11 +1,15 @@
 // TEST INFRASTRUCTURE ONLY -- see hip_emul.h.
 #include "hip_emul.h"
 
-dim3 threadIdx, blockIdx, blockDim, gridDim;
+#include <stdlib.h>
+
+#include <thread>
+
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace wsl_emu {
 
-static State g_state;
+static thread_local State g_state;   // workgroups of one launch are spread over host threads
 State& st() { return g_state; }
 
 // Minimal x86-64 SysV context switch: callee-saved GPRs + stack pointer.
@@ -33,9 +37,10 @@ wsl_emu_switch:
 )");
 
 static const size_t kStack = 96 * 1024;
-static std::vector<unsigned char> g_dyn(192 * 1024 + 64);
+static thread_local std::vector<unsigned char> g_dyn;
 
 unsigned char* dyn_smem() {
+  if (g_dyn.empty()) g_dyn.resize(192 * 1024 + 64);
   uintptr_t p = (uintptr_t)g_dyn.data();
   return (unsigned char*)((p + 63) & ~(uintptr_t)63);
 }
@@ -124,20 +129,44 @@ static void run_block(const std::function<void()>& body) {
   }
 }
 
+static int host_threads() {
+  static int n = 0;
+  if (n == 0) {
+    const char* e = getenv("WSL_EMU_THREADS");
+    n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (n > 16) n = 16;
+  }
+  return n;
+}
+
+// Workgroups are independent (the kernels use no inter-workgroup atomics or ordering), so a launch's blocks are dealt
+// round-robin to a few host threads; inside a block the lock-step fiber schedule is unchanged.
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
   if (smem > 160 * 1024) {
     fprintf(stderr, "wsl_emu: %zu bytes of dynamic LDS requested (> 160 KiB)\n", smem);
     abort();
   }
-  gridDim = grid;
-  blockDim = block;
-  g_state.nthreads = block.x * block.y * block.z;
-  for (unsigned z = 0; z < grid.z; ++z)
-    for (unsigned y = 0; y < grid.y; ++y)
-      for (unsigned x = 0; x < grid.x; ++x) {
-        blockIdx = dim3(x, y, z);
-        run_block(body);
-      }
+  const unsigned long total = (unsigned long)grid.x * grid.y * grid.z;
+  int nt = host_threads();
+  if ((unsigned long)nt > total) nt = (int)total;
+  auto worker = [&](int w, int stride) {
+    gridDim = grid;
+    blockDim = block;
+    g_state.nthreads = block.x * block.y * block.z;
+    for (unsigned long b = w; b < total; b += stride) {
+      blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((unsigned long)grid.x * grid.y)));
+      run_block(body);
+    }
+  };
+  if (nt <= 1) {
+    worker(0, 1);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int w = 1; w < nt; ++w) pool.emplace_back(worker, w, nt);
+  worker(0, nt);
+  for (auto& t : pool) t.join();
 }
 
 }  // namespace wsl_emu

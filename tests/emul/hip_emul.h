@@ -25,7 +25,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local   /* one workgroup at a time per host thread */
 #ifndef __restrict__
 #define __restrict__ __restrict
 #endif
@@ -76,7 +76,7 @@ void wave_sync();
 unsigned char* dyn_smem();
 }  // namespace wsl_emu
 
-extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 static inline void __syncthreads() {
   auto& s = wsl_emu::st();

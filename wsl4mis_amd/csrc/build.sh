@@ -42,6 +42,6 @@ if [ "${1:-}" = "emul" ]; then
   "$CXX" -std=c++17 -O2 -g -fPIC -c "$em/hip_emul.cpp" -o "$em/build/hip_emul.o" &
   pids+=($!)
   for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-  "$CXX" -shared -fPIC "${eobjs[@]}" "$em/build/hip_emul.o" -o "$em/libwslhip_emul.so"
+  "$CXX" -shared -fPIC -pthread "${eobjs[@]}" "$em/build/hip_emul.o" -o "$em/libwslhip_emul.so"
   echo "built $em/libwslhip_emul.so"
 fi
