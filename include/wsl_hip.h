@@ -71,7 +71,8 @@ typedef struct WslSrc {
  * wmode 0: w is [Co][Ci][ks][ks] (forward).  wmode 1: data-gradient mode, w is the FORWARD weight
  * [Ci][Co][ks][ks] and the kernel uses w[ci][co][ks-1-ky][ks-1-kx] (what autograd's conv backward computes).
  * If stat_part != NULL the epilogue also emits per-block (sum, M2) of y per channel for BatchNorm
- * (layout [nblk][Co][2], nblk = wsl_conv2d_stat_blocks(); stat_cnt [nblk] = valid pixels per block). */
+ * (layout [Co][nblk][2] -- channel-major, so the finalize kernel's per-channel scan is contiguous; nblk =
+ * wsl_conv2d_stat_blocks(); stat_cnt [nblk] = valid pixels per block). */
 int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y, int64_t y_bs,
                    int N, int H, int W, int Co, int ks, int wmode, float* stat_part, float* stat_cnt, void* stream);
 int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int ks);

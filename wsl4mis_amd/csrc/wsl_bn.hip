@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, con
   for (int b = threadIdx.x; b < nblk; b += kThreads) {
     if (cnt[b] > 0.f) {   // empty slots (count 0) carry no data
       n += cnt[b];
-      s += part[((int64_t)b * C + c) * 2];
+      s += part[((int64_t)c * nblk + b) * 2];
     }
   }
   n = block_sum_d(n, red);
@@ -41,8 +41,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, con
   for (int b = threadIdx.x; b < nblk; b += kThreads) {
     const double nb = cnt[b];
     if (nb > 0) {
-      const double d = part[((int64_t)b * C + c) * 2] / nb - mean;
-      m2 += part[((int64_t)b * C + c) * 2 + 1] + nb * d * d;
+      const double d = part[((int64_t)c * nblk + b) * 2] / nb - mean;
+      m2 += part[((int64_t)c * nblk + b) * 2 + 1] + nb * d * d;
     }
   }
   m2 = block_sum_d(m2, red);

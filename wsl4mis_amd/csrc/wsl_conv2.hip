@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
       for (int j = 0; j < C::NT; ++j) {
         const int col = j * 16 + lane, co = co0 + col;
         if (co < p.Co) {
-          float* dst = p.stat_part + ((int64_t)tile_id * p.slots * p.Co + co) * 2;   // slot 0 of this tile's slots
+          const int64_t nsl = (int64_t)gridDim.x * p.slots;                                 // [Co][slots][2]
+          float* dst = p.stat_part + ((int64_t)co * nsl + (int64_t)tile_id * p.slots) * 2;   // slot 0 of this tile's slots
           dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
           dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
         }
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINWL)) void 
 #pragma unroll
       for (int j = 0; j < C::NT; ++j) {
         const int col = j * 16 + lane, co = co0 + col;
-        float* dst = p.stat_part + ((int64_t)tile_id * p.slots * Co + co) * 2;   // slot 0 of this tile's slots
+        float* dst = p.stat_part + ((int64_t)co * ((int64_t)nb * p.slots) + (int64_t)tile_id * p.slots) * 2;   // [Co][slots][2]
         dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
         dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
       }

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma3_kernel(Conv3P p) {
           q += __shfl_xor(q, 16);
           q += __shfl_xor(q, 32);
           if (lane < 16 && co < p.Co) {
-            float* dst = p.stat_part + (((int64_t)tile * 4 + wave) * p.Co + co) * 2;
+            float* dst = p.stat_part + ((int64_t)co * (4 * T) + tile * 4 + wave) * 2;   // [Co][slots][2]
             dst[0] = sum, dst[1] = q;
           }
           // the count is the same for every channel column of a wave; channel 0 of co-tile 0 always exists
