@@ -232,6 +232,21 @@ def test_engine_loss_curve_start(mode):
             assert rel_err(sd[k].cpu().numpy().ravel()[:256], g[f"final.{k}"]) < 5e-2, k
 
 
+def test_two_stream_decoders_are_bit_identical_to_one_stream(mode):
+    """unet_cct runs its auxiliary decoder on a side stream (wsl_debug_net_concurrent): same bits either way"""
+    if mode != "hip":
+        pytest.skip("streams only exist on the device")
+    from wsl4mis_amd import _lib
+    outs = []
+    for conc in (1, 0, 1):
+        _lib.lib().wsl_debug_net_concurrent(conc)
+        got, _, eng = run_curve(3)
+        outs.append((got, eng.model.flat_params().clone(), eng.model.flat_grads().clone()))
+    _lib.lib().wsl_debug_net_concurrent(1)
+    for got, prm, grd in outs[1:]:
+        assert np.array_equal(got, outs[0][0]) and torch.equal(prm, outs[0][1]) and torch.equal(grd, outs[0][2])
+
+
 def test_mean_teacher_step_against_oracle(mode):
     """SURVEY 8d config 4 (student unet + EMA teacher; pCE + TV + consistency): one engine step vs the oracle's
     composition of the pinned pieces -- losses, student parameters after SGD, teacher parameters after the EMA."""
