@@ -154,6 +154,19 @@ static inline wsl_v4f wsl_emu_mfma16(float a, float b, wsl_v4f c) {
   }
   return c;
 }
+// v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products; layout probed on the device by tools/probe_mfma4.py):
+// block = l >> 2;  D[l][r] = A[4 * block + r] * B[l] + C[l][r]   (row r of the block comes from lane 4*block + r).
+static inline wsl_v4f wsl_emu_mfma4(float a, float b, wsl_v4f c) {
+  auto& w = wsl_emu::wave();
+  auto& f = wsl_emu::st().fibers[wsl_emu::st().cur];
+  int buf = f.seq & 1;
+  f.seq++;
+  int l = wsl_emu::lane();
+  w.xa[buf][l] = wsl_emu_bits(a);
+  wsl_emu::wave_sync();
+  for (int r = 0; r < 4; ++r) c[r] = fmaf(wsl_emu_unbits<float>(w.xa[buf][(l & ~3) + r]), b, c[r]);
+  return c;
+}
 // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col=l&31,row=(r&3)+8*(r>>2)+4*(l>>5).
 static inline wsl_v16f wsl_emu_mfma32(float a, float b, wsl_v16f c) {
   auto& w = wsl_emu::wave();

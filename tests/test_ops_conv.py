@@ -51,6 +51,7 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
     (2, 16, 64, 1, 0, 16, 3, False),
     (2, 8, 128, 16, 0, 4, 3, False),
     (1, 16, 64, 16, 0, 4, 3, 'bn'),
+    (3, 24, 64, 16, 0, 4, 3, 'bn'),
 ]
 
 
@@ -110,6 +111,12 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
                 be.ptr(part2), be.ptr(cnt2), be.stream)
         assert rel_err(be.np(y2), y_ref.detach().numpy()) < TOL
         assert float(be.np(cnt2).sum()) == N * H * W     # per-wave partials: the counts tile the tensor exactly
+        # without statistics (how the network calls a layer that no BatchNorm follows): 16 -> 4 classifiers with full
+        # 8x64 tiles take the 4x4x1-MFMA kernel of wsl_conv4.hip
+        y3 = be.zeros((N, Co, H, W))
+        be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), be.ptr(d["bias"]), be.ptr(y3), Co * H * W, N, H, W, Co, ks, 2,
+                None, None, be.stream)
+        assert rel_err(be.np(y3), y_ref.detach().numpy()) < TOL
     # BatchNorm statistics from the epilogue partials
     gamma, beta = be.arr(np.linspace(0.5, 1.5, Co, dtype=np.float32)), be.arr(np.linspace(-0.2, 0.2, Co, dtype=np.float32))
     rm, rv = be.arr(np.full(Co, 0.1, np.float32)), be.arr(np.full(Co, 0.9, np.float32))

@@ -529,6 +529,10 @@ int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
 int wgrad_small_kind(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks);   // wsl_conv4.hip
 int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                        int H, int W, int nsplit, void* stream);
+bool conv_cls_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_bs, int H, int W, int Co, int ks,
+                       const float* stat_part);                                              // wsl_conv4.hip
+int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H, int W,
+                    void* stream);
 bool conv3_enabled();
 void conv_set_variant(int v);
 int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
@@ -597,6 +601,9 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
       set_error("conv2d_fwd: packed weights (wmode %d) need W %% 4 == 0 and 16-byte aligned tensors", wmode);
       return WSL_EINVAL;
     }
+    static const bool cls_on = !(getenv("WSL_CONV_CLS") && atoi(getenv("WSL_CONV_CLS")) == 0);
+    if (cls_on && wmode == 2 && conv_cls_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, stat_part))
+      return conv_cls_launch(p.in.a, w, bias, y, y_bs, N, H, W, stream);   // 4-class classifier (wsl_conv4.hip)
     if (conv3_enabled() && p.in.Ci <= 256)   // wave-specialised persistent kernel (wsl_conv3.hip)
       return conv3_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
                        stat_cnt, stream);

@@ -6,6 +6,8 @@
 // an LDS halo tile with a per-lane shift: 1 resp. 3 MFMAs per step where the general kernel issues 9 that are 1/16 resp.
 // 1/4 full (profiles/r1f: 261 us per launch for ~0.6 GFLOP).  These launches are HBM-bound (A is a 268 MB tensor).
 // Partials go to the same [split][tap][Co][Ci] workspace, reduced by wgrad_reduce_kernel.
+#include <type_traits>
+
 #include "wsl_rt.h"
 
 namespace wsl {
@@ -240,4 +242,176 @@ int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs
   return launch_wgrad_small<4, -1>(p, stream);
 }
 
+
+// ================================================================================================ classifier forward
+// out_conv of a decoder: 3x3, 16 -> 4 channels at full resolution.  On the 16x16x4 tiling three quarters of every MFMA are
+// padding (conv_mfma2_kernel: ~270 us per launch).  v_mfma_f32_4x4x1_16b_f32 fits exactly: 16 independent 4x4 outer
+// products per instruction = 64 consecutive pixels of a row (4 per block) x the 4 classes, K = 1 (one (ci, tap) pair).
+// Lane l supplies the input of pixel l (A) and the weight of class l & 3 (B) and receives pixels 4*(l>>2)..+3 of class
+// l & 3 -- a float4 store.  The 144 weights of a lane's class live in registers for the whole (persistent) workgroup.
+struct ClsP {
+  const float* x;        // [N,16,H,W] raw conv output of the last decoder block
+  int64_t x_bs;
+  const float* scale;    // BN+LeakyReLU loader transform (or null)
+  const float* shift;
+  const float* wp;       // packed [9][16][4]
+  const float* bias;
+  float* y;
+  int64_t y_bs;
+  int N, H, W, tiles_x, tiles_y, items;
+};
+
+struct ClsCfg {
+  static constexpr int TH = 8, TW = 64, ROWP = TW + 8, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4, KC = 8;
+  static constexpr int PLANE = ROWS * ROWP;
+  static constexpr size_t SMEM = sizeof(float) * (KC * PLANE + 32);
+  static_assert(POS <= 256, "one float4 position per thread");
+};
+
+__global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
+  using C = ClsCfg;
+  WSL_DYN_SMEM(smem);
+  float* in_t = reinterpret_cast<float*>(smem);
+  float2* tab = reinterpret_cast<float2*>(in_t + C::KC * C::PLANE);   // [16] {scale, shift}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, W = p.W, HW = H * W;
+  const bool has_scale = p.scale != nullptr;
+  if (tid < 16) tab[tid] = has_scale ? make_float2(p.scale[tid], p.shift[tid]) : make_float2(1.f, 0.f);
+
+  // weights of this lane's class, all (tap, ci): registers (every index below is a compile-time constant)
+  float wreg[9 * 16];
+#pragma unroll
+  for (int k = 0; k < 9 * 16; ++k) wreg[k] = p.wp[k * 4 + (lane & 3)];
+  const float bias = p.bias ? p.bias[lane & 3] : 0.f;
+
+  // staging position of this thread (fixed) -- threads past the halo tile idle while staging
+  const int pty = tid / C::ROWP4, ptx4 = tid - pty * C::ROWP4;
+  const bool owner = tid < C::POS;
+  const int loff = pty * C::ROWP + ptx4 * 4;
+  const int it0 = (int)((int64_t)blockIdx.x * p.items / gridDim.x), it1 = (int)((int64_t)(blockIdx.x + 1) * p.items / gridDim.x);
+
+  float4 pre[C::KC];
+  bool pok = false;
+  auto tile_of = [&](int item, int& n, int& y0, int& x0) {
+    int q = item;
+    const int tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    const int ty = q % p.tiles_y;
+    n = q / p.tiles_y, y0 = ty * C::TH, x0 = tx * C::TW;
+  };
+  auto issue = [&](int item, int ch) __attribute__((always_inline)) {
+    int n, y0, x0;
+    tile_of(item, n, y0, x0);
+    const int gy = y0 + pty - 1, gx = x0 + ptx4 * 4 - 4;
+    pok = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const uint32_t off = pok ? (uint32_t)(gy * W + gx) : 0u;
+    const float* xb = p.x + n * p.x_bs + (int64_t)ch * C::KC * HW;
+#pragma unroll
+    for (int i = 0; i < C::KC; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + (int64_t)i * HW + off);
+  };
+  auto commit = [&](int ch) __attribute__((always_inline)) {
+    if (owner) {
+#pragma unroll
+      for (int i = 0; i < C::KC; ++i) {
+        wsl_v2f lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
+        if (has_scale) {
+          const float2 t = tab[ch * C::KC + i];
+          xform_bn_leaky(lo, hi, t.x, t.y);
+        }
+        if (!pok) lo = wsl_v2f{0.f, 0.f}, hi = wsl_v2f{0.f, 0.f};
+        *reinterpret_cast<float4*>(in_t + i * C::PLANE + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
+      }
+    }
+  };
+
+  v4f acc[2];
+  // one 8-channel half of the reduction: rows 2*wave and 2*wave+1 of the tile, pixel = lane
+  auto mfma_half = [&](auto ch_tag) __attribute__((always_inline)) {
+    constexpr int CH = decltype(ch_tag)::value;   // std::integral_constant
+#pragma unroll
+    for (int cc = 0; cc < C::KC; ++cc)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float av[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) av[rr][kx] = in_t[cc * C::PLANE + (wave * 2 + rr + ky) * C::ROWP + lane + kx + 3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) acc[rr] = WSL_MFMA4(av[rr][kx], wreg[(ky * 3 + kx) * 16 + CH * C::KC + cc], acc[rr]);
+      }
+  };
+
+  if (it0 < it1) issue(it0, 0);
+  __syncthreads();   // table visible
+  for (int item = it0; item < it1; ++item) {
+    acc[0] = v4f{bias, bias, bias, bias}, acc[1] = acc[0];
+    commit(0);
+    __syncthreads();
+    issue(item, 1);
+    mfma_half(std::integral_constant<int, 0>{});
+    __syncthreads();
+    commit(1);
+    __syncthreads();
+    if (item + 1 < it1) issue(item + 1, 0);
+    mfma_half(std::integral_constant<int, 1>{});
+    __syncthreads();
+    int n, y0, x0;
+    tile_of(item, n, y0, x0);
+    float* yb = p.y + n * p.y_bs + (int64_t)(lane & 3) * HW + (int64_t)(y0 + wave * 2) * W + x0 + (lane >> 2) * 4;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+      *reinterpret_cast<float4*>(yb + rr * W) = make_float4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
+  }
+}
+
+// 3x3, 16 -> 4, one source with at most the BN+LeakyReLU transform, no statistics, full 8x64 tiles, aligned planes
+bool conv_cls_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_bs, int H, int W, int Co, int ks,
+                       const float* stat_part) {
+  if (ks != 3 || Co != 4 || a.C != 16 || (b && b->C > 0) || a.emask || a.cmask || stat_part) return false;
+  if ((H % 8) || (W % 64) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.bs & 3)) return false;
+  return (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_bs & 3) == 0;
+}
+
+int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H, int W,
+                    void* stream) {
+  ClsP p;
+  p.x = a.x, p.x_bs = a.bs, p.scale = a.scale, p.shift = a.shift, p.wp = wp, p.bias = bias, p.y = y, p.y_bs = y_bs;
+  p.N = N, p.H = H, p.W = W, p.tiles_x = W / 64, p.tiles_y = H / 8, p.items = N * p.tiles_x * p.tiles_y;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(conv_cls_kernel, ClsCfg::SMEM);
+    attr_done = true;
+  }
+  int wgs = 2 * device_cu_count();
+  if (wgs > p.items) wgs = p.items;
+  const double px = (double)N * H * W;
+  void* tok = prof_begin(0, 2.0 * px * 4 * 16 * 9, 4.0 * px * (16 + 4), stream);
+  WSL_LAUNCH(conv_cls_kernel, dim3(wgs), dim3(kThreads), ClsCfg::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_cls_kernel");
+}
+
+// Operand-layout probe of the 4x4x1 (16 blocks) f32 MFMA used by the classifier forward: d[lane][r] for given a, b.
+#ifndef WSL_HOST_EMUL
+__global__ void mfma4_probe_kernel(const float* a, const float* b, float* d) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[threadIdx.x], b[threadIdx.x], acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) d[threadIdx.x * 4 + r] = acc[r];
+}
+#endif
+
 }  // namespace wsl
+
+extern "C" int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, void* stream) {
+#ifndef WSL_HOST_EMUL
+  WSL_LAUNCH(wsl::mfma4_probe_kernel, dim3(1), dim3(64), 0, stream, a, b, d);
+  return wsl::check_launch("mfma4_probe_kernel");
+#else
+  (void)a, (void)b, (void)d, (void)stream;
+  return WSL_EUNSUPPORTED;
+#endif
+}

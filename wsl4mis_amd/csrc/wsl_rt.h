@@ -14,6 +14,7 @@
 #define WSL_SET_MAX_DYN_SMEM(kern, bytes) 0
 typedef wsl_v4f v4f;
 #define WSL_MFMA16(a, b, c) wsl_emu_mfma16(a, b, c)
+#define WSL_MFMA4(a, b, c) wsl_emu_mfma4(a, b, c)
 #define WSL_SCHED_BARRIER()
 #else
 #include <hip/hip_runtime.h>
@@ -25,6 +26,8 @@ typedef wsl_v4f v4f;
 typedef float v4f __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4] (1 VGPR), B[k=l>>4][j=l&15] (1 VGPR), D col=l&15,row=(l>>4)*4+r.
 #define WSL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products; block = l >> 2, D[l][r] = A[4*block + r] * B[l] + C[l][r]
+#define WSL_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0)
 // keeps the instruction scheduler from moving LDS reads / MFMAs across a software-pipeline stage boundary
 #define WSL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
