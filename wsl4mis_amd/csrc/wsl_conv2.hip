@@ -1101,6 +1101,228 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2l_kernel(Wgrad2P p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ split-halo weight gradient
+// Same blocking and staging discipline as wgrad_mfma2l_kernel, with the 3x3 tap offset split between the two operands:
+//   dw[co][ci][ky][kx] = sum_p dy[co][p] * a[ci][p + (ky-1, kx-1)] = sum_q dy[co][q - (ky-1) rows] * a[ci][q + (kx-1) cols]
+// so a step needs 3 row-shifted A operands (dy, tile with a +-1 row halo) and 3 column-shifted B operands (activations,
+// tile with a +-4 column halo): 6 LDS reads feed 9 MFMAs where one-sided shifting needs 10, and the BN/LeakyReLU/mask
+// transform runs over TH x (TW+8) activations instead of (TH+2) x (TW+8).  Tiles partition the image in q, out-of-image
+// rows of dy and columns of a are staged as zeros (the convolution's zero padding), so every product is counted once.
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+struct WgradSCfg {
+  static constexpr int P = KS / 2, KK = KS * KS, PADL = P ? 4 : 0;
+  static constexpr int ROWS_D = TH + 2 * P, SD = ROWS_D * TW, PD = SD / 4, GD = 256 / PD, ND = (CB + GD - 1) / GD;
+  static constexpr int ROWP = TW + 2 * PADL, ROWP4 = ROWP / 4, SA = TH * ROWP, PA = SA / 4, GA = 256 / PA, NA = (IB + GA - 1) / GA;
+  static constexpr int PLD = ((SD - 2 + 31) / 32) * 32 + 2;   // == 2 (mod 32)
+  static constexpr int PLA = ((SA - 2 + 31) / 32) * 32 + 2;   // == 2 (mod 32)
+  static constexpr int CBT = CB / 16, IBT = IB / 16, PAIRS = CBT * IBT, WP = 4 / WK, PP = PAIRS / WP;
+  static constexpr int DY_FLOATS = CB * PLD, A_FLOATS = IB * PLA;
+  static constexpr int RED_FLOATS = (WK > 1) ? 4 * 64 * ((KK + 1) * 4) : 0;
+  static constexpr int MAIN_FLOATS = DY_FLOATS + A_FLOATS > RED_FLOATS ? DY_FLOATS + A_FLOATS : RED_FLOATS;
+  static constexpr size_t SMEM = sizeof(float) * (MAIN_FLOATS + 2 * IB);
+  static_assert(PD <= 256 && PA <= 256 && PAIRS == WP && TH % WK == 0, "split-halo wgrad tile shape");
+};
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
+  using C = WgradSCfg<KS, TH, TW, CB, IB, WK>;
+  WSL_DYN_SMEM(smem);
+  float* dy_t = reinterpret_cast<float*>(smem);
+  float* a_t = dy_t + C::DY_FLOATS;
+  float2* tab = reinterpret_cast<float2*>(dy_t + C::MAIN_FLOATS);   // [IB] {scale, shift} of this block's channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = blockIdx.x % p.co_blocks, ib = blockIdx.x / p.co_blocks, split = blockIdx.y;
+  const int co0 = cb * CB, ci0 = ib * IB;
+  const int wp_ = wave % C::WP, wk = wave / C::WP;
+  const int H = p.H, W = p.W, Ci = p.Ci;
+  const int HW = H * W;
+
+  // the source this block of input channels comes from (uniform for the whole workgroup)
+  const bool ina = ci0 < p.a.C;
+  const Src2& s = ina ? p.a : p.b;
+  const int chb0 = ina ? ci0 : ci0 - p.a.C;
+  const bool has_scale = s.scale != nullptr, has_mask = s.emask != nullptr, has_cm = s.cmask != nullptr;
+  const float es = s.es;
+  for (int c = tid; c < IB; c += kThreads) tab[c] = has_scale ? make_float2(s.scale[chb0 + c], s.shift[chb0 + c]) : make_float2(1.f, 0.f);
+
+  // fixed staging positions of this thread
+  const int gd = tid / C::PD, pd = tid - gd * C::PD;             // dy: float4 index pd inside the (TH+2P) x TW tile
+  const int dty = (pd * 4) / TW, dtx = (pd * 4) - dty * TW;
+  const bool owner_d = gd < C::GD;
+  const int tdconst = gd * HW + (dty - C::P) * W + dtx;          // + y0 * W + x0 per tile (valid rows only)
+  const int dloff = gd * C::PLD + pd * 4;
+  const int ga = tid / C::PA, pa = tid - ga * C::PA;             // input: float4 index inside the TH x (TW+8) tile
+  const int aty = pa / C::ROWP4, atx4 = pa - aty * C::ROWP4;
+  const bool owner_a = ga < C::GA;
+  const int aloff = ga * C::PLA + aty * C::ROWP + atx4 * 4;
+  const int64_t dstride = (int64_t)C::GD * HW, astride = (int64_t)C::GA * HW;
+
+  v4f acc[C::KK];
+  v4f accb = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < C::KK; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  const bool want_db = (ib == 0) && (p.part_db != nullptr);
+  const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
+
+  float4 prd[C::ND], pra[C::NA];
+  uint32_t prm[C::NA];
+  float prc[C::NA];
+  bool pr_aok = false, pr_dok = false;   // the prefetched input / dy position lies inside the image
+  int nx_tx, nx_ty, nx_n;   // tile the next issue() fetches
+  {
+    int q = it0;
+    nx_tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    nx_ty = q % p.tiles_y;
+    nx_n = q / p.tiles_y;
+  }
+
+  // channel ga + i * GA of the block exists (the last group of a ragged split may not)
+  auto a_has = [&](int i) { return (i + 1) * C::GA <= IB || ga + i * C::GA < IB; };
+  auto issue = [&]() __attribute__((always_inline)) {
+    const int n = nx_n, y0 = nx_ty * TH, x0 = nx_tx * TW;
+    if (++nx_tx == p.tiles_x) {
+      nx_tx = 0;
+      if (++nx_ty == p.tiles_y) nx_ty = 0, ++nx_n;
+    }
+    const float* dyb = p.dy + n * p.dy_bs + (int64_t)co0 * HW;
+    const int dgy = y0 + dty - C::P;
+    pr_dok = owner_d && dgy >= 0 && dgy < H;
+    const uint32_t tdoff = pr_dok ? (uint32_t)(tdconst + y0 * W + x0) : 0u;
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i)   // a ragged last group re-reads a valid channel; commit() skips it
+      prd[i] = *reinterpret_cast<const float4*>(dyb + ((i + 1) * C::GD <= CB || gd + i * C::GD < CB ? i * dstride : 0) + tdoff);
+    const int gy = y0 + aty, gx = x0 + atx4 * 4 - C::PADL;
+    pr_aok = owner_a && gx >= 0 && gx < W;
+    const uint32_t taoff = pr_aok ? (uint32_t)(ga * HW + gy * W + gx) : 0u;
+    const float* xb = s.x + n * s.bs + (int64_t)chb0 * HW;
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i) pra[i] = *reinterpret_cast<const float4*>(xb + (a_has(i) ? i * astride : 0) + taoff);
+    if (has_mask) {
+      const uint8_t* mb = s.emask + ((int64_t)n * s.C + chb0) * HW;
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + (a_has(i) ? i * astride : 0) + taoff);
+    }
+    if (has_cm) {
+      const float* cmb = s.cmask + (int64_t)n * s.C + chb0 + (owner_a ? ga : 0);
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) prc[i] = cmb[a_has(i) ? i * C::GA : 0];
+    }
+  };
+
+  auto commit = [&]() __attribute__((always_inline)) {
+    if (owner_d) {
+#pragma unroll
+      for (int i = 0; i < C::ND; ++i) {
+        if (!((i + 1) * C::GD <= CB || gd + i * C::GD < CB)) continue;
+        float* dst = dy_t + i * (C::GD * C::PLD) + dloff;   // plane stride == 2 (mod 32): 8-byte aligned, not 16
+        *reinterpret_cast<float2*>(dst) = pr_dok ? make_float2(prd[i].x, prd[i].y) : make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(dst + 2) = pr_dok ? make_float2(prd[i].z, prd[i].w) : make_float2(0.f, 0.f);
+      }
+    }
+    if (owner_a) {
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) {
+        if (!a_has(i)) continue;
+        wsl_v2f lo = {pra[i].x, pra[i].y}, hi = {pra[i].z, pra[i].w};
+        if (has_scale) {
+          const float2 t = tab[ga + i * C::GA];
+          xform_bn_leaky(lo, hi, t.x, t.y);
+        }
+        if (has_mask) xform_mask(lo, hi, prm[i], es);   // keep-mask bytes are 0 or 1
+        if (has_cm) lo = lo * prc[i], hi = hi * prc[i];
+        if (!pr_aok) lo = wsl_v2f{0.f, 0.f}, hi = wsl_v2f{0.f, 0.f};
+        float* dst = a_t + i * (C::GA * C::PLA) + aloff;
+        *reinterpret_cast<float2*>(dst) = make_float2(lo[0], lo[1]);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(hi[0], hi[1]);
+      }
+    }
+  };
+
+  if (it0 < it1) issue();
+  __syncthreads();  // BN table visible
+  const int cot = wp_ / C::IBT, cit = wp_ % C::IBT;
+  const float* dyp = dy_t + (cot * 16 + (lane & 15)) * C::PLD + (lane >> 4);
+  const float* ap = a_t + (cit * 16 + (lane & 15)) * C::PLA + (lane >> 4) + (C::PADL - C::P);
+  const bool dbw = want_db && cit == 0;
+  for (int item = it0; item < it1; ++item) {
+    if (!(p.ablate & 2) || item == it0) commit();
+    __syncthreads();
+    if (item + 1 < it1 && !(p.ablate & 2)) issue();   // prefetch the next tile; in flight during the MFMA loop
+    constexpr int RW = TH / WK, NX = TW / 4, NSTEP = RW * NX;
+    float avv[2][KS], bvv[2][KS];
+    auto load = [&](int st, int buf) {   // step st = (row, group of 4 pixels)
+      const int r = wk * RW + st / NX, x4 = st % NX;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) avv[buf][ky] = dyp[(r + 2 * C::P - ky) * TW + x4 * 4];   // dy shifted by -(ky-P) rows
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) bvv[buf][kx] = ap[r * C::ROWP + x4 * 4 + kx];           // a shifted by +(kx-P) cols
+    };
+    load(0, 0);
+    if (p.ablate & 1) continue;
+#pragma unroll 2
+    for (int st = 0; st < NSTEP; ++st) {   // operands of step st+1 are read before the MFMAs of step st issue
+      const int cur = st & 1;
+      if (st + 1 < NSTEP && !(p.ablate & 8)) load(st + 1, cur ^ 1);
+      if (dbw) accb = WSL_MFMA16(avv[cur][C::P], 1.0f, accb);
+#pragma unroll
+      for (int t = 0; t < C::KK; ++t) acc[t] = WSL_MFMA16(avv[cur][t / KS], bvv[cur][t % KS], acc[t]);
+      WSL_SCHED_BARRIER();
+    }
+    __syncthreads();
+  }
+  // ---- merge the WK row-groups (fixed order) and store partials
+  if (WK > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int PER = (C::KK + 1) * 4;
+    float* mine = red + (wave * 64 + lane) * PER;
+#pragma unroll
+    for (int t = 0; t < C::KK; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[t * 4 + r] = acc[t][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[C::KK * 4 + r] = accb[r];
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int t = 0; t <= C::KK; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sum = 0.f;
+          for (int k = 0; k < WK; ++k) sum += red[((k * C::WP + wp_) * 64 + lane) * PER + t * 4 + r];
+          if (t < C::KK) acc[t][r] = sum; else accb[r] = sum;
+        }
+    }
+  }
+  if (wk == 0) {
+    const int ci = ci0 + cit * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + cot * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+      for (int t = 0; t < C::KK; ++t) p.part_dw[(((int64_t)split * C::KK + t) * p.Co + co) * Ci + ci] = acc[t][r];
+      if (dbw && (lane & 15) == 0) p.part_db[(int64_t)split * p.Co + co] = accb[r];
+    }
+  }
+}
+
+template <int KS, int TH, int TW, int CB, int IB, int WK>
+static int launch_wgrad2s(Wgrad2P& p, int ci_blocks, void* stream) {
+  using C = WgradSCfg<KS, TH, TW, CB, IB, WK>;
+  auto kern = wgrad_mfma2s_kernel<KS, TH, TW, CB, IB, WK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("wgrad_mfma2s_kernel");
+}
+
 template <int KS, int TH, int TW, int CB, int IB, int WK>
 static int launch_wgrad2l(Wgrad2P& p, int ci_blocks, void* stream) {
   using C = Wgrad2Cfg<KS, TH, TW, CB, IB, WK>;
@@ -1124,8 +1346,11 @@ static int launch_wgrad2(Wgrad2P& p, int ci_blocks, void* stream) {
   static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
   const int64_t span = (int64_t)(p.a.C > p.b.C ? p.a.C : p.b.C) * p.H * p.W;
   if (lean_on && p.Ci % IB == 0 && p.Co % CB == 0 && (p.b.C == 0 || p.a.C % IB == 0) && p.H % TH == 0 && p.W % TW == 0 &&
-      span < (int64_t(1) << 31) && (int64_t)p.Co * p.H * p.W < (int64_t(1) << 31))
+      span < (int64_t(1) << 31) && (int64_t)p.Co * p.H * p.W < (int64_t(1) << 31)) {
+    static const bool split_on = !(getenv("WSL_WGRAD_SPLIT") && atoi(getenv("WSL_WGRAD_SPLIT")) == 0);
+    if (split_on) return launch_wgrad2s<KS, TH, TW, CB, IB, WK>(p, ci_blocks, stream);
     return launch_wgrad2l<KS, TH, TW, CB, IB, WK>(p, ci_blocks, stream);
+  }
   auto kern = wgrad_mfma2_kernel<KS, TH, TW, CB, IB, WK>;
   static bool attr_done = false;
   if (!attr_done) {
