@@ -91,6 +91,8 @@ int wsl_debug_conv_variant(int v);
  * (+5 % step rate).  0 serialises everything on the caller's stream (per-launch timings then do not overlap: what
  * bench.py's roofline segment and profiles/ use); 1 restores the default.  Env WSL_NET_CONCURRENT=0 does the same. */
 int wsl_debug_net_concurrent(int on);
+/* Operand-layout probe of v_mfma_f32_4x4x1_16b_f32 (64 lanes: a[64], b[64] -> d[64][4]); tools/probe_mfma4.py. */
+int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, void* stream);
 
 /* dw[Co][Ci][ks][ks] = sum_{n,y,x} dy[n,co,y,x] * in[n,ci,y+ky-p,x+kx-p];  db[Co] = sum dy  (db may be NULL).
  * Split over pixels into partials in `ws`, then an order-fixed second stage. */
@@ -197,6 +199,24 @@ int wsl_axpy(float* dst, const float* src, float k, int64_t n, void* stream);
  *   if (ema) ema = ema_alpha*ema + (1-ema_alpha)*p      (update_ema_variables, ref: ..._ustm_2D.py:61-65) */
 int wsl_sgd_step(float* p, const float* grad, float* buf, int64_t n, float lr, float momentum, float wd, int first,
                  float grad_scale, float* ema, float ema_alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ data path
+ * The per-slice augmentation of RandomGenerator (ref: code/dataloaders/dataset_semi.py:128-171) for a batch of slices
+ * of different native sizes, one gather per output pixel:  op 0 nothing | 1 np.rot90(k) then np.flip(axis) |
+ * 2 scipy.ndimage.rotate(order 0, reshape=False, constant cval) with the host-computed 2x2 matrix m and offset
+ * (rows first, as scipy builds them from cosdg/sindg and the centres (shape-1)/2);  then scipy.ndimage.zoom(order 0) to
+ * [Ho, Wo].  Image out [n,1,Ho,Wo] float32, label out [n,Ho,Wo] uint8.  The descriptor array lives on the HOST
+ * (copied into the launch); img / lab are device pointers.  Results equal numpy/scipy bit for bit. */
+typedef struct {
+  const float* img;    /* [h, w] */
+  const uint8_t* lab;  /* [h, w] */
+  int h, w;
+  int op, k, axis;     /* op 1: k in 0..3, axis in {0,1} */
+  int lab_cval;        /* op 2: fill of the label outside the rotated image (4 for scribbles, else 0) */
+  float img_cval;      /* op 2: fill of the image (0) */
+  double m00, m01, m10, m11, off0, off1;   /* op 2: input coord = m * output coord + off */
+} WslAugSample;
+int wsl_augment_batch(const WslAugSample* samples, int n, float* out_img, uint8_t* out_lab, int Ho, int Wo, void* stream);
 
 /* Bernoulli masks for nn.Dropout / F.dropout2d in ONE launch (Philox4x32-10, counter-based: reproducible per seed).
  * Mask i: is_f32[i] == 0 -> uint8 keep mask (1 with probability keep_probs[i]); == 1 -> float multiplier

@@ -37,6 +37,12 @@ class WslNetEntry(C.Structure):
                 ("offset", C.c_int64)]
 
 
+class WslAugSample(C.Structure):
+    _fields_ = [("img", c_fp), ("lab", c_fp), ("h", C.c_int32), ("w", C.c_int32), ("op", C.c_int32), ("k", C.c_int32),
+                ("axis", C.c_int32), ("lab_cval", C.c_int32), ("img_cval", C.c_float), ("m00", C.c_double),
+                ("m01", C.c_double), ("m10", C.c_double), ("m11", C.c_double), ("off0", C.c_double), ("off1", C.c_double)]
+
+
 i32, i64, f32, f64, sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 PS, PD, PE = C.POINTER(WslSrc), C.POINTER(WslNetDesc), C.POINTER(WslNetEntry)
 PP = C.POINTER(c_fp)
@@ -53,6 +59,7 @@ _PROTOS = {
     "wsl_conv2d_fast_ok": (i32, [PS, PS, c_fp, i64, i32]),
     "wsl_debug_conv_variant": (i32, [i32]),
     "wsl_debug_net_concurrent": (i32, [i32]),
+    "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
     "wsl_conv2d_wgrad": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "wsl_bn_stats_finalize": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, f32, f32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
@@ -84,6 +91,7 @@ _PROTOS = {
     "wsl_softmax_mse_fwd_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, f32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_axpy": (i32, [c_fp, c_fp, f32, i64, c_fp]),
     "wsl_sgd_step": (i32, [c_fp, c_fp, c_fp, i64, f32, f32, f32, i32, f32, c_fp, f32, c_fp]),
+    "wsl_augment_batch": (i32, [C.POINTER(WslAugSample), i32, c_fp, c_fp, i32, i32, c_fp]),
     "wsl_draw_masks": (i32, [i32, PP, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float),
                              C.POINTER(C.c_int), C.c_uint64, c_fp]),
     "wsl_net_num_entries": (i32, [PD]),

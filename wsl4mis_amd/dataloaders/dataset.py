@@ -1,0 +1,93 @@
+"""Device-side mirror of the reference's per-slice augmentation.
+
+Reference: code/dataloaders/dataset_semi.py:128-171 (`random_rot_flip`, `random_rotate`, `RandomGenerator`), which runs
+numpy / scipy.ndimage per sample on the CPU inside DataLoader workers.  Here the random parameters are drawn on the host
+in exactly the reference's order from the same generators (`random`, `numpy.random`), and the pixels are produced by ONE
+gather kernel for a whole batch of slices of different native sizes (`wsl_augment_batch`, csrc/wsl_data.hip): every
+step of the reference is a nearest-neighbour index map, so the composition is exact -- results equal numpy/scipy bit for
+bit (tests/test_data.py).  No CPU fallback: without the HIP library these calls raise.
+
+Not mirrored (out of this round): HDF5 ingest (`BaseDataSets`; h5py is not in the image), `TwoStreamBatchSampler`."""
+import random
+
+import numpy as np
+import torch
+from scipy import special
+
+from .. import _lib
+from .. import runtime as rt
+
+
+def draw_params(label_np):
+    """The reference's random decisions for ONE sample, same draw order and generators (dataset_semi.py:155-161)."""
+    p = {"op": 0}
+    if random.random() > 0.5:
+        p["op"], p["k"] = 1, int(np.random.randint(0, 4))
+        p["axis"] = int(np.random.randint(0, 2))
+    elif random.random() > 0.5:
+        p["op"], p["angle"] = 2, int(np.random.randint(-20, 20))
+        p["lab_cval"] = 4 if 4 in np.unique(label_np) else 0
+    return p
+
+
+def _rotate_matrix(angle, shape):
+    """scipy.ndimage.rotate(reshape=False) for a 2-D array: matrix from cosdg/sindg, offset about the centres (n-1)/2."""
+    c, s = special.cosdg(angle), special.sindg(angle)
+    m = np.array([[c, s], [-s, c]], dtype=np.float64)
+    ctr = (np.array(shape, dtype=np.float64) - 1) / 2
+    off = ctr - m @ ctr
+    return m, off
+
+
+def augment_batch(images, labels, params, output_size):
+    """images: list of [h,w] float32 tensors, labels: list of [h,w] uint8 tensors (any device; moved to the GPU),
+    params: list of dicts from draw_params.  Returns (image [N,1,Ho,Wo] float32, label [N,Ho,Wo] uint8) on the device."""
+    L = _lib.lib()
+    dev = rt.device()
+    n = len(images)
+    Ho, Wo = int(output_size[0]), int(output_size[1])
+    keep = []
+    arr = (_lib.WslAugSample * n)()
+    for i, (im, lb, p) in enumerate(zip(images, labels, params)):
+        im = torch.as_tensor(im, dtype=torch.float32).to(dev).contiguous()
+        lb = torch.as_tensor(lb, dtype=torch.uint8).to(dev).contiguous()
+        if im.dim() != 2 or im.shape != lb.shape:
+            raise ValueError(f"augment_batch: sample {i}: image {tuple(im.shape)} / label {tuple(lb.shape)} must be equal 2-D shapes")
+        keep += [im, lb]
+        s = arr[i]
+        s.img, s.lab, s.h, s.w = rt.ptr(im), rt.ptr(lb), im.shape[0], im.shape[1]
+        s.op, s.k, s.axis = p["op"], p.get("k", 0), p.get("axis", 0)
+        s.lab_cval, s.img_cval = p.get("lab_cval", 0), 0.0
+        if p["op"] == 2:
+            m, off = _rotate_matrix(p["angle"], im.shape)
+            s.m00, s.m01, s.m10, s.m11, s.off0, s.off1 = m[0, 0], m[0, 1], m[1, 0], m[1, 1], off[0], off[1]
+    out_img = torch.empty((n, 1, Ho, Wo), dtype=torch.float32, device=dev)
+    out_lab = torch.empty((n, Ho, Wo), dtype=torch.uint8, device=dev)
+    _lib.check(L.wsl_augment_batch(arr, n, rt.ptr(out_img), rt.ptr(out_lab), Ho, Wo, rt.stream()))
+    if dev.type == "cuda":
+        torch.cuda.current_stream().synchronize()   # the descriptor array and the staged inputs may go out of scope
+    return out_img, out_lab
+
+
+class RandomGenerator(object):
+    """Same call contract as the reference class: sample dict {'image': [h,w], 'label': [h,w]} -> {'image': [1,H,W]
+    float32, 'label': [H,W] uint8}, with the tensors living on the device."""
+
+    def __init__(self, output_size):
+        self.output_size = output_size
+
+    def __call__(self, sample):
+        image, label = np.asarray(sample["image"]), np.asarray(sample["label"])
+        img, lab = augment_batch([image], [label], [draw_params(label)], self.output_size)
+        return {"image": img[0], "label": lab[0]}
+
+
+class BatchRandomGenerator(object):
+    """The batched form the engine wants: a list of samples in, one device batch out (one kernel launch)."""
+
+    def __init__(self, output_size):
+        self.output_size = output_size
+
+    def __call__(self, samples):
+        params = [draw_params(np.asarray(s["label"])) for s in samples]     # the reference's per-sample draw order
+        return augment_batch([s["image"] for s in samples], [s["label"] for s in samples], params, self.output_size)
