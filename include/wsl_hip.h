@@ -218,6 +218,12 @@ typedef struct {
 } WslAugSample;
 int wsl_augment_batch(const WslAugSample* samples, int n, float* out_img, uint8_t* out_lab, int Ho, int Wo, void* stream);
 
+/* Validation metric pieces (medpy.metric.binary.hd95 as called by code/val_2D.py:7-15): the surface of a binary [D,H,W]
+ * volume (object minus its erosion by the 6-neighbourhood, background outside the array) and, for every point of one
+ * voxel list ([n][3] int64 z,y,x -- torch.nonzero layout), the exact squared distance to the nearest point of another. */
+int wsl_surface_u8(const uint8_t* vol, uint8_t* border, int D, int H, int W, void* stream);
+int wsl_nearest_dist2(const int64_t* a_zyx, int na, const int64_t* b_zyx, int nb, int64_t* out, void* stream);
+
 /* Bernoulli masks for nn.Dropout / F.dropout2d in ONE launch (Philox4x32-10, counter-based: reproducible per seed).
  * Mask i: is_f32[i] == 0 -> uint8 keep mask (1 with probability keep_probs[i]); == 1 -> float multiplier
  * (scales[i] with probability keep_probs[i], else 0).  uint8 outputs must be 4-byte aligned.  n_masks <= 12. */

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import get_backend
-from oracle import data_ref
+from oracle import data_ref, metrics_ref
 
 
 @pytest.fixture(params=[pytest.param("emul"), pytest.param("hip", marks=pytest.mark.gpu)])
@@ -70,3 +70,35 @@ def test_bad_input_raises(mode):
     from wsl4mis_amd.dataloaders import dataset
     with pytest.raises(ValueError):
         dataset.augment_batch([np.zeros((4, 5), np.float32)], [np.zeros((5, 4), np.uint8)], [{"op": 0}], (8, 8))
+
+
+def blobs(rng, shape, k):
+    z, y, x = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    v = np.zeros(shape, bool)
+    for _ in range(k):
+        c = [rng.uniform(0, n) for n in shape]
+        r = rng.uniform(2, 0.35 * min(shape[1:]))
+        v |= ((z - c[0]) * 2.5) ** 2 + (y - c[1]) ** 2 + (x - c[2]) ** 2 < r * r
+    return v
+
+
+def test_validation_metrics_match_the_medpy_algorithm(mode):
+    """Dice and HD95 of the validation loop (val_2D.py:7-15) against the scipy restatement of medpy's algorithm"""
+    from wsl4mis_amd import val_2D
+    rng = np.random.default_rng(17)
+    checked = 0
+    for shape in ((6, 40, 48), (9, 64, 56), (1, 33, 47), (4, 30, 30)):
+        gt, pred = blobs(rng, shape, 3), blobs(rng, shape, 3)
+        if shape[0] == 4:
+            pred = np.ones(shape, bool)                           # object touching every array face
+        if not (gt.any() and pred.any()):
+            continue
+        d_ref, h_ref = metrics_ref.calculate_metric_percase(pred, gt)
+        d, h = val_2D.metric_percase(pred, gt)
+        assert d == d_ref
+        assert abs(h - h_ref) <= 1e-12 * max(1.0, h_ref), (shape, h, h_ref)
+        checked += 1
+    assert checked >= 3
+    assert val_2D.metric_percase(np.zeros((3, 8, 8), bool), np.ones((3, 8, 8), bool)) == (0, 0)
+    with pytest.raises(RuntimeError, match="second supplied array"):
+        val_2D.metric_percase(np.ones((2, 8, 8), bool), np.zeros((2, 8, 8), bool))

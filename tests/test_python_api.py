@@ -306,7 +306,12 @@ def test_validation_volume_label_maps(mode):
     m = net_factory("unet_cct", 1, 4)
     load_det(m, 5)
     got = val_2D.test_single_volume_cct(torch.from_numpy(vol)[None], torch.from_numpy(lab)[None], m, classes=4, patch_size=P)
-    assert len(got) == 3 and all(0.0 <= d <= 1.0 and np.isnan(h) for d, h in got)
+    assert len(got) == 3 and all(0.0 <= d <= 1.0 and (h == 0 or np.isfinite(h)) for d, h in got)
+    from oracle import metrics_ref
+    pred0 = val_2D._predict_volume(vol, m, P, first_output=True)
+    for c, (d, h) in enumerate(got, start=1):       # metrics of the predicted maps == the medpy algorithm on the same maps
+        d_ref, h_ref = metrics_ref.calculate_metric_percase(pred0 == c, lab == c)
+        assert d == d_ref and abs(h - h_ref) <= 1e-12 * max(1.0, h_ref)
     # oracle label maps for the same slices
     from scipy.ndimage import zoom
     sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in det_state(

@@ -91,6 +91,8 @@ _PROTOS = {
     "wsl_softmax_mse_fwd_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, f32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_axpy": (i32, [c_fp, c_fp, f32, i64, c_fp]),
     "wsl_sgd_step": (i32, [c_fp, c_fp, c_fp, i64, f32, f32, f32, i32, f32, c_fp, f32, c_fp]),
+    "wsl_surface_u8": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wsl_nearest_dist2": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp]),
     "wsl_augment_batch": (i32, [C.POINTER(WslAugSample), i32, c_fp, c_fp, i32, i32, c_fp]),
     "wsl_draw_masks": (i32, [i32, PP, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float),
                              C.POINTER(C.c_int), C.c_uint64, c_fp]),

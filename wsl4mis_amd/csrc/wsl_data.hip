@@ -6,6 +6,8 @@
 //   step1 = flip(rot90(img, k), axis)                                                      (numpy index permutations)
 //         | img[floor(M (i,j) + off + 0.5)] if 0 <= M (i,j) + off <= n-1 else cval          (scipy.ndimage.rotate, order 0)
 // Coordinates are computed in double without contraction, in the order that reproduces scipy bit for bit on the tests.
+#include <stdint.h>
+
 #include "wsl_rt.h"
 
 namespace wsl {
@@ -58,9 +60,62 @@ __global__ __launch_bounds__(256) void augment_kernel(AugTable t, float* out_img
   }
 }
 
+// ---- validation metric: the two device pieces of medpy.metric.binary.hd95
+// surface of a binary volume = the object minus its erosion by the 6-neighbourhood with a background border
+// (scipy.ndimage.binary_erosion(structure=generate_binary_structure(3, 1), border_value=0))
+__global__ __launch_bounds__(256) void surface_kernel(const uint8_t* vol, uint8_t* border, int D, int H, int W) {
+  const int64_t n = (int64_t)D * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((int64_t)W * H));
+    uint8_t b = 0;
+    if (vol[i]) {
+      const bool inner = z > 0 && z < D - 1 && y > 0 && y < H - 1 && x > 0 && x < W - 1 && vol[i - 1] && vol[i + 1] &&
+                         vol[i - W] && vol[i + W] && vol[i - (int64_t)W * H] && vol[i + (int64_t)W * H];
+      b = inner ? 0 : 1;
+    }
+    border[i] = b;
+  }
+}
+
+// out[i] = min_j |a_i - b_j|^2 over integer voxel coordinates (exact in int64); b is streamed through LDS
+__global__ __launch_bounds__(256) void nearest_d2_kernel(const int64_t* a, int na, const int64_t* b, int nb, int64_t* out) {
+  __shared__ int bs[3 * 1024];
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  const bool live = i < na;
+  const int az = live ? (int)a[3 * (int64_t)i] : 0, ay = live ? (int)a[3 * (int64_t)i + 1] : 0, ax = live ? (int)a[3 * (int64_t)i + 2] : 0;
+  int64_t best = INT64_MAX;
+  for (int j0 = 0; j0 < nb; j0 += 1024) {
+    const int m = nb - j0 < 1024 ? nb - j0 : 1024;
+    __syncthreads();
+    for (int k = threadIdx.x; k < 3 * m; k += kThreads) bs[k] = (int)b[3 * (int64_t)j0 + k];
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+      const int64_t dz = az - bs[3 * j], dy = ay - bs[3 * j + 1], dx = ax - bs[3 * j + 2];
+      const int64_t d = dz * dz + dy * dy + dx * dx;
+      best = d < best ? d : best;
+    }
+  }
+  if (live) out[i] = best;
+}
+
 }  // namespace wsl
 
 using namespace wsl;
+
+extern "C" int wsl_surface_u8(const uint8_t* vol, uint8_t* border, int D, int H, int W, void* stream) {
+  WSL_REQUIRE(vol && border && D > 0 && H > 0 && W > 0, "surface_u8: bad arguments");
+  const int64_t n = (int64_t)D * H * W;
+  int64_t blocks = (n + kThreads - 1) / kThreads;
+  if (blocks > 4096) blocks = 4096;
+  WSL_LAUNCH(surface_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, vol, border, D, H, W);
+  return check_launch("surface_kernel");
+}
+
+extern "C" int wsl_nearest_dist2(const int64_t* a_zyx, int na, const int64_t* b_zyx, int nb, int64_t* out, void* stream) {
+  WSL_REQUIRE(a_zyx && b_zyx && out && na > 0 && nb > 0, "nearest_dist2: both point sets must be non-empty");
+  WSL_LAUNCH(nearest_d2_kernel, dim3(cdiv(na, kThreads)), dim3(kThreads), 0, stream, a_zyx, na, b_zyx, nb, out);
+  return check_launch("nearest_d2_kernel");
+}
 
 extern "C" int wsl_augment_batch(const WslAugSample* samples, int n, float* out_img, uint8_t* out_lab, int Ho, int Wo,
                                  void* stream) {

@@ -1,8 +1,10 @@
 """In-training validation of the reference (ref: code/val_2D.py:18-50 test_single_volume, :90-124
 test_single_volume_cct): per-slice zoom to the patch size -> net in eval mode -> argmax over softmax -> zoom back, then
-per-class metrics over the volume.  The forward runs on the HIP path; the zoom (scipy, order 0, like the reference) and
-the metric are host-side glue.  medpy is not available offline, so Dice is computed here and HD95 is reported as NaN
-("hd95/medpy out of scope")."""
+per-class metrics over the volume.  The forward runs on the HIP path; the zoom (scipy, order 0, like the reference) is
+host-side glue.  medpy is not available offline: Dice is computed here, and HD95 follows medpy 0.4.0
+`metric.binary.hd95` (surface = object minus its 6-neighbourhood erosion; both directed sets of nearest-surface
+distances; 95th percentile with numpy's linear rule) with the two heavy pieces on the device (`wsl_surface_u8`,
+`wsl_nearest_dist2`: exact integer squared distances) and `torch.nonzero` / `torch.sort` as plumbing."""
 import numpy as np
 import torch
 from scipy.ndimage import zoom
@@ -18,6 +20,49 @@ def dice_percase(pred, gt):
     inter = np.count_nonzero(pred & gt)
     denom = np.count_nonzero(pred) + np.count_nonzero(gt)
     return 2.0 * inter / denom if denom else 0.0
+
+
+def _surface_points(vol_bool):
+    v = torch.as_tensor(np.ascontiguousarray(vol_bool, dtype=np.uint8)).to(rt.device())
+    if v.dim() == 2:
+        v = v[None]
+    border = torch.empty_like(v)
+    rt.call("wsl_surface_u8", rt.ptr(v), rt.ptr(border), v.shape[0], v.shape[1], v.shape[2], rt.stream())
+    return torch.nonzero(border).contiguous()          # [n, 3] int64 (z, y, x)
+
+
+def hd95_percase(pred, gt, voxelspacing=None):
+    """medpy.metric.binary.hd95(result, reference) for isotropic unit voxels (what val_2D.py:12 passes)."""
+    if voxelspacing is not None:
+        raise NotImplementedError("voxelspacing is not built (the reference's validation never passes it)")
+    pred, gt = np.asarray(pred).astype(bool), np.asarray(gt).astype(bool)
+    if not pred.any():
+        raise RuntimeError("The first supplied array does not contain any binary object.")
+    if not gt.any():
+        raise RuntimeError("The second supplied array does not contain any binary object.")
+    a, b = _surface_points(pred), _surface_points(gt)
+    d = []
+    for p, q in ((a, b), (b, a)):
+        out = torch.empty((p.shape[0],), dtype=torch.int64, device=p.device)
+        rt.call("wsl_nearest_dist2", rt.ptr(p), p.shape[0], rt.ptr(q), q.shape[0], rt.ptr(out), rt.stream())
+        d.append(out)
+    dist, _ = torch.sort(torch.sqrt(torch.cat(d).double()))
+    n = dist.numel()
+    pos = 0.95 * (n - 1)                                # numpy.percentile(..., 95), method 'linear'
+    lo = int(np.floor(pos))
+    hi = min(lo + 1, n - 1)
+    t = pos - lo
+    lo_v, hi_v = float(dist[lo]), float(dist[hi])
+    diff = hi_v - lo_v
+    return hi_v - diff * (1 - t) if t >= 0.5 else lo_v + diff * t
+
+
+def metric_percase(pred, gt):
+    """ref: val_2D.py:7-15 calculate_metric_percase -> (dice, hd95), (0, 0) when nothing is predicted."""
+    pred, gt = np.asarray(pred) > 0, np.asarray(gt) > 0
+    if pred.sum() > 0:
+        return dice_percase(pred, gt), hd95_percase(pred, gt)
+    return 0, 0
 
 
 def _predict_volume(image, net, patch_size, first_output):
@@ -50,7 +95,7 @@ def test_single_volume(image, label, net, classes, patch_size=(256, 256)):
         raise NotImplementedError("2-D slices of a [D,H,W] volume are the built path (the reference's else-branch "
                                   "feeds a single image)")
     prediction = _predict_volume(image, net, patch_size, first_output=False)
-    return [(dice_percase(prediction == i, label == i), float("nan")) for i in range(1, classes)]
+    return [metric_percase(prediction == i, label == i) for i in range(1, classes)]
 
 
 def test_single_volume_cct(image, label, net, classes, patch_size=(256, 256)):
@@ -59,7 +104,7 @@ def test_single_volume_cct(image, label, net, classes, patch_size=(256, 256)):
         raise NotImplementedError("2-D slices of a [D,H,W] volume are the built path (val_2D.py:116 unpacks four "
                                   "outputs in its else-branch, which no 2-D net returns)")
     prediction = _predict_volume(image, net, patch_size, first_output=True)
-    return [(dice_percase(prediction == i, label == i), float("nan")) for i in range(1, classes)]
+    return [metric_percase(prediction == i, label == i) for i in range(1, classes)]
 
 
 test_single_volume.__test__ = False        # (names kept from the reference; not pytest cases)
