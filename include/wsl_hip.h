@@ -86,6 +86,9 @@ int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t
 /* Debug / experiments: which packed-path kernel wsl_conv2d_fwd(wmode 2|3) launches: 2 = lock-step workgroups with a
  * register prefetch (default, fastest measured), 3 = wave-specialised persistent workgroups (wsl_conv3.hip). */
 int wsl_debug_conv_variant(int v);
+/* Force the conv tile shape (rows, columns, output-channel block) wherever it divides the layer; th <= 0 restores the
+ * built-in per-layer table.  Tests use it to run every kernel instantiation at small sizes; env WSL_CONV_PLAN=th,tw,co_t. */
+int wsl_debug_conv_plan(int th, int tw, int co_t);
 /* unet_cct runs its auxiliary decoder (forward and backward) on a library-owned side stream, forked from / joined to the
  * caller's stream with events, so the two independent decoders fill each other's launch gaps and workgroup tails
  * (+5 % step rate).  0 serialises everything on the caller's stream (per-launch timings then do not overlap: what

@@ -58,6 +58,7 @@ _PROTOS = {
     "wsl_conv2d_pack_weights": (i32, [c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "wsl_conv2d_fast_ok": (i32, [PS, PS, c_fp, i64, i32]),
     "wsl_debug_conv_variant": (i32, [i32]),
+    "wsl_debug_conv_plan": (i32, [i32, i32, i32]),
     "wsl_debug_net_concurrent": (i32, [i32]),
     "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
     "wsl_conv2d_wgrad": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),

@@ -223,13 +223,19 @@ struct FwdPlan {
 // 64-pixel-wide tiles only pay for <= 16 output channels; wider layers take 8x32 pixels x as many channels as one
 // workgroup can hold (halves the staging per MFMA); at 16x16 resolution the channel block shrinks until the launch
 // has >= 2 workgroups per CU (a 128-workgroup launch leaves half the chip idle).
+static int g_forced_plan[3] = {-1, 0, 0};   // th, tw, co_t; th < 0: environment not read yet, 0: none
 static FwdPlan fwd_plan(int N, int H, int W, int Co) {
   FwdPlan f;
-  // tuning aid: WSL_CONV_PLAN=th,tw,co_t forces one tile shape wherever it divides the layer (tools/sweep_conv_plans.py)
-  static const char* forced = getenv("WSL_CONV_PLAN");
-  if (forced) {
+  // tuning / test aid: WSL_CONV_PLAN=th,tw,co_t or wsl_debug_conv_plan() force one tile shape wherever it divides the layer
+  if (g_forced_plan[0] < 0) {
+    const char* e = getenv("WSL_CONV_PLAN");
     int th = 0, tw = 0, ct = 0;
-    if (sscanf(forced, "%d,%d,%d", &th, &tw, &ct) == 3 && tw > 0 && W % tw == 0 && ct > 0 && Co % ct == 0) {
+    if (e && sscanf(e, "%d,%d,%d", &th, &tw, &ct) == 3) g_forced_plan[0] = th, g_forced_plan[1] = tw, g_forced_plan[2] = ct;
+    else g_forced_plan[0] = 0;
+  }
+  if (g_forced_plan[0] > 0) {
+    const int th = g_forced_plan[0], tw = g_forced_plan[1], ct = g_forced_plan[2];
+    if (tw > 0 && W % tw == 0 && ct > 0 && Co % ct == 0) {
       f.th = th, f.tw = tw, f.co_t = ct;
       return f;
     }
@@ -545,6 +551,11 @@ int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_
 }  // namespace wsl
 
 using namespace wsl;
+
+extern "C" int wsl_debug_conv_plan(int th, int tw, int co_t) {
+  g_forced_plan[0] = th > 0 ? th : 0, g_forced_plan[1] = tw, g_forced_plan[2] = co_t;
+  return WSL_OK;
+}
 
 extern "C" int wsl_debug_conv_variant(int v) {
   WSL_REQUIRE(v == 2 || v == 3, "debug_conv_variant: 2 (lock-step, default) or 3 (wave-specialised, experimental)");
