@@ -50,6 +50,8 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
     (1, 8, 32, 16, 0, 16, 3, True),
     (2, 16, 16, 32, 32, 32, 3, True),
     (1, 8, 32, 32, 0, 32, 1, True),
+    (1, 8, 32, 32, 0, 64, 3, True),
+    (2, 16, 16, 32, 32, 128, 3, True),
     # the narrow-operand weight-gradient kernel: first convolution (1 -> 16) and 4-class classifier (16 -> 4)
     (2, 16, 64, 1, 0, 16, 3, False),
     (2, 8, 128, 16, 0, 4, 3, False),

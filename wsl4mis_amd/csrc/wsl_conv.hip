@@ -471,7 +471,7 @@ struct WgPlan {
   int th, tw, cb, ib, wk, nsplit, items, tiles_x, tiles_y, co_blocks, ci_blocks;
 };
 // v2 = the prefetching kernels of wsl_conv2.hip: half-height tiles keep the register-held prefetch set small
-static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co, bool v2 = false) {
+static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co, bool v2 = false, bool wide = false) {
   WgPlan g;
   const bool small = (Co <= 16 || Ci <= 16);
   if (small) {
@@ -479,13 +479,14 @@ static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co, bool v2 = false) {
     if (W >= 64) g.th = v2 ? 4 : 8, g.tw = 64; else if (W >= 32) g.th = v2 ? 4 : 8, g.tw = 32; else g.th = v2 ? 8 : 16, g.tw = 16;
   } else {
     g.cb = g.ib = 32, g.wk = 1;
+    if (wide) g.cb = 64;   // two output-channel tiles per wave (split-halo kernel only): 2 resident workgroups per CU
     if (W >= 32) g.th = v2 ? 4 : 8, g.tw = 32; else g.th = v2 ? 8 : 16, g.tw = 16;
   }
   g.tiles_x = cdiv(W, g.tw), g.tiles_y = cdiv(H, g.th);
   g.items = N * g.tiles_x * g.tiles_y;
   g.co_blocks = cdiv(Co, g.cb), g.ci_blocks = cdiv(Ci, g.ib);
   static const int wgs = getenv("WSL_WGRAD_WGS") ? atoi(getenv("WSL_WGRAD_WGS")) : 768;   // 3 resident workgroups x 256 CUs
-  int want = wgs / (g.co_blocks * g.ci_blocks);
+  int want = (wide ? 512 : wgs) / (g.co_blocks * g.ci_blocks);
   if (want < 1) want = 1;
   g.nsplit = g.items < want ? g.items : want;
   return g;
@@ -545,6 +546,7 @@ int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
               int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
               void* stream);
 bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, int W);
+bool wgrad2s_wide_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks);
 int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                   int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
                   int tiles_y, int co_blocks, int ci_blocks, void* stream);
@@ -628,8 +630,10 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
 
 extern "C" size_t wsl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co, int ks) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
-  const WgPlan g = wgrad_plan(N, H, W, Ci, Co), g2 = wgrad_plan(N, H, W, Ci, Co, true);
-  return sizeof(float) * (size_t)(g.nsplit > g2.nsplit ? g.nsplit : g2.nsplit) * ((size_t)ks * ks * Co * Ci + Co);
+  const WgPlan g = wgrad_plan(N, H, W, Ci, Co), g2 = wgrad_plan(N, H, W, Ci, Co, true), g3 = wgrad_plan(N, H, W, Ci, Co, true, true);
+  int ns = g.nsplit > g2.nsplit ? g.nsplit : g2.nsplit;
+  if (g3.nsplit > ns) ns = g3.nsplit;
+  return sizeof(float) * (size_t)ns * ((size_t)ks * ks * Co * Ci + Co);
 }
 
 extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db,
@@ -650,7 +654,8 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   const int Ci = p.in.Ci;
   WSL_REQUIRE(dy_bs >= (int64_t)Co * H * W, "conv2d_wgrad: dy batch stride too small");
   const bool v2 = wgrad2_eligible(p.in.a, &p.in.b, dy, dy_bs, W);
-  const WgPlan g = wgrad_plan(N, H, W, Ci, Co, v2);
+  const bool wide = v2 && wgrad2s_wide_ok(p.in.a, &p.in.b, H, W, Co, ks);
+  const WgPlan g = wgrad_plan(N, H, W, Ci, Co, v2, wide);
   const size_t need = wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks);
   if (ws_bytes < need) {
     set_error("conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);

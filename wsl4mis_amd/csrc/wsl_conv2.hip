@@ -1120,7 +1120,9 @@ struct WgradSCfg {
   static constexpr int RED_FLOATS = (WK > 1) ? 4 * 64 * ((KK + 1) * 4) : 0;
   static constexpr int MAIN_FLOATS = DY_FLOATS + A_FLOATS > RED_FLOATS ? DY_FLOATS + A_FLOATS : RED_FLOATS;
   static constexpr size_t SMEM = sizeof(float) * (MAIN_FLOATS + 2 * IB);
-  static_assert(PD <= 256 && PA <= 256 && PAIRS == WP && TH % WK == 0, "split-halo wgrad tile shape");
+  // PP channel pairs per wave: they share the input-channel tile (one B operand set feeds PP x 9 MFMAs)
+  static_assert(PD <= 256 && PA <= 256 && PAIRS % WP == 0 && (PP == 1 || (WK == 1 && CBT % PP == 0)) && TH % WK == 0,
+                "split-halo wgrad tile shape");
 };
 
 template <int KS, int TH, int TW, int CB, int IB, int WK>
@@ -1157,10 +1159,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
   const int aloff = ga * C::PLA + aty * C::ROWP + atx4 * 4;
   const int64_t dstride = (int64_t)C::GD * HW, astride = (int64_t)C::GA * HW;
 
-  v4f acc[C::KK];
-  v4f accb = v4f{0.f, 0.f, 0.f, 0.f};
+  v4f acc[C::PP][C::KK];
+  v4f accb[C::PP];
 #pragma unroll
-  for (int t = 0; t < C::KK; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < C::PP; ++j) {
+    accb[j] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C::KK; ++t) acc[j][t] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
   const bool want_db = (ib == 0) && (p.part_db != nullptr);
   const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
 
@@ -1241,7 +1247,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
 
   if (it0 < it1) issue();
   __syncthreads();  // BN table visible
-  const int cot = wp_ / C::IBT, cit = wp_ % C::IBT;
+  const int cot = (wp_ / C::IBT) * C::PP, cit = wp_ % C::IBT;   // this wave: output-channel tiles cot .. cot+PP-1, one ci tile
   const float* dyp = dy_t + (cot * 16 + (lane & 15)) * C::PLD + (lane >> 4);
   const float* ap = a_t + (cit * 16 + (lane & 15)) * C::PLA + (lane >> 4) + (C::PADL - C::P);
   const bool dbw = want_db && cit == 0;
@@ -1250,11 +1256,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
     __syncthreads();
     if (item + 1 < it1 && !(p.ablate & 2)) issue();   // prefetch the next tile; in flight during the MFMA loop
     constexpr int RW = TH / WK, NX = TW / 4, NSTEP = RW * NX;
-    float avv[2][KS], bvv[2][KS];
+    float avv[2][C::PP][KS], bvv[2][KS];
     auto load = [&](int st, int buf) {   // step st = (row, group of 4 pixels)
       const int r = wk * RW + st / NX, x4 = st % NX;
 #pragma unroll
-      for (int ky = 0; ky < KS; ++ky) avv[buf][ky] = dyp[(r + 2 * C::P - ky) * TW + x4 * 4];   // dy shifted by -(ky-P) rows
+      for (int j = 0; j < C::PP; ++j)
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)   // dy shifted by -(ky-P) rows
+          avv[buf][j][ky] = dyp[j * 16 * C::PLD + (r + 2 * C::P - ky) * TW + x4 * 4];
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) bvv[buf][kx] = ap[r * C::ROWP + x4 * 4 + kx];           // a shifted by +(kx-P) cols
     };
@@ -1264,9 +1273,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
     for (int st = 0; st < NSTEP; ++st) {   // operands of step st+1 are read before the MFMAs of step st issue
       const int cur = st & 1;
       if (st + 1 < NSTEP && !(p.ablate & 8)) load(st + 1, cur ^ 1);
-      if (dbw) accb = WSL_MFMA16(avv[cur][C::P], 1.0f, accb);
 #pragma unroll
-      for (int t = 0; t < C::KK; ++t) acc[t] = WSL_MFMA16(avv[cur][t / KS], bvv[cur][t % KS], acc[t]);
+      for (int j = 0; j < C::PP; ++j) {
+        if (dbw) accb[j] = WSL_MFMA16(avv[cur][j][C::P], 1.0f, accb[j]);
+#pragma unroll
+        for (int t = 0; t < C::KK; ++t) acc[j][t] = WSL_MFMA16(avv[cur][j][t / KS], bvv[cur][t % KS], acc[j][t]);
+      }
       WSL_SCHED_BARRIER();
     }
     __syncthreads();
@@ -1279,9 +1291,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
 #pragma unroll
     for (int t = 0; t < C::KK; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mine[t * 4 + r] = acc[t][r];
+      for (int r = 0; r < 4; ++r) mine[t * 4 + r] = acc[0][t][r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mine[C::KK * 4 + r] = accb[r];
+    for (int r = 0; r < 4; ++r) mine[C::KK * 4 + r] = accb[0][r];
     __syncthreads();
     if (wk == 0) {
 #pragma unroll
@@ -1290,19 +1302,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
         for (int r = 0; r < 4; ++r) {
           float sum = 0.f;
           for (int k = 0; k < WK; ++k) sum += red[((k * C::WP + wp_) * 64 + lane) * PER + t * 4 + r];
-          if (t < C::KK) acc[t][r] = sum; else accb[r] = sum;
+          if (t < C::KK) acc[0][t][r] = sum; else accb[0][r] = sum;
         }
     }
   }
   if (wk == 0) {
     const int ci = ci0 + cit * 16 + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co0 + cot * 16 + (lane >> 4) * 4 + r;
+    for (int j = 0; j < C::PP; ++j)
 #pragma unroll
-      for (int t = 0; t < C::KK; ++t) p.part_dw[(((int64_t)split * C::KK + t) * p.Co + co) * Ci + ci] = acc[t][r];
-      if (dbw && (lane & 15) == 0) p.part_db[(int64_t)split * p.Co + co] = accb[r];
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + (cot + j) * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+        for (int t = 0; t < C::KK; ++t) p.part_dw[(((int64_t)split * C::KK + t) * p.Co + co) * Ci + ci] = acc[j][t][r];
+        if (dbw && (lane & 15) == 0) p.part_db[(int64_t)split * p.Co + co] = accb[j][r];
+      }
   }
 }
 
@@ -1369,6 +1383,21 @@ bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t 
   return conv2_eligible(a, b, nullptr, 0, W, 0) && aligned16(dy) && !(dy_bs & 3);
 }
 
+// 64 output channels x 32 input channels per workgroup (wgrad_mfma2s_kernel with two co tiles per wave): non-small layers
+// with Co % 64 == 0 that satisfy the lean contract.  WSL_WGRAD_CB64=0 keeps the 32 x 32 blocking.
+bool wgrad2s_wide_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks) {
+  static const bool on = getenv("WSL_WGRAD_CB64") && atoi(getenv("WSL_WGRAD_CB64")) != 0;
+  static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
+  static const bool split_on = !(getenv("WSL_WGRAD_SPLIT") && atoi(getenv("WSL_WGRAD_SPLIT")) == 0);
+  if (!on || !lean_on || !split_on) return false;
+  const int bC = b ? b->C : 0, Ci = a.C + bC;
+  if (Co <= 16 || Ci <= 16 || (Co % 64) || (Ci % 32) || (bC > 0 && (a.C % 32))) return false;
+  const int th = W >= 32 ? 4 : 8, tw = W >= 32 ? 32 : 16;
+  if ((H % th) || (W % tw) || (ks != 1 && ks != 3)) return false;
+  const int64_t span = (int64_t)(a.C > bC ? a.C : bC) * H * W;
+  return span < (int64_t(1) << 31) && (int64_t)Co * H * W < (int64_t(1) << 31);
+}
+
 int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                   int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
                   int tiles_y, int co_blocks, int ci_blocks, void* stream) {
@@ -1380,6 +1409,12 @@ int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
   static const int ablate = getenv("WSL_WGRAD_ABLATE") ? atoi(getenv("WSL_WGRAD_ABLATE")) : 0;
   p.ablate = ablate;
+  if (cb == 64 && ib == 32) {   // two output-channel tiles per wave: only the split-halo kernel is built for this blocking
+    if (ks == 3 && th == 4 && tw == 32) return launch_wgrad2s<3, 4, 32, 64, 32, 1>(p, ci_blocks, stream);
+    if (ks == 3 && th == 8 && tw == 16) return launch_wgrad2s<3, 8, 16, 64, 32, 1>(p, ci_blocks, stream);
+    if (ks == 1 && th == 4 && tw == 32) return launch_wgrad2s<1, 4, 32, 64, 32, 1>(p, ci_blocks, stream);
+    if (ks == 1 && th == 8 && tw == 16) return launch_wgrad2s<1, 8, 16, 64, 32, 1>(p, ci_blocks, stream);
+  }
 #define WSL_CASE(KS_, TH_, TW_, CB_, IB_, WK_) \
   if (ks == KS_ && th == TH_ && tw == TW_ && cb == CB_ && ib == IB_)  \
     return launch_wgrad2<KS_, TH_, TW_, CB_, IB_, WK_>(p, ci_blocks, stream);
