@@ -394,6 +394,39 @@ int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* 
   return check_launch("conv_cls_kernel");
 }
 
+// Pure MFMA stream (no memory): the practical f32 matrix ceiling of the machine at its sustained clock, per MFMA shape.
+// shape 0: 16x16x4 (16 independent accumulators), 1: 32x32x2 (4 accumulators), 2: 4x4x1 (16 accumulators).
+#ifndef WSL_HOST_EMUL
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_stream_kernel(float* out, int iters) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  typedef float v16 __attribute__((ext_vector_type(16)));
+  const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+  float r = 0.f;
+  if (SHAPE == 1) {
+    v16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 4; ++i) r += acc[i][0];
+  } else {
+    v4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = v4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        acc[i] = SHAPE == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0) : __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 16; ++i) r += acc[i][0];
+  }
+  if (r == 123.456f) out[0] = r;
+}
+#endif
+
 // Operand-layout probe of the 4x4x1 (16 blocks) f32 MFMA used by the classifier forward: d[lane][r] for given a, b.
 #ifndef WSL_HOST_EMUL
 __global__ void mfma4_probe_kernel(const float* a, const float* b, float* d) {
@@ -405,6 +438,18 @@ __global__ void mfma4_probe_kernel(const float* a, const float* b, float* d) {
 #endif
 
 }  // namespace wsl
+
+extern "C" int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* out, void* stream) {
+#ifndef WSL_HOST_EMUL
+  if (shape == 0) WSL_LAUNCH(wsl::mfma_stream_kernel<0>, dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 1) WSL_LAUNCH(wsl::mfma_stream_kernel<1>, dim3(blocks), dim3(256), 0, stream, out, iters);
+  else WSL_LAUNCH(wsl::mfma_stream_kernel<2>, dim3(blocks), dim3(256), 0, stream, out, iters);
+  return wsl::check_launch("mfma_stream_kernel");
+#else
+  (void)shape, (void)blocks, (void)iters, (void)out, (void)stream;
+  return WSL_EUNSUPPORTED;
+#endif
+}
 
 extern "C" int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, void* stream) {
 #ifndef WSL_HOST_EMUL
