@@ -11,7 +11,7 @@ step on one batch of 64 slices per GPU, inputs resident in HBM.  Prints ONE JSON
 (HIP events around every launch of the dominant kernel family, recorded on the launch stream) and, at N=1, the
 `cpu_baseline` (the oracle's torch-CPU restatement of the same step, timed on this box's host cores).
 
-unet_cct runs its two decoders on two streams (+5 % step rate), so in the timed region launches of the dominant kernel
+unet_cct runs its two decoders on two streams (+5 % step rate; mean teacher: the teacher's forward), so in the timed region launches of the dominant kernel
 overlap each other and a per-launch duration no longer measures the kernel.  The `roofline` object is therefore taken
 from a short second segment of the same workload in the same process with the decoders serialised
 (`wsl_debug_net_concurrent(0)`), where launches do not overlap; the timed region's own (overlapping) per-launch figures
@@ -143,9 +143,11 @@ def main():
     L = _lib.lib()
     if args.serial_decoders:
         L.wsl_debug_net_concurrent(0)
+        eng.concurrent = False
     for _ in range(args.warmup):
         eng.step(x, lab, random.random() + 1e-10)
-    overlapped = args.net == "unet_cct" and not args.serial_decoders and os.environ.get("WSL_NET_CONCURRENT") != "0"
+    overlapped = (args.net == "unet_cct" or args.loss == "mean_teacher") and not args.serial_decoders and \
+        os.environ.get("WSL_NET_CONCURRENT") != "0"
     # per-launch HIP events cost ~2 % of the step rate: when the roofline comes from its own serialised segment anyway
     # (overlapped run) the timed region stays uninstrumented unless --prof-timed asks for its overlapping figures too
     prof_timed = not args.no_prof and (not overlapped or args.prof_timed)
@@ -223,6 +225,7 @@ def main():
                 timed = {k: roof[k] for k in ("achieved", "frac", "launches", "avg_launch_us", "all_mfma_kernels_tflops")}
             seg = max(1, min(args.steps, 5))
             L.wsl_debug_net_concurrent(0)
+            eng.concurrent = False
             eng.step(x, lab, random.random() + 1e-10)
             L.wsl_prof_enable(1)
             torch.cuda.synchronize()
@@ -233,6 +236,7 @@ def main():
             seg_ms = 1e3 * (time.perf_counter() - ts) / seg
             rows2, fams = report()
             L.wsl_debug_net_concurrent(1)
+            eng.concurrent = True
             roof = roofline_of(rows2, seg)
             if roof:
                 roof["measured"] = (f"{seg} extra steps of the same workload right after the timed region, two decoder streams "

@@ -17,6 +17,7 @@ decoders' slice as soon as the decoder backward has been enqueued (it overlaps t
 encoder's slice.  Losses stay on the device; `losses()` is the only host sync.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -55,6 +56,8 @@ class TrainEngine:
             dist.broadcast(self.model._buf_arena, src=0)
         self._bufs = {}
         self.teacher = None
+        self._tstream, self._zt = None, None
+        self.concurrent = os.environ.get("WSL_NET_CONCURRENT") != "0"   # side streams (teacher forward); see DESIGN 4
         if loss == "mean_teacher":
             if self.dual:
                 raise _lib.WslError("'mean_teacher' is defined for the single-decoder unet")
@@ -95,14 +98,38 @@ class TrainEngine:
         self.forward_backward(x, label_u8, beta, noise)
         self.optimizer_step()
 
+    def _teacher_forward(self, x, noise):
+        if noise is None:                                  # ustm_2D.py:125-127 / train_mean_teacher_2D.py:147-149
+            noise = torch.clamp(torch.randn_like(x) * 0.1, -0.2, 0.2)
+        with torch.no_grad():
+            return self.teacher._run_forward(x + noise)[0]
+
+    def _start_teacher(self, x, noise):
+        """The teacher's forward is independent of the student's: on the GPU it runs on a side stream, forked here (before
+        the student forward is enqueued) and joined where its logits are consumed."""
+        if x.device.type != "cuda" or not self.concurrent:
+            self._zt = None
+            return
+        if self._tstream is None:
+            self._tstream = torch.cuda.Stream(device=x.device)
+        cur = torch.cuda.current_stream()
+        self._tstream.wait_stream(cur)
+        with torch.cuda.stream(self._tstream):
+            self._zt = self._teacher_forward(x, noise)
+        self._zt.record_stream(cur)
+
+    def _teacher_logits(self, x, noise):
+        if self._zt is None:
+            return self._teacher_forward(x, noise)
+        torch.cuda.current_stream().wait_stream(self._tstream)
+        zt, self._zt = self._zt, None
+        return zt
+
     def _mean_teacher_losses(self, x, label_u8, z, t, noise):
         """dz of pCE + tv + consistency for the student logits z; teacher logits from x + noise (no gradient)."""
         m, N, H, W = self.model, x.shape[0], x.shape[2], x.shape[3]
         HW, C_ = H * W, self.model.class_num
-        if noise is None:                                  # ustm_2D.py:125-127 / train_mean_teacher_2D.py:147-149
-            noise = torch.clamp(torch.randn_like(x) * 0.1, -0.2, 0.2)
-        with torch.no_grad():
-            zt = self.teacher._run_forward(x + noise)[0]
+        zt = self._teacher_logits(x, noise)                # usually already in flight on the side stream
         nl = rt.L().wsl_loss_ws_bytes(N, C_, HW)
         lws = rt.workspace("loss", nl)
         lo = self.loss_out
@@ -127,6 +154,8 @@ class TrainEngine:
         HW = H * W
         t = self._tensors(N, H, W)
         m.train()
+        if self.loss_kind == "mean_teacher":
+            self._start_teacher(x, noise)
         outs = m._run_forward(x, keep_for_backward=True)
         z1, z2 = outs[0], (outs[1] if self.dual else None)
         L = rt.L()
