@@ -197,6 +197,10 @@ int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* loss, float* 
                             void* ws, size_t ws_bytes, void* stream);
 
 /* dst += k * src (sums the logit-gradients of several loss terms). */
+/* entropy_loss(p, C) = mean over pixels of -sum_c p log(p + 1e-6), divided by log(C) (ref: utils/losses.py:30-36);
+ * dp = gscale * dloss/dp.  p is [N,C,HW] (already a softmax). */
+int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float gscale, int N, int C, int HW, void* ws,
+                        size_t ws_bytes, void* stream);
 int wsl_axpy(float* dst, const float* src, float k, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ optimiser

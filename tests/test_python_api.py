@@ -214,6 +214,24 @@ def run_curve(steps):
     return np.array(got), g, eng
 
 
+def test_entropy_loss_kernel(mode):
+    """entropy_loss (utils/losses.py:30-36) as one kernel: value and gradient against the plain fp32 torch expression"""
+    import math
+    from wsl4mis_amd.utils import losses
+    rng = np.random.default_rng(21)
+    z = torch.from_numpy(rng.standard_normal((3, 4, 9, 11)).astype(np.float32))
+    p_ref = torch.softmax(z, 1).requires_grad_()
+    ref = torch.mean(-1 * torch.sum(p_ref * torch.log(p_ref + 1e-6), dim=1) / math.log(4))
+    ref.backward()
+    p = p_ref.detach().clone().to(dev()).requires_grad_()
+    got = losses.entropy_loss(p, C=4)
+    (2.0 * got).backward()
+    assert abs(got.item() - ref.item()) < 1e-6
+    assert rel_err(p.grad.cpu().numpy(), 2.0 * p_ref.grad.numpy()) < 1e-5
+    with pytest.raises(ValueError):
+        losses.entropy_loss(p, C=2)
+
+
 def test_engine_loss_curve_start(mode):
     """first optimiser steps of the fused engine vs the reference loop (SGD + poly LR incl. its one-step lag)."""
     steps = 1 if mode == "emul" else 12

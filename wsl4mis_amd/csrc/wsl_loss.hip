@@ -8,6 +8,8 @@
 //   softmax_mse_loss                    ref: utils/losses.py:65-82
 // Every reduction is two-stage: per-workgroup partials, then a single-workgroup finalize that merges them in a fixed
 // order in fp64 and does the scalar arithmetic on the device (no host sync, no float atomics).
+#include <math.h>
+
 #include "wsl_rt.h"
 
 namespace wsl {
@@ -628,6 +630,24 @@ __global__ __launch_bounds__(256) void softmax_mse_kernel(const float* a, const 
   write_partials<1>(v, part, red);
 }
 
+// ------------------------------------------------------------------------------------------------ entropy minimisation
+// entropy_loss(p, C) = mean_px( -sum_c p log(p + 1e-6) ) / log(C)   (ref: utils/losses.py:30-36; used on softmax(outputs)
+// with weight 0.1 by train_weakly_supervised_pCE_Entropy_Mini_2D.py:99-102).  d/dp_c = -(log(p_c + 1e-6) + p_c/(p_c + 1e-6)) * k.
+__global__ __launch_bounds__(256) void entropy_kernel(const float* p, int C, int HW, int64_t P, float k, float* dp,
+                                                      float* part) {
+  __shared__ float red[4];
+  float v[1] = {0.f};
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, q = i - n * HW, base = n * C * HW + q;
+    for (int c = 0; c < C; ++c) {
+      const float x = p[base + (int64_t)c * HW], xe = x + 1e-6f, lg = logf(xe);
+      v[0] = fmaf(-x, lg, v[0]);
+      dp[base + (int64_t)c * HW] = -(lg + x / xe) * k;
+    }
+  }
+  write_partials<1>(v, part, red);
+}
+
 // ------------------------------------------------------------------------------------------------ mixed probabilities
 // y = beta*softmax(z1) + (1-beta)*softmax(z2): the prediction the dual-branch + GatedCRF composition regularises
 // (ref: train_ACDC_scribblevc.py:171-206).  z2 == NULL: y = softmax(z1).
@@ -850,6 +870,20 @@ extern "C" int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* lo
   WSL_LAUNCH(softmax_mse_kernel, dim3(nb), dim3(kThreads), 0, stream, a, b, C, HW, P, (float)(gscale / numel), da, part);
   WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, 1, 1.0 / numel, loss);
   return check_launch("softmax_mse_fwd_bwd");
+}
+
+extern "C" int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float gscale, int N, int C, int HW, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(p && loss && dp && N > 0 && C > 1 && C <= kMaxC && HW > 0, "entropy: bad args");
+  const int HW_ = HW;
+  WSL_WS_OK("entropy_fwd_bwd");
+  const int64_t P = (int64_t)N * HW;
+  const double norm = 1.0 / ((double)P * log((double)C));
+  const int nb = grid_for(P);
+  float* part = static_cast<float*>(ws);
+  WSL_LAUNCH(entropy_kernel, dim3(nb), dim3(kThreads), 0, stream, p, C, HW, P, (float)(gscale * norm), dp, part);
+  WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, 1, norm, loss);
+  return check_launch("entropy_fwd_bwd");
 }
 
 extern "C" int wsl_mixprob_fwd(const float* z1, const float* z2, double beta, float* y, int N, int C, int HW, void* stream) {

@@ -276,8 +276,25 @@ def softmax_mse_loss(input_logits, target_logits, sigmoid=False):
     return (_Softmax.apply(input_logits) - _Softmax.apply(target_logits).detach()) ** 2
 
 
+class _Entropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, C):
+        p = rt.f32c(p, "p")
+        N, Cn, HW = p.shape[0], p.shape[1], p[0, 0].numel()
+        if int(C) != Cn:
+            raise ValueError(f"entropy_loss: C={C} but p has {Cn} channels")
+        ws, n = _lws(N, Cn, HW)
+        loss, dp = _scalar(p.device), torch.empty_like(p)
+        rt.call("wsl_entropy_fwd_bwd", rt.ptr(p), rt.ptr(loss), rt.ptr(dp), 1.0, N, Cn, HW, rt.ptr(ws), n, rt.stream())
+        ctx.save_for_backward(dp)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return dp * g, None
+
+
 def entropy_loss(p, C=2):
-    """mean(-sum_c p log(p+1e-6)) / log(C)  (ref: utils/losses.py:30-36).  Composed from device tensor ops: it is a
-    "next" row of SURVEY 8f (not on the named configs) and has no dedicated kernel yet."""
-    y1 = -1 * torch.sum(p * torch.log(p + 1e-6), dim=1) / math.log(C)
-    return torch.mean(y1)
+    """mean(-sum_c p log(p+1e-6)) / log(C)  (ref: utils/losses.py:30-36), one fused kernel for value and gradient."""
+    return _Entropy.apply(p, C)
