@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""End-to-end trainer on the reference's ACDC layout, built only from this package's pieces -- the flow of
+code/train_weakly_supervised_pCE_WSL4MIS (ours_proposed) / ..._pCE_GatedCRFLoss_2D.py, one process per GPU:
+
+    BaseDataSets(h5lite) -> BatchRandomGenerator (device augmentation) -> TrainEngine.step -> val_2D metrics
+
+    python examples/train_acdc_scribble.py --root_path <.../data/ACDC> --fold fold1 --max_iterations 60000
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_acdc_scribble.py ...
+
+Each rank draws its own batches (independent shuffles), gradients are averaged by the engine."""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wsl4mis_amd import val_2D  # noqa: E402
+from wsl4mis_amd.dataloaders.dataset import BaseDataSets, BatchRandomGenerator  # noqa: E402
+from wsl4mis_amd.engine import TrainEngine  # noqa: E402
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--root_path", required=True)
+    ap.add_argument("--fold", default="fold1")
+    ap.add_argument("--sup_type", default="scribble")
+    ap.add_argument("--model", default="unet_cct", choices=["unet_cct", "unet"])
+    ap.add_argument("--loss", default="ours_proposed", choices=["ours_proposed", "pce", "pce_gatedcrf"])
+    ap.add_argument("--num_classes", type=int, default=4)
+    ap.add_argument("--max_iterations", type=int, default=60000)
+    ap.add_argument("--batch_size", type=int, default=12)
+    ap.add_argument("--base_lr", type=float, default=0.01)
+    ap.add_argument("--patch_size", type=int, nargs=2, default=[256, 256])
+    ap.add_argument("--seed", type=int, default=2022)
+    ap.add_argument("--val_every", type=int, default=200)
+    ap.add_argument("--labeled_type", default="labeled")
+    args = ap.parse_args(argv)
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    random.seed(args.seed), np.random.seed(args.seed + rank), torch.manual_seed(args.seed)
+    train = BaseDataSets(base_dir=args.root_path, split="train", fold=args.fold, sup_type=args.sup_type,
+                         labeled_type=args.labeled_type)
+    val = BaseDataSets(base_dir=args.root_path, split="val", fold=args.fold)
+    if len(train) == 0:
+        raise SystemExit("no training slices for this fold under " + args.root_path)
+    aug = BatchRandomGenerator(args.patch_size)
+    eng = TrainEngine(args.model, 1, args.num_classes, base_lr=args.base_lr, max_iterations=args.max_iterations,
+                      loss=args.loss)
+    torch.manual_seed(args.seed + 1000 * rank)          # dropout masks differ per rank; beta is shared (python RNG)
+    order = np.random.RandomState(args.seed + rank)
+    it, best, history = 0, 0.0, []
+    while it < args.max_iterations:
+        perm = order.permutation(len(train))
+        for b in range(0, len(perm), args.batch_size):
+            idx = perm[b:b + args.batch_size]
+            if len(idx) < 2:                            # BatchNorm needs more than one slice
+                continue
+            image, label = aug([train[int(i)] for i in idx])
+            eng.step(image, label, random.random() + 1e-10)
+            it += 1
+            if rank == 0 and (it % 20 == 0 or it == 1):
+                o = eng.losses()
+                history.append((it, o["loss"]))
+                print("iteration %d : " % it + ", ".join(f"{k} {v:.4f}" for k, v in o.items()), flush=True)
+            if rank == 0 and len(val) and it % args.val_every == 0:
+                m = np.array([[d for d, _ in val_2D.test_single_volume_cct(v["image"], v["label"], eng.model, args.num_classes,
+                                                                          args.patch_size)] for v in (val[i] for i in range(len(val)))])
+                best = max(best, float(m.mean()))
+                print("iteration %d : mean_dice %.4f (best %.4f)" % (it, m.mean(), best), flush=True)
+                eng.model.train()
+            if it >= args.max_iterations:
+                break
+    return history
+
+
+if __name__ == "__main__":
+    main()

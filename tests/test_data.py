@@ -1,4 +1,5 @@
 """Data path: the batched device augmentation equals the reference's numpy/scipy pipeline bit for bit."""
+import os
 import random
 
 import numpy as np
@@ -102,3 +103,72 @@ def test_validation_metrics_match_the_medpy_algorithm(mode):
     assert val_2D.metric_percase(np.zeros((3, 8, 8), bool), np.ones((3, 8, 8), bool)) == (0, 0)
     with pytest.raises(RuntimeError, match="second supplied array"):
         val_2D.metric_percase(np.ones((2, 8, 8), bool), np.zeros((2, 8, 8), bool))
+
+
+ACDC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "acdc")
+
+
+def test_h5lite_reads_the_reference_files():
+    """five files of the reference's shipped ACDC data (tests/golden/acdc): every dataset decodes to the recorded digest;
+    the decode is pinned by the data itself -- scribble pixels carry the dense label's class, images are min-max
+    normalised (tools/acdc_stats.py runs the same checks over all 2102 files and reproduces SURVEY 8d's statistics)"""
+    import hashlib
+    import json
+    from wsl4mis_amd.dataloaders import h5lite
+    exp = json.load(open(os.path.join(ACDC, "expected.json")))
+    assert len(exp) == 5
+    for name, dsets in exp.items():
+        sub = "ACDC_training_slices" if "slice" in name else "ACDC_training_volumes"
+        with h5lite.File(os.path.join(ACDC, sub, name)) as f:
+            assert f.keys() == ["image", "label", "scribble"] and "image" in f
+            arr = {k: f[k][:] for k in f.keys()}
+            with pytest.raises(KeyError):
+                f["nope"]
+        for k, e in dsets.items():
+            a = arr[k]
+            assert list(a.shape) == e["shape"] and str(a.dtype) == e["dtype"]
+            assert hashlib.sha1(a.tobytes()).hexdigest() == e["sha1"], (name, k)
+        img, lab, scr = arr["image"], arr["label"], arr["scribble"]
+        assert img.min() >= 0.0 and img.max() == 1.0 and set(np.unique(lab)) <= {0, 1, 2, 3} and set(np.unique(scr)) <= {0, 1, 2, 3, 4}
+        m = scr != 4
+        assert 0.002 < m.mean() < 0.05 and (scr[m] == lab[m]).mean() > 0.999
+    with pytest.raises(h5lite.H5Error):
+        h5lite.File(os.path.join(ACDC, "expected.json"))
+
+
+def test_base_datasets_folds_and_samples(mode):
+    from wsl4mis_amd.dataloaders import dataset
+    tr = dataset.BaseDataSets(base_dir=ACDC, split="train", fold="fold1", sup_type="scribble",
+                              transform=dataset.RandomGenerator((64, 64)))
+    assert sorted(tr.sample_list) == ["patient030_frame01_slice_9.h5"]            # patient010 is a fold-1 test patient
+    un = dataset.BaseDataSets(base_dir=ACDC, split="train", fold="fold1", labeled_type="unlabeled")
+    assert sorted(un.sample_list) == ["patient094_frame01_slice_9.h5", "patient094_frame07_slice_9.h5"]
+    f2 = dataset.BaseDataSets(base_dir=ACDC, split="train", fold="fold2")
+    assert sorted(f2.sample_list) == ["patient010_frame13_slice_9.h5"]            # fold 2 tests patients 21-40
+    random.seed(1), np.random.seed(2)
+    s = tr[0]
+    assert s["idx"] == "patient030" and tuple(s["image"].shape) == (1, 64, 64) and s["label"].dtype == torch.uint8
+    assert set(s["label"].unique().tolist()) <= {0, 1, 2, 3, 4} and 4 in s["label"].unique().tolist()
+    val = dataset.BaseDataSets(base_dir=ACDC, split="val", fold="fold3")
+    assert val.sample_list == ["patient041_frame11.h5"] and len(val) == 1
+    v = val[0]
+    assert v["image"].shape == v["label"].shape == (6, 224, 154) and v["label"].dtype == np.uint8 and v["idx"] == "patient041"
+    assert len(dataset.BaseDataSets(base_dir=ACDC, split="val", fold="fold1")) == 0
+    with pytest.raises(ValueError):
+        dataset.BaseDataSets(base_dir=ACDC, fold="fold9")
+
+
+@pytest.mark.gpu
+def test_example_trainer_runs_on_the_fixture_files():
+    """data files -> h5lite -> device augmentation -> engine -> validation metrics, end to end on the GPU"""
+    import importlib.util
+    from wsl4mis_amd import _lib, runtime
+    _lib._reset_for_tests()
+    runtime._ws_cache.clear()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_acdc", os.path.join(root, "examples", "train_acdc_scribble.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(["--root_path", ACDC, "--fold", "fold3", "--labeled_type", "unlabeled", "--max_iterations", "40",
+                     "--batch_size", "3", "--patch_size", "64", "64", "--val_every", "20"])
+    assert len(hist) == 3 and all(np.isfinite(l) for _, l in hist) and hist[-1][1] < hist[0][1]

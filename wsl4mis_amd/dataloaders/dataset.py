@@ -7,15 +7,66 @@ gather kernel for a whole batch of slices of different native sizes (`wsl_augmen
 step of the reference is a nearest-neighbour index map, so the composition is exact -- results equal numpy/scipy bit for
 bit (tests/test_data.py).  No CPU fallback: without the HIP library these calls raise.
 
-Not mirrored (out of this round): HDF5 ingest (`BaseDataSets`; h5py is not in the image), `TwoStreamBatchSampler`."""
+`BaseDataSets` mirrors the fold-aware dataset of `dataset_semi.py:17-127` (same constructor, same file selection, same
+sample dicts) on top of `h5lite` (h5py is not in the image).  Not mirrored: `TwoStreamBatchSampler`."""
+import os
 import random
 
 import numpy as np
 import torch
 from scipy import special
 
+from torch.utils.data import Dataset
+
 from .. import _lib
 from .. import runtime as rt
+from . import h5lite
+
+
+class BaseDataSets(Dataset):
+    """ACDC slices (train) / volumes (val) of one cross-validation fold (ref: dataset_semi.py:17-127).
+
+    Folds are blocks of 20 patients (fold k tests patients 20(k-1)+1 .. 20k); the "labeled" patients are
+    patient010, 020, ..., 100 among the fold's training patients, the rest are "unlabeled"; train samples are the slice
+    files whose name starts with a selected patient id, read as {'image', 'label' = file[sup_type]} and passed through
+    `transform`; val samples are whole volumes {'image', 'label'} as numpy arrays.  'idx' carries the patient id."""
+
+    FOLDS = ("fold1", "fold2", "fold3", "fold4", "fold5")
+
+    def __init__(self, base_dir=None, num=4, labeled_type="labeled", split="train", transform=None, fold="fold1",
+                 sup_type="label"):
+        if fold not in self.FOLDS:
+            raise ValueError(f"unknown fold {fold!r} (the reference returns 'ERROR KEY' here and fails later)")
+        self._base_dir, self.split, self.sup_type, self.transform = base_dir, split, sup_type, transform
+        self.num, self.labeled_type = num, labeled_type
+        k = self.FOLDS.index(fold)
+        test_ids = ["patient{:0>3}".format(i) for i in range(20 * k + 1, 20 * k + 21)]
+        train_ids = [p for p in ("patient{:0>3}".format(i) for i in range(1, 101)) if p not in test_ids]
+        labeled = [p for p in ("patient{:0>3}".format(10 * i) for i in range(1, 11)) if p in train_ids]
+        if split == "train":
+            files = os.listdir(os.path.join(base_dir, "ACDC_training_slices"))
+            chosen = labeled if labeled_type == "labeled" else [p for p in train_ids if p not in labeled]
+        elif split == "val":
+            files = os.listdir(os.path.join(base_dir, "ACDC_training_volumes"))
+            chosen = test_ids
+        else:
+            files, chosen = [], []
+        self.sample_list = [f for pid in chosen for f in files if f.startswith(pid)]     # per patient, listing order
+
+    def __len__(self):
+        return len(self.sample_list)
+
+    def __getitem__(self, idx):
+        case = self.sample_list[idx]
+        sub = "ACDC_training_slices" if self.split == "train" else "ACDC_training_volumes"
+        with h5lite.File(os.path.join(self._base_dir, sub, case)) as f:
+            image = f["image"][:]
+            label = f[self.sup_type if self.split == "train" else "label"][:]
+        sample = {"image": image, "label": label}
+        if self.split == "train" and self.transform is not None:
+            sample = self.transform(sample)
+        sample["idx"] = case.split("_")[0]
+        return sample
 
 
 def draw_params(label_np):
