@@ -32,3 +32,17 @@ def random_generator(sample, output_size, rng_random, rng_numpy):
     elif rng_random.random() > 0.5:
         p = {"op": 2, "angle": int(rng_numpy.randint(-20, 20)), "lab_cval": 4 if 4 in np.unique(label) else 0}
     return apply(image, label, p, output_size), p
+
+
+def two_stream_batches(primary, secondary, batch_size, secondary_batch_size, rng_numpy):
+    """dataset_semi.py:174-229 restated: zip of fixed-length groups of one primary permutation and of the endless
+    chain of secondary permutations (generator semantics: the next secondary permutation is only drawn when needed)."""
+    import itertools
+    pb = batch_size - secondary_batch_size
+    prim = iter(rng_numpy.permutation(primary))
+
+    def forever():
+        while True:
+            yield rng_numpy.permutation(secondary)
+    sec = itertools.chain.from_iterable(forever())
+    return [a + b for a, b in zip(zip(*[prim] * pb), zip(*[sec] * secondary_batch_size))]

@@ -172,3 +172,18 @@ def test_example_trainer_runs_on_the_fixture_files():
     hist = mod.main(["--root_path", ACDC, "--fold", "fold3", "--labeled_type", "unlabeled", "--max_iterations", "40",
                      "--batch_size", "3", "--patch_size", "64", "64", "--val_every", "20"])
     assert len(hist) == 3 and all(np.isfinite(l) for _, l in hist) and hist[-1][1] < hist[0][1]
+
+
+def test_two_stream_batch_sampler_matches_the_reference_semantics():
+    from wsl4mis_amd.dataloaders.dataset import TwoStreamBatchSampler
+    prim, sec = list(range(0, 23)), list(range(100, 107))
+    for bs, sb in ((6, 2), (5, 4), (8, 7)):
+        sm = TwoStreamBatchSampler(prim, sec, bs, sb)
+        np.random.seed(42)
+        got = [tuple(int(v) for v in b) for b in sm]
+        ref = [tuple(int(v) for v in b) for b in data_ref.two_stream_batches(prim, sec, bs, sb, np.random.RandomState(42))]
+        assert got == ref and len(got) == len(sm) == len(prim) // (bs - sb)
+        flat = [v for b in got for v in b[:bs - sb]]
+        assert len(set(flat)) == len(flat) and set(flat) <= set(prim) and all(set(b[bs - sb:]) <= set(sec) for b in got)
+    with pytest.raises(AssertionError):
+        TwoStreamBatchSampler(prim, sec, 40, 2)

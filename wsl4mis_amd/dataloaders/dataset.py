@@ -8,7 +8,8 @@ step of the reference is a nearest-neighbour index map, so the composition is ex
 bit (tests/test_data.py).  No CPU fallback: without the HIP library these calls raise.
 
 `BaseDataSets` mirrors the fold-aware dataset of `dataset_semi.py:17-127` (same constructor, same file selection, same
-sample dicts) on top of `h5lite` (h5py is not in the image).  Not mirrored: `TwoStreamBatchSampler`."""
+sample dicts) on top of `h5lite` (h5py is not in the image); `TwoStreamBatchSampler` the labelled/unlabelled batch
+composer of `dataset_semi.py:174-229`."""
 import os
 import random
 
@@ -17,6 +18,7 @@ import torch
 from scipy import special
 
 from torch.utils.data import Dataset
+from torch.utils.data.sampler import Sampler
 
 from .. import _lib
 from .. import runtime as rt
@@ -142,3 +144,31 @@ class BatchRandomGenerator(object):
     def __call__(self, samples):
         params = [draw_params(np.asarray(s["label"])) for s in samples]     # the reference's per-sample draw order
         return augment_batch([s["image"] for s in samples], [s["label"] for s in samples], params, self.output_size)
+
+
+class TwoStreamBatchSampler(Sampler):
+    """Batches of `batch_size - secondary_batch_size` primary indices followed by `secondary_batch_size` secondary ones
+    (ref: dataset_semi.py:174-229).  One epoch = one random pass over the primary indices (a short tail is dropped);
+    the secondary indices are drawn from an endless sequence of fresh permutations.  Uses `numpy.random` like the
+    reference: one permutation of the primary set when the iterator is created, then one of the secondary set whenever
+    the previous one is exhausted."""
+
+    def __init__(self, primary_indices, secondary_indices, batch_size, secondary_batch_size):
+        self.primary_indices, self.secondary_indices = primary_indices, secondary_indices
+        self.secondary_batch_size = secondary_batch_size
+        self.primary_batch_size = batch_size - secondary_batch_size
+        assert len(self.primary_indices) >= self.primary_batch_size > 0
+        assert len(self.secondary_indices) >= self.secondary_batch_size > 0
+
+    def __iter__(self):
+        primary = np.random.permutation(self.primary_indices)
+        pool = []
+        for b in range(len(self)):
+            head = tuple(primary[b * self.primary_batch_size:(b + 1) * self.primary_batch_size])
+            while len(pool) < self.secondary_batch_size:
+                pool.extend(np.random.permutation(self.secondary_indices))
+            tail, pool = tuple(pool[:self.secondary_batch_size]), pool[self.secondary_batch_size:]
+            yield head + tail
+
+    def __len__(self):
+        return len(self.primary_indices) // self.primary_batch_size
