@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce", "mean_teacher"])
+    ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce", "mean_teacher", "ustm"])
     ap.add_argument("--crf-radius", type=int, default=5, help="reference default 5 (11x11); 2 = the 5x5 of BASELINE.json")
     ap.add_argument("--net", default="unet_cct", choices=["unet_cct", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,8 +115,8 @@ def cpu_baseline_subprocess(args):
 
 def main():
     args = parse()
-    if args.loss == "mean_teacher":
-        args.net, args.no_cpu_baseline = "unet", True      # config 4: single-decoder student + EMA teacher
+    if args.loss in ("mean_teacher", "ustm"):
+        args.net, args.no_cpu_baseline = "unet", True      # config 4 (and USTM): single-decoder student + EMA teacher
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
         return
@@ -248,6 +248,8 @@ def main():
         gflop = 28.98 if args.net == "unet_cct" else 17.68     # conv-stack training GFLOP/slice
         if args.loss == "mean_teacher":
             gflop += 5.899                                     # + the teacher's forward
+        if args.loss == "ustm":
+            gflop += 9 * 5.899                                 # + 1 + 4 x 2 teacher forwards per student slice
         value = args.batch * world * args.steps / dt
         out = {"metric": "training slices/sec (256x256, bs64, unet_cct pCE+GatedCRF)", "value": round(value, 2),
                "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

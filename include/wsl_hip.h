@@ -197,6 +197,16 @@ int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* loss, float* 
                             void* ws, size_t ws_bytes, void* stream);
 
 /* dst += k * src (sums the logit-gradients of several loss terms). */
+/* Uncertainty-aware mean teacher (ref: train_weakly_supervised_ustm_2D.py:121-157).
+ * wsl_rot90: torch.rot90(x, k, [2,3]) of `planes` [H,W] planes (output planes [W,H] for odd k; x != y).
+ * wsl_softmax_accum: acc = (init ? 0 : acc) + scale * softmax(z) -- the mean of the T stochastic teacher predictions.
+ * wsl_ustm_consistency_fwd_bwd: mask = [-sum_c pm log(pm + 1e-6) < threshold] per pixel (pm = pmean [N,C,HW]);
+ *   loss[0] = sum(mask * (softmax(a) - softmax(b))^2) / (2 sum(mask) + 1e-16), loss[1] = sum(mask), loss[2] = 1/(2 sum(mask)+1e-16);
+ *   da = gscale * dloss/da (no gradient to b or the mask).  `loss` holds 3 floats. */
+int wsl_rot90(const float* x, float* y, int planes, int H, int W, int k, void* stream);
+int wsl_softmax_accum(const float* z, float* acc, float scale, int init, int N, int C, int HW, void* stream);
+int wsl_ustm_consistency_fwd_bwd(const float* a, const float* b, const float* pmean, float threshold, float* loss, float* da,
+                                 float gscale, int N, int C, int HW, void* ws, size_t ws_bytes, void* stream);
 /* entropy_loss(p, C) = mean over pixels of -sum_c p log(p + 1e-6), divided by log(C) (ref: utils/losses.py:30-36);
  * dp = gscale * dloss/dp.  p is [N,C,HW] (already a softmax). */
 int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float gscale, int N, int C, int HW, void* ws,

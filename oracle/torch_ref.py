@@ -262,6 +262,23 @@ def mean_teacher_loss(z_s, z_t, label_u8, it):
     return ce + 1e-2 * tv + w * cons, ce, tv, cons
 
 
+def ustm_loss(z_s, z_t_rot, preds_logits, label_u8, rot_k, it, max_it):
+    """train_weakly_supervised_ustm_2D.py:119-157 given the forwards: z_s student logits, z_t_rot teacher logits on the
+    rotated noisy batch, preds_logits = the T//2 teacher outputs on the doubled rotated batch (each [2N,C,H,W])."""
+    ce = ce_ignore(z_s, label_u8)
+    N, C = z_s.shape[0], z_s.shape[1]
+    preds = torch.cat(list(preds_logits), 0)                                    # [stride*T, C, w, h], stride = N
+    T = preds.shape[0] // N
+    preds = torch.softmax(preds, 1).reshape(T, N, C, z_s.shape[2], z_s.shape[3]).mean(0)
+    unc = -1.0 * torch.sum(preds * torch.log(preds + 1e-6), dim=1, keepdim=True)
+    w = 1.0 * sigmoid_rampup(it // 1000, 60)                                     # ustm_2D.py:56-58,146
+    dist = softmax_mse(torch.rot90(z_s, rot_k, [2, 3]), z_t_rot.detach())
+    thr = (0.75 + 0.25 * sigmoid_rampup(it, max_it)) * math.log(2.0)
+    mask = (unc < thr).float()
+    cons = torch.sum(mask * dist) / (2 * torch.sum(mask) + 1e-16)
+    return ce + w * cons, ce, cons, torch.sum(mask)
+
+
 # --------------------------------------------------------------------------- whole step (CPU baseline)
 class RefTrainer:
     """One process' training loop of ours_proposed (or pCE+GatedCRF) in stock torch CPU ops, used as the

@@ -346,3 +346,62 @@ def test_validation_volume_label_maps(mode):
     assert val_2D.dice_percase(np.array([1, 1, 0]), np.array([1, 0, 0])) == pytest.approx(2 / 3)
     with pytest.raises(NotImplementedError):
         val_2D.test_single_volume(torch.from_numpy(vol[0]), torch.from_numpy(lab[0]), m, 4)
+
+
+def test_ustm_step_against_oracle(mode):
+    """train_weakly_supervised_ustm_2D.py:119-163 (pCE + uncertainty-masked consistency against an EMA teacher, T = 8
+    stochastic teacher passes on the rotated batch): one engine step vs the oracle's composition of the pinned pieces."""
+    import random as pyrandom
+    from oracle import torch_ref as R
+    from wsl4mis_amd.engine import TrainEngine
+    from wsl4mis_amd.synthetic import scribble_labels
+    N, S, it0, max_it = 4, 16, 20000, 30000       # (N = 4: two samples make the deepest BatchNorm ill-conditioned)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.rand((N, 1, S, S), generator=gen)
+    lab = torch.from_numpy(scribble_labels(N, S, S, 4, share=0.08))
+    noises = [torch.clamp(torch.randn((N, 1, S, S), generator=gen) * 0.1, -0.2, 0.2)] + \
+             [torch.clamp(torch.randn((2 * N, 1, S, S), generator=gen) * 0.1, -0.2, 0.2) for _ in range(4)]
+
+    def mk_masks(n):
+        return [(torch.rand((n, 16 << l, S >> l, S >> l), generator=gen) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
+    m_s, m_t = mk_masks(N), {N: mk_masks(N), 2 * N: mk_masks(2 * N)}
+    eng = TrainEngine("unet", 1, 4, base_lr=0.01, max_iterations=max_it, loss="ustm")
+    load_det(eng.model, 31)
+    load_det(eng.teacher, 32)
+    SHARP = 60.0                        # a confident teacher head, so that the entropy threshold splits the pixels
+    tsd = eng.teacher.state_dict()
+    tsd["decoder.out_conv.weight"] = tsd["decoder.out_conv.weight"] * SHARP
+    eng.teacher.load_state_dict(tsd)
+    eng.it = it0
+    eng.model.set_dropout_masks([T(m) for m in m_s])
+    eng.teacher.set_dropout_masks(lambda n, h, w: ([T(m) for m in m_t[n]], None))
+    pyrandom.seed(77)
+    k = pyrandom.Random(77).randrange(0, 4)
+    # ---- oracle
+    sd_s = {kk: torch.from_numpy(np.asarray(v)).clone() for kk, v in det_state(
+        {kk: tuple(v.shape) for kk, v in eng.model.state_dict().items()}, 31).items()}
+    sd_t = {kk: torch.from_numpy(np.asarray(v)).clone() for kk, v in det_state(
+        {kk: tuple(v.shape) for kk, v in eng.teacher.state_dict().items()}, 32).items()}
+    sd_t["decoder.out_conv.weight"] = sd_t["decoder.out_conv.weight"] * SHARP
+    pk = [kk for kk in sd_s if R.is_param(kk)]
+    for kk in pk:
+        sd_s[kk].requires_grad_(True)
+    z_s = R.net_forward(sd_s, x, "unet", m_s, None, True)
+    xr = torch.rot90(x, k, [2, 3])
+    with torch.no_grad():
+        z_t = R.net_forward(sd_t, xr + noises[0], "unet", m_t[N], None, True)
+        preds = [R.net_forward(sd_t, xr.repeat(2, 1, 1, 1) + noises[1 + i], "unet", m_t[2 * N], None, True) for i in range(4)]
+    loss, ce, cons, n_mask = R.ustm_loss(z_s, z_t, preds, lab, k, it0, max_it)
+    loss.backward()
+    assert 0 < float(n_mask) < N * S * S                      # the threshold actually splits the pixels
+    # ---- engine
+    eng.forward_backward(T(x), T(lab), 0.5, noise=[T(n) for n in noises])
+    o = eng.losses()
+    assert rel_err([o["loss"], o["ce"], o["cons"]], [loss.item(), ce.item(), cons.item()]) < TOL
+    assert o["n_certain"] == float(n_mask)
+    flat = eng.model.flat_grads().cpu().numpy()
+    off = 0
+    for kk in pk:
+        g = sd_s[kk].grad.numpy().ravel()
+        assert np.max(np.abs(flat[off:off + g.size] - g)) <= grad_tol(kk, g), kk
+        off += g.size

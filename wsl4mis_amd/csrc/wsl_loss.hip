@@ -648,6 +648,102 @@ __global__ __launch_bounds__(256) void entropy_kernel(const float* p, int C, int
   write_partials<1>(v, part, red);
 }
 
+// ------------------------------------------------------------------------------------------------ uncertainty-aware mean teacher
+// Pieces of train_weakly_supervised_ustm_2D.py:121-157.
+// torch.rot90(x, k, [2, 3]) of every [H, W] plane (output planes are [W, H] for odd k)
+__global__ __launch_bounds__(256) void rot90_kernel(const float* x, float* y, int H, int W, int k) {
+  const int Ho = (k & 1) ? W : H, Wo = (k & 1) ? H : W;
+  const float* xp = x + (int64_t)blockIdx.y * H * W;
+  float* yp = y + (int64_t)blockIdx.y * H * W;
+  for (int o = blockIdx.x * kThreads + threadIdx.x; o < Ho * Wo; o += gridDim.x * kThreads) {
+    const int i = o / Wo, j = o - i * Wo;
+    int sy, sx;
+    switch (k & 3) {
+      case 0: sy = i, sx = j; break;
+      case 1: sy = j, sx = W - 1 - i; break;
+      case 2: sy = H - 1 - i, sx = W - 1 - j; break;
+      default: sy = H - 1 - j, sx = i; break;
+    }
+    yp[o] = xp[sy * W + sx];
+  }
+}
+
+// acc = (init ? 0 : acc) + scale * softmax(z): the Monte-Carlo mean of the teacher's predictions, one pass per forward
+__global__ __launch_bounds__(256) void softmax_accum_kernel(const float* z, float* acc, float scale, int init, int C, int HW,
+                                                            int64_t P) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, q = i - n * HW, base = n * C * HW + q;
+    float sm[kMaxC];
+    softmax_c(z + base, HW, C, sm);
+    for (int c = 0; c < C; ++c) {
+      const int64_t e = base + (int64_t)c * HW;
+      acc[e] = init ? scale * sm[c] : fmaf(scale, sm[c], acc[e]);
+    }
+  }
+}
+
+// mask(px) = [ -sum_c pm log(pm + 1e-6) < threshold ]  (uncertainty of the mean prediction pm)
+__device__ __forceinline__ bool ustm_certain(const float* pm, int64_t base, int HW, int C, float threshold) {
+  float u = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float x = pm[base + (int64_t)c * HW];
+    u = fmaf(-x, logf(x + 1e-6f), u);
+  }
+  return u < threshold;
+}
+
+// partials: { sum_px mask * sum_c (softmax(a) - softmax(b))^2 , sum_px mask }
+__global__ __launch_bounds__(256) void ustm_reduce_kernel(const float* a, const float* b, const float* pm, float threshold,
+                                                          int C, int HW, int64_t P, float* part) {
+  __shared__ float red[4];
+  float v[2] = {0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, q = i - n * HW, base = n * C * HW + q;
+    if (!ustm_certain(pm, base, HW, C, threshold)) continue;
+    float sa[kMaxC], sb[kMaxC];
+    softmax_c(a + base, HW, C, sa);
+    softmax_c(b + base, HW, C, sb);
+    for (int c = 0; c < C; ++c) {
+      const float d = sa[c] - sb[c];
+      v[0] = fmaf(d, d, v[0]);
+    }
+    v[1] += 1.f;
+  }
+  write_partials<2>(v, part, red);
+}
+
+// loss[0] = S / (2 M + 1e-16), loss[1] = M, scal[0] = gradient factor 1 / (2 M + 1e-16)
+__global__ __launch_bounds__(256) void ustm_finalize_kernel(const float* part, int nblk, float* loss) {
+  __shared__ double red[kThreads];
+  const double S = col_sum(part, nblk, 2, 0, red), M = col_sum(part, nblk, 2, 1, red);
+  if (threadIdx.x == 0) {
+    const double den = 2.0 * M + 1e-16;
+    loss[0] = (float)(S / den);
+    loss[1] = (float)M;
+    loss[2] = (float)(1.0 / den);
+  }
+}
+
+__global__ __launch_bounds__(256) void ustm_bwd_kernel(const float* a, const float* b, const float* pm, float threshold,
+                                                       const float* loss, float gscale, int C, int HW, int64_t P, float* da) {
+  const float k = 2.f * gscale * loss[2];
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, q = i - n * HW, base = n * C * HW + q;
+    if (!ustm_certain(pm, base, HW, C, threshold)) {
+      for (int c = 0; c < C; ++c) da[base + (int64_t)c * HW] = 0.f;
+      continue;
+    }
+    float sa[kMaxC], sb[kMaxC], ds[kMaxC], dot = 0.f;
+    softmax_c(a + base, HW, C, sa);
+    softmax_c(b + base, HW, C, sb);
+    for (int c = 0; c < C; ++c) {
+      ds[c] = k * (sa[c] - sb[c]);
+      dot = fmaf(ds[c], sa[c], dot);
+    }
+    for (int c = 0; c < C; ++c) da[base + (int64_t)c * HW] = sa[c] * (ds[c] - dot);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ mixed probabilities
 // y = beta*softmax(z1) + (1-beta)*softmax(z2): the prediction the dual-branch + GatedCRF composition regularises
 // (ref: train_ACDC_scribblevc.py:171-206).  z2 == NULL: y = softmax(z1).
@@ -870,6 +966,34 @@ extern "C" int wsl_softmax_mse_fwd_bwd(const float* a, const float* b, float* lo
   WSL_LAUNCH(softmax_mse_kernel, dim3(nb), dim3(kThreads), 0, stream, a, b, C, HW, P, (float)(gscale / numel), da, part);
   WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, 1, 1.0 / numel, loss);
   return check_launch("softmax_mse_fwd_bwd");
+}
+
+extern "C" int wsl_rot90(const float* x, float* y, int planes, int H, int W, int k, void* stream) {
+  WSL_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && x != y, "rot90: bad args");
+  WSL_LAUNCH(rot90_kernel, dim3(cdiv(H * W, kThreads * 4), planes), dim3(kThreads), 0, stream, x, y, H, W, ((k % 4) + 4) % 4);
+  return check_launch("rot90_kernel");
+}
+
+extern "C" int wsl_softmax_accum(const float* z, float* acc, float scale, int init, int N, int C, int HW, void* stream) {
+  WSL_REQUIRE(z && acc && N > 0 && C > 0 && C <= kMaxC && HW > 0, "softmax_accum: bad args");
+  const int64_t P = (int64_t)N * HW;
+  WSL_LAUNCH(softmax_accum_kernel, dim3(grid_for(P)), dim3(kThreads), 0, stream, z, acc, scale, init, C, HW, P);
+  return check_launch("softmax_accum_kernel");
+}
+
+extern "C" int wsl_ustm_consistency_fwd_bwd(const float* a, const float* b, const float* pmean, float threshold, float* loss,
+                                            float* da, float gscale, int N, int C, int HW, void* ws, size_t ws_bytes,
+                                            void* stream) {
+  WSL_REQUIRE(a && b && pmean && loss && da && N > 0 && C > 0 && C <= kMaxC && HW > 0, "ustm_consistency: bad args");
+  const int HW_ = HW;
+  WSL_WS_OK("ustm_consistency_fwd_bwd");
+  const int64_t P = (int64_t)N * HW;
+  const int nb = grid_for(P);
+  float* part = static_cast<float*>(ws);
+  WSL_LAUNCH(ustm_reduce_kernel, dim3(nb), dim3(kThreads), 0, stream, a, b, pmean, threshold, C, HW, P, part);
+  WSL_LAUNCH(ustm_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, loss);
+  WSL_LAUNCH(ustm_bwd_kernel, dim3(nb), dim3(kThreads), 0, stream, a, b, pmean, threshold, loss, gscale, C, HW, P, da);
+  return check_launch("ustm_consistency_fwd_bwd");
 }
 
 extern "C" int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float gscale, int N, int C, int HW, void* ws,

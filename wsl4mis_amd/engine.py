@@ -6,6 +6,8 @@ Steps reproduced (reference file:line, all under code/):
   'pce'             train_weakly_supervised_pCE_2D.py:96-108 (unet) / dual-branch 0.5*(ce1+ce2) (unet_cct, config 1)
   'pce_gatedcrf'    train_weakly_supervised_pCE_GatedCRFLoss_2D.py:108-130 (unet);  unet_cct: 0.5*(ce1+ce2) +
                     0.1*GatedCRF(beta*s1+(1-beta)*s2) as in train_ACDC_scribblevc.py:171-206
+  'ustm'            train_weakly_supervised_ustm_2D.py:119-163: pCE + w(t) * uncertainty-masked consistency against the EMA
+                    teacher (T = 8 stochastic teacher passes on the rot90'ed batch), unet only
   'mean_teacher'    SURVEY 8d config 4 (unet student + EMA teacher): pCE + 1e-2*tv_loss(softmax[1:]) (pCE_TV_2D.py:113-114)
                     + w(t)*mean((softmax(s)-softmax(teacher(x+noise)))^2) (train_mean_teacher_2D.py:147-171); teacher =
                     EMA of the student every step (train_weakly_supervised_ustm_2D.py:61-65,163), kept in train mode
@@ -17,6 +19,7 @@ decoders' slice as soon as the decoder backward has been enqueued (it overlaps t
 encoder's slice.  Losses stay on the device; `losses()` is the only host sync.
 """
 import ctypes as C
+import math
 import os
 
 import torch
@@ -31,7 +34,7 @@ class TrainEngine:
     def __init__(self, net_type="unet_cct", in_chns=1, class_num=4, base_lr=0.01, max_iterations=60000, momentum=0.9,
                  weight_decay=1e-4, loss="ours_proposed", w_pse=0.5, crf_radius=5, crf_weight=0.1,
                  crf_desc=None, ignore_index=4, model=None):
-        if loss not in ("ours_proposed", "pce", "pce_gatedcrf", "mean_teacher"):
+        if loss not in ("ours_proposed", "pce", "pce_gatedcrf", "mean_teacher", "ustm"):
             raise NotImplementedError(f"loss composition '{loss}'")
         self.model = model if model is not None else net_factory(net_type, in_chns, class_num)
         if self.model is None:
@@ -58,9 +61,9 @@ class TrainEngine:
         self.teacher = None
         self._tstream, self._zt = None, None
         self.concurrent = os.environ.get("WSL_NET_CONCURRENT") != "0"   # side streams (teacher forward); see DESIGN 4
-        if loss == "mean_teacher":
+        if loss in ("mean_teacher", "ustm"):
             if self.dual:
-                raise _lib.WslError("'mean_teacher' is defined for the single-decoder unet")
+                raise _lib.WslError(f"'{loss}' is defined for the single-decoder unet")
             self.teacher = net_factory(net_type, in_chns, class_num)
             self.teacher.train()                          # the reference never puts the EMA model in eval()
             with torch.no_grad():
@@ -79,6 +82,8 @@ class TrainEngine:
                 t["y"], t["msg"] = mk(), mk()
             if self.loss_kind == "mean_teacher":
                 t["s"], t["ds"], t["dzx"] = mk(), mk(), mk()
+            if self.loss_kind == "ustm":
+                t["zr"], t["dzx"], t["pm"] = mk(), mk(), mk()
             self._bufs = {key: t}
         return self._bufs[key]
 
@@ -125,6 +130,44 @@ class TrainEngine:
         zt, self._zt = self._zt, None
         return zt
 
+    def _ustm_losses(self, x, label_u8, z, t, noise):
+        """train_weakly_supervised_ustm_2D.py:119-157: pCE + w(t) * uncertainty-masked consistency.  `noise`: None (drawn
+        like the script) or a list of T//2 + 1 tensors (teacher input noise, then the T//2 double-batch noises)."""
+        m, N, H, W = self.model, x.shape[0], x.shape[2], x.shape[3]
+        HW, C_, T_ = H * W, self.model.class_num, 8
+        if H != W:
+            raise _lib.WslError("ustm rotates the batch by multiples of 90 degrees: square inputs only")
+        nl = rt.L().wsl_loss_ws_bytes(N, C_, HW)
+        lws = rt.workspace("loss", nl)
+        lo = self.loss_out
+        rt.call("wsl_head_fwd_bwd", rt.ptr(z), None, rt.ptr(label_u8), self.ignore, 0.0, 0.0, 1.0, rt.ptr(lo), None,
+                rt.ptr(t["dz1"]), None, N, C_, HW, rt.ptr(lws), nl, rt.stream())
+        import random as _random
+        k = _random.randrange(0, 4)                           # ustm_2D.py:121 (the script's only python-RNG draw per step)
+        xr = torch.empty_like(x)
+        rt.call("wsl_rot90", rt.ptr(x), rt.ptr(xr), N * x.shape[1], H, W, k, rt.stream())
+
+        def nz(i, ref):
+            if noise is not None:
+                return rt.f32c(noise[i], "noise")
+            return torch.clamp(torch.randn_like(ref) * 0.1, -0.2, 0.2)
+        with torch.no_grad():
+            zt = self.teacher._run_forward(xr + nz(0, xr))[0]
+            xr2 = xr.repeat(2, 1, 1, 1)
+            for i in range(T_ // 2):                          # T stochastic passes, two per double batch
+                z2 = self.teacher._run_forward(xr2 + nz(1 + i, xr2))[0]
+                for h in range(2):
+                    rt.call("wsl_softmax_accum", rt.ptr(z2[h * N:]), rt.ptr(t["pm"]), 1.0 / T_, int(i == 0 and h == 0), N, C_,
+                            HW, rt.stream())
+        from .utils.ramps import sigmoid_rampup
+        self._cons_w = 1.0 * sigmoid_rampup(self.it // 1000, 60)      # ustm_2D.py:56-58,146: get_current_consistency_weight(iter // 1000)
+        thr = (0.75 + 0.25 * sigmoid_rampup(self.it, self.max_it)) * math.log(2.0)
+        rt.call("wsl_rot90", rt.ptr(z), rt.ptr(t["zr"]), N * C_, H, W, k, rt.stream())
+        rt.call("wsl_ustm_consistency_fwd_bwd", rt.ptr(t["zr"]), rt.ptr(zt), rt.ptr(t["pm"]), float(thr), rt.ptr(lo[4:]),
+                rt.ptr(t["dzx"]), self._cons_w, N, C_, HW, rt.ptr(lws), nl, rt.stream())
+        rt.call("wsl_rot90", rt.ptr(t["dzx"]), rt.ptr(t["zr"]), N * C_, H, W, 4 - k, rt.stream())    # gradient back through rot90
+        rt.call("wsl_axpy", rt.ptr(t["dz1"]), rt.ptr(t["zr"]), 1.0, N * C_ * HW, rt.stream())
+
     def _mean_teacher_losses(self, x, label_u8, z, t, noise):
         """dz of pCE + tv + consistency for the student logits z; teacher logits from x + noise (no gradient)."""
         m, N, H, W = self.model, x.shape[0], x.shape[2], x.shape[3]
@@ -163,6 +206,10 @@ class TrainEngine:
         lws = rt.workspace("loss", nl)
         if self.loss_kind == "mean_teacher":
             self._mean_teacher_losses(x, label_u8, z1, t, noise)
+            self._finish_backward(x, t)
+            return
+        if self.loss_kind == "ustm":
+            self._ustm_losses(x, label_u8, z1, t, noise)
             self._finish_backward(x, t)
             return
         w_pse = self.w_pse if self.loss_kind == "ours_proposed" else 0.0
@@ -208,6 +255,8 @@ class TrainEngine:
         o = self.loss_out.tolist()
         if self.loss_kind == "pce_gatedcrf":
             return {"loss": o[1] + self.crf_weight * o[4], "ce": o[1], "crf": o[4], "n_valid": o[3]}
+        if self.loss_kind == "ustm":           # cons is the raw (unweighted) masked consistency; n_certain = sum(mask)
+            return {"loss": o[1] + self._cons_w * o[4], "ce": o[1], "cons": o[4], "n_certain": o[5], "n_valid": o[3]}
         if self.loss_kind == "mean_teacher":   # tv / cons are the raw (unweighted) terms
             return {"loss": o[1] + self.tv_weight * o[4] + self._cons_w * o[5], "ce": o[1], "tv": o[4], "cons": o[5],
                     "n_valid": o[3]}

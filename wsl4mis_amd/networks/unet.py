@@ -132,11 +132,13 @@ class _HipUNet(nn.Module):
     # ------------------------------------------------------------------ masks (host-side RNG = torch's, on the device)
     def set_dropout_masks(self, emasks, cmasks=None):
         """Inject the Bernoulli masks of the next forward(s) (parity tests replay the reference's); None = draw."""
-        self._forced_masks = None if emasks is None and cmasks is None else (emasks, cmasks)
+        self._forced_masks = emasks if callable(emasks) else (None if emasks is None and cmasks is None else (emasks, cmasks))
 
     def _draw_masks(self, N, H, W, training):
         dev = self._param_arena.device
-        if self._forced_masks is not None:
+        if callable(self._forced_masks):                 # (tests) masks that depend on the batch shape of the forward
+            em, cm = self._forced_masks(N, H, W)
+        elif self._forced_masks is not None:
             em, cm = self._forced_masks
         else:
             em = cm = None
