@@ -405,3 +405,45 @@ def test_ustm_step_against_oracle(mode):
         g = sd_s[kk].grad.numpy().ravel()
         assert np.max(np.abs(flat[off:off + g.size] - g)) <= grad_tol(kk, g), kk
         off += g.size
+
+
+@pytest.mark.parametrize("kind", ["pce_tv", "pce_ms", "pce_entropy"])
+def test_regularised_pce_steps_against_oracle(mode, kind):
+    """the single-branch pCE + regulariser scripts (TV / Mumford-Shah / entropy minimisation): losses and gradients of one
+    engine step vs the oracle's pinned pieces composed like the scripts"""
+    import math
+    from oracle import torch_ref as R
+    from wsl4mis_amd.engine import TrainEngine
+    from wsl4mis_amd.synthetic import scribble_labels
+    N, S = 4, 16
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand((N, 1, S, S), generator=gen)
+    lab = torch.from_numpy(scribble_labels(N, S, S, 4, share=0.08))
+    masks = [(torch.rand((N, 16 << l, S >> l, S >> l), generator=gen) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
+    eng = TrainEngine("unet", 1, 4, loss=kind)
+    load_det(eng.model, 41)
+    eng.model.set_dropout_masks([T(m) for m in masks])
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in det_state(
+        {k: tuple(v.shape) for k, v in eng.model.state_dict().items()}, 41).items()}
+    pk = [k for k in sd if R.is_param(k)]
+    for k in pk:
+        sd[k].requires_grad_(True)
+    z = R.net_forward(sd, x, "unet", masks, None, True)
+    s = torch.softmax(z, 1)
+    ce = R.ce_ignore(z, lab)
+    if kind == "pce_tv":
+        reg, w = R.tv_loss(s[1:]), 1e-2
+    elif kind == "pce_ms":
+        reg, w = R.mumford_shah(x, s), 1e-6
+    else:
+        reg, w = torch.mean(-1 * torch.sum(s * torch.log(s + 1e-6), dim=1) / math.log(4)), 0.1      # losses.py:30-36
+    (ce + w * reg).backward()
+    eng.forward_backward(T(x), T(lab), 0.5)
+    o = eng.losses()
+    assert rel_err([o["loss"], o["ce"], o["reg"]], [(ce + w * reg).item(), ce.item(), reg.item()]) < TOL
+    flat = eng.model.flat_grads().cpu().numpy()
+    off = 0
+    for k in pk:
+        g = sd[k].grad.numpy().ravel()
+        assert np.max(np.abs(flat[off:off + g.size] - g)) <= grad_tol(k, g), k
+        off += g.size

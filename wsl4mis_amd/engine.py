@@ -6,6 +6,9 @@ Steps reproduced (reference file:line, all under code/):
   'pce'             train_weakly_supervised_pCE_2D.py:96-108 (unet) / dual-branch 0.5*(ce1+ce2) (unet_cct, config 1)
   'pce_gatedcrf'    train_weakly_supervised_pCE_GatedCRFLoss_2D.py:108-130 (unet);  unet_cct: 0.5*(ce1+ce2) +
                     0.1*GatedCRF(beta*s1+(1-beta)*s2) as in train_ACDC_scribblevc.py:171-206
+  'pce_tv' | 'pce_ms' | 'pce_entropy'   pCE + 1e-2 tv_loss(softmax[1:]) | + 1e-6 MumfordShah(image, softmax) | + 0.1
+                    entropy_loss(softmax, 4)  (..._pCE_TV_2D.py:113-114, ..._pCE_MumfordShah_Loss_2D.py:102-103,
+                    ..._pCE_Entropy_Mini_2D.py:99-102), unet only
   'ustm'            train_weakly_supervised_ustm_2D.py:119-163: pCE + w(t) * uncertainty-masked consistency against the EMA
                     teacher (T = 8 stochastic teacher passes on the rot90'ed batch), unet only
   'mean_teacher'    SURVEY 8d config 4 (unet student + EMA teacher): pCE + 1e-2*tv_loss(softmax[1:]) (pCE_TV_2D.py:113-114)
@@ -31,10 +34,16 @@ from .networks.net_factory import net_factory
 
 
 class TrainEngine:
+    # pCE + weight * regulariser(softmax(outputs)) of the single-branch scripts: (weight, reference lines)
+    REGULARISED = ("pce_tv", "pce_ms", "pce_entropy")
+    REG_WEIGHT = {"pce_tv": 1e-2,        # train_weakly_supervised_pCE_TV_2D.py:113-114 (tv_loss on outputs_soft[1:])
+                  "pce_ms": 1e-6,        # ..._pCE_MumfordShah_Loss_2D.py:102-103 (MumfordShah_Loss(image, softmax))
+                  "pce_entropy": 0.1}    # ..._pCE_Entropy_Mini_2D.py:99-102 (entropy_loss(softmax, C=4))
+
     def __init__(self, net_type="unet_cct", in_chns=1, class_num=4, base_lr=0.01, max_iterations=60000, momentum=0.9,
                  weight_decay=1e-4, loss="ours_proposed", w_pse=0.5, crf_radius=5, crf_weight=0.1,
                  crf_desc=None, ignore_index=4, model=None):
-        if loss not in ("ours_proposed", "pce", "pce_gatedcrf", "mean_teacher", "ustm"):
+        if loss not in ("ours_proposed", "pce", "pce_gatedcrf", "mean_teacher", "ustm") + self.REGULARISED:
             raise NotImplementedError(f"loss composition '{loss}'")
         self.model = model if model is not None else net_factory(net_type, in_chns, class_num)
         if self.model is None:
@@ -43,6 +52,8 @@ class TrainEngine:
         self.dual = self.model._n_dec == 2
         if loss == "ours_proposed" and not self.dual:
             raise _lib.WslError("'ours_proposed' needs the dual-branch unet_cct")
+        if loss in self.REGULARISED and self.dual:
+            raise _lib.WslError(f"'{loss}' is a single-branch (unet) composition")
         self.loss_kind, self.w_pse, self.ignore = loss, w_pse, ignore_index
         self.crf_radius, self.crf_weight = crf_radius, crf_weight
         self.crf_desc = crf_desc or {"weight": 1.0, "xy": 6.0, "rgb": 0.1}
@@ -84,6 +95,8 @@ class TrainEngine:
                 t["s"], t["ds"], t["dzx"] = mk(), mk(), mk()
             if self.loss_kind == "ustm":
                 t["zr"], t["dzx"], t["pm"] = mk(), mk(), mk()
+            if self.loss_kind in self.REGULARISED:
+                t["s"], t["ds"], t["dzx"] = mk(), mk(), mk()
             self._bufs = {key: t}
         return self._bufs[key]
 
@@ -129,6 +142,26 @@ class TrainEngine:
         torch.cuda.current_stream().wait_stream(self._tstream)
         zt, self._zt = self._zt, None
         return zt
+
+    def _regularised_losses(self, x, label_u8, z, t):
+        """pCE + weight * R(softmax(z)) with R = tv_loss([1:]) | MumfordShah(image, .) | entropy_loss(., C)."""
+        N, H, W = x.shape[0], x.shape[2], x.shape[3]
+        HW, C_ = H * W, self.model.class_num
+        nl = rt.L().wsl_loss_ws_bytes(N, C_, HW)
+        lws = rt.workspace("loss", nl)
+        lo, w = self.loss_out, self.REG_WEIGHT[self.loss_kind]
+        rt.call("wsl_head_fwd_bwd", rt.ptr(z), None, rt.ptr(label_u8), self.ignore, 0.0, 0.0, 1.0, rt.ptr(lo), None,
+                rt.ptr(t["dz1"]), None, N, C_, HW, rt.ptr(lws), nl, rt.stream())
+        rt.call("wsl_softmax_fwd", rt.ptr(z), rt.ptr(t["s"]), N, C_, HW, rt.stream())
+        if self.loss_kind == "pce_tv":
+            rt.call("wsl_tv_fwd_bwd", rt.ptr(t["s"]), 1, rt.ptr(lo[4:]), rt.ptr(t["ds"]), w, N, C_, H, W, rt.ptr(lws), nl, rt.stream())
+        elif self.loss_kind == "pce_ms":
+            rt.call("wsl_mumford_shah_fwd_bwd", rt.ptr(x), rt.ptr(t["s"]), rt.ptr(lo[4:]), rt.ptr(t["ds"]), w, N, C_, H, W,
+                    rt.ptr(lws), nl, rt.stream())
+        else:
+            rt.call("wsl_entropy_fwd_bwd", rt.ptr(t["s"]), rt.ptr(lo[4:]), rt.ptr(t["ds"]), w, N, C_, HW, rt.ptr(lws), nl, rt.stream())
+        rt.call("wsl_softmax_bwd", rt.ptr(t["s"]), rt.ptr(t["ds"]), rt.ptr(t["dzx"]), N, C_, HW, rt.stream())
+        rt.call("wsl_axpy", rt.ptr(t["dz1"]), rt.ptr(t["dzx"]), 1.0, N * C_ * HW, rt.stream())
 
     def _ustm_losses(self, x, label_u8, z, t, noise):
         """train_weakly_supervised_ustm_2D.py:119-157: pCE + w(t) * uncertainty-masked consistency.  `noise`: None (drawn
@@ -212,6 +245,10 @@ class TrainEngine:
             self._ustm_losses(x, label_u8, z1, t, noise)
             self._finish_backward(x, t)
             return
+        if self.loss_kind in self.REGULARISED:
+            self._regularised_losses(x, label_u8, z1, t)
+            self._finish_backward(x, t)
+            return
         w_pse = self.w_pse if self.loss_kind == "ours_proposed" else 0.0
         rt.call("wsl_head_fwd_bwd", rt.ptr(z1), rt.ptr(z2), rt.ptr(label_u8), self.ignore, float(beta), w_pse, 1.0,
                 rt.ptr(self.loss_out), None, rt.ptr(t["dz1"]), rt.ptr(t["dz2"]), N, m.class_num, HW, rt.ptr(lws), nl,
@@ -255,6 +292,8 @@ class TrainEngine:
         o = self.loss_out.tolist()
         if self.loss_kind == "pce_gatedcrf":
             return {"loss": o[1] + self.crf_weight * o[4], "ce": o[1], "crf": o[4], "n_valid": o[3]}
+        if self.loss_kind in self.REGULARISED:  # reg is the raw (unweighted) regulariser
+            return {"loss": o[1] + self.REG_WEIGHT[self.loss_kind] * o[4], "ce": o[1], "reg": o[4], "n_valid": o[3]}
         if self.loss_kind == "ustm":           # cons is the raw (unweighted) masked consistency; n_certain = sum(mask)
             return {"loss": o[1] + self._cons_w * o[4], "ce": o[1], "cons": o[4], "n_certain": o[5], "n_valid": o[3]}
         if self.loss_kind == "mean_teacher":   # tv / cons are the raw (unweighted) terms
