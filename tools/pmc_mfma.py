@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Aggregates rocprofv3 --pmc passes (any of SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_LDS_BANK_CONFLICT,
+SQ_LDS_IDX_ACTIVE, SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE) per kernel family and prints ratios.
+   python tools/pmc_mfma.py <dir> [<dir> ...] > profiles/<tag>_pmc_sq.md"""
+import collections
+import csv
+import glob
+import sys
+
+
+def family(k):
+    for f in ("conv_mfma2l_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "conv_cls_kernel", "wgrad_small_kernel",
+              "conv_mfma2_kernel", "bnact_bwd_apply", "bnact_bwd_reduce", "gatedcrf_fwd"):
+        if f in k:
+            return f
+    return None
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for d in sys.argv[1:]:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            fam = family(r["Kernel_Name"])
+            if fam:
+                acc[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+print("| kernel family | MFMA pipe busy / SQ busy | LDS bank-conflict cycles / LDS active | VALU instr (incl. MFMA) per MFMA instr |")
+print("|---|---|---|---|")
+for fam, c in sorted(acc.items()):
+    def ratio(a, b):
+        return f"{c[a] / c[b]:.3f}" if c.get(a) is not None and c.get(b) else "–"
+    # SQ_BUSY_CYCLES is reported per shader engine (32 on MI355X), SQ_VALU_MFMA_BUSY_CYCLES per SIMD (1024): the busy
+    # fraction of one SIMD's matrix pipe while its shader engine is busy = MFMA / 1024 / (BUSY / 32)
+    mf = f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['SQ_BUSY_CYCLES'] * 32):.3f}" if c.get("SQ_BUSY_CYCLES") and c.get("SQ_VALU_MFMA_BUSY_CYCLES") else "–"
+    print(f"| `{fam}` | {mf} | {ratio('SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE')} | {ratio('SQ_INSTS_VALU', 'SQ_INSTS_MFMA')} |")
+
