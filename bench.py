@@ -208,7 +208,9 @@ def main():
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
         return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,     # HBM bytes per launch (PMC)
+                "traffic_detail": traffic,
                 "launches": int(calls), "avg_launch_us": round(1e3 * ms / calls, 2), "flops_per_launch": fl / calls,
                 "all_mfma_kernels_tflops": round(sum(r.flops for r in conv) / (sum(r.ms for r in conv) * 1e-3) / 1e12, 2),
                 "all_mfma_kernels_ms_per_step": round(sum(r.ms for r in conv) / nsteps, 3)}
