@@ -99,6 +99,8 @@ int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, void* stream
 /* Pure f32 MFMA stream (no memory traffic): shape 0 = 16x16x4, 1 = 32x32x2, 2 = 4x4x1; `blocks` workgroups of 4 waves,
  * 16 MFMAs per iteration and wave (tools/mfma_ceiling.py: the practical matrix ceiling at the sustained clock). */
 int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* out, void* stream);
+/* Destination-layout probe of global_load_lds_dwordx4: g[1024] -> out[2048] (the LDS image; tools/probe_lds_dma.py). */
+int wsl_debug_lds_dma_probe(const float* g, float* out, void* stream);
 
 /* dw[Co][Ci][ks][ks] = sum_{n,y,x} dy[n,co,y,x] * in[n,ci,y+ky-p,x+kx-p];  db[Co] = sum dy  (db may be NULL).
  * Split over pixels into partials in `ws`, then an order-fixed second stage. */

@@ -167,6 +167,10 @@ static inline wsl_v4f wsl_emu_mfma4(float a, float b, wsl_v4f c) {
   for (int r = 0; r < 4; ++r) c[r] = fmaf(wsl_emu_unbits<float>(w.xa[buf][(l & ~3) + r]), b, c[r]);
   return c;
 }
+// global_load_lds_dwordx4: lane l's 16 bytes land at the wave's LDS base + 16 * l
+static inline void wsl_emu_lds_dma16(const void* gsrc, void* lds_wave_base) {
+  memcpy((char*)lds_wave_base + 16 * wsl_emu::lane(), gsrc, 16);
+}
 // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col=l&31,row=(r&3)+8*(r>>2)+4*(l>>5).
 static inline wsl_v16f wsl_emu_mfma32(float a, float b, wsl_v16f c) {
   auto& w = wsl_emu::wave();

@@ -191,6 +191,7 @@ def test_conv_argument_errors(be):
         be.call("wsl_conv2d_fwd", s, be.src(), None, None, be.ptr(x), 16, 1, 4, 4, 1, 3, 0, None, None, be.stream)
 
 
+# (run the suite with WSL_CONV_DMA=1 to route the data-gradient launches below through the opt-in LDS-DMA kernel)
 PLANS = [(8, 64, 16), (8, 64, 32), (8, 32, 16), (8, 32, 32), (8, 32, 64), (16, 16, 16), (16, 16, 32), (16, 16, 64)]
 
 

@@ -20,7 +20,9 @@ wp = torch.empty(ks * ks * Ci * Co, device=dev)
 y = torch.empty(N, Co, H, W, device=dev)
 scale, shift = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.1
 s = _lib.WslSrc()
-s.x, s.bs, s.C, s.scale, s.shift, s.emask_scale = x.data_ptr(), Ci * H * W, Ci, scale.data_ptr(), shift.data_ptr(), 1.0
+s.x, s.bs, s.C, s.emask_scale = x.data_ptr(), Ci * H * W, Ci, 1.0
+if not os.environ.get("MB_RAW"):          # MB_RAW=1: a plain source (what every data-gradient launch sees)
+    s.scale, s.shift = scale.data_ptr(), shift.data_ptr()
 nblk = L.wsl_conv2d_stat_blocks(N, H, W, Ci, Co, ks)
 part, cnt = torch.zeros(max(nblk * Co * 2, nblk * 64), device=dev), torch.empty(nblk, device=dev)
 st = torch.cuda.current_stream().cuda_stream

@@ -61,6 +61,7 @@ _PROTOS = {
     "wsl_debug_conv_plan": (i32, [i32, i32, i32]),
     "wsl_debug_net_concurrent": (i32, [i32]),
     "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
+    "wsl_debug_lds_dma_probe": (i32, [c_fp, c_fp, c_fp]),
     "wsl_debug_mfma_stream": (i32, [i32, i32, i32, c_fp, c_fp]),
     "wsl_conv2d_wgrad": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),

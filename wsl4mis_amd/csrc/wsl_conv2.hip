@@ -563,6 +563,196 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINWL)) void 
 }
 #undef WSL_MARK
 
+// ------------------------------------------------------------------------------------------------ raw-source variant (LDS DMA)
+// conv_mfma2l_kernel for launches whose sources carry no loader transform (every data-gradient launch: the source is a
+// plain gradient tensor).  The input tile then needs no VGPR round trip at all: global_load_lds_dwordx4 streams it into
+// LDS (the tile layout is lane-contiguous: a thread's slot is 16 * tid bytes into its plane group), double-buffered so the
+// DMA of chunk k+1 flies during the MFMA stages of chunk k.  Per chunk a wave issues NLD DMA instructions + the weight
+// prefetch; no staging VALU, no input ds_write, ~35 fewer VGPRs than the lean kernel.
+template <int KS, int TH, int TW, int CO_T, int KC>
+struct Conv2RCfg : Conv2Cfg<KS, TH, TW, CO_T, KC> {
+  using B = Conv2Cfg<KS, TH, TW, CO_T, KC>;
+  static constexpr size_t SMEM = sizeof(float) * (2 * B::IN_FLOATS + B::W_FLOATS);
+  static constexpr int MINWR = (B::MT * B::NT * 4 <= 64) ? 3 : 2;
+  static_assert(B::PLANE == B::ROWS * B::ROWP && B::PLANE == 4 * B::POS, "lane-contiguous tile layout");
+};
+
+template <int KS, int TH, int TW, int CO_T, int KC>
+__global__ __launch_bounds__(256, (Conv2RCfg<KS, TH, TW, CO_T, KC>::MINWR)) void conv_mfma2r_kernel(Conv2P p) {
+  using C = Conv2RCfg<KS, TH, TW, CO_T, KC>;
+  static_assert(KC % C::G == 0 && C::MT % C::SEGS == 0, "lean staging shape");
+  WSL_DYN_SMEM(smem);
+  float* in_b = reinterpret_cast<float*>(smem);          // two input tiles
+  float* w_t = in_b + 2 * C::IN_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD-aware tile order, as conv_mfma2_kernel
+  const int tile_id = bid;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = blockIdx.y * CO_T;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
+  const int HW = H * W;
+
+  const int grp = tid / C::POS, pos = tid - grp * C::POS;
+  const int pty = pos / C::ROWP4, ptx4 = pos - pty * C::ROWP4;
+  const int gy = y0 + pty - C::P, gx = x0 + ptx4 * 4 - C::PADL;
+  const bool owner = grp < C::G;
+  const bool pvalid = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
+  const uint32_t toff = pvalid ? (uint32_t)(grp * HW + gy * W + gx) : 0u;
+  const int64_t gstride = (int64_t)C::G * HW;
+  const float* xa_n = p.a.x + n * p.a.bs;
+  const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
+
+  uint32_t woff[C::NWL];
+  int wl[C::NWL];
+#pragma unroll
+  for (int i = 0; i < C::NWL; ++i) {
+    const int f = tid + i * kThreads;
+    const int row = f / C::WQ, q = f - row * C::WQ;
+    const int tap = row / KC, c = row - tap * KC;
+    woff[i] = f < C::WF4 ? (uint32_t)((tap * Ci + c) * Co + q * 4) : 0u;
+    wl[i] = row * C::CSTR + q * 4;
+  }
+  const float* w_n = p.wp + co0;
+  v4f prw[C::NWL];
+
+  // slots of positions outside the image (and of both buffers) stay zero for the whole kernel: the DMA never touches them
+  if (owner && !pvalid) {
+#pragma unroll
+    for (int bsel = 0; bsel < 2; ++bsel)
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i)
+        *reinterpret_cast<float4*>(in_b + bsel * C::IN_FLOATS + i * (C::G * C::PLANE) + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  auto issue = [&](int c0, int bsel) __attribute__((always_inline)) {
+    const bool ina = c0 < p.a.C;                                   // uniform
+    const int chb = ina ? c0 : c0 - p.a.C;
+    const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
+    float* dst = in_b + bsel * C::IN_FLOATS + wave * 256;          // wave-uniform: lane l lands at dst + 4 * l floats
+    if (pvalid) {
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) WSL_LDS_DMA16(xb + i * gstride + toff, dst + i * (C::G * C::PLANE));
+    }
+    const float* wb = w_n + (int64_t)c0 * Co;
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) prw[i] = *reinterpret_cast<const v4f*>(wb + woff[i]);
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i)
+      if ((i + 1) * kThreads <= C::WF4 || tid + i * kThreads < C::WF4) *reinterpret_cast<v4f*>(w_t + wl[i]) = prw[i];
+  };
+
+  issue(0, 0);
+  v4f acc[C::MT][C::NT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  int abase[C::MT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i) {
+    const int mt = wave * C::MT + i;
+    abase[i] = (lane >> 4) * C::PLANE + (mt / C::SEGS) * C::ROWP + (mt % C::SEGS) * 16 + (lane & 15) + (C::PADL - C::P);
+  }
+  const int bbase = (lane >> 4) * C::CSTR + (lane & 15);
+  int bsel = 0;
+  for (int c0 = 0; c0 < Ci; c0 += KC, bsel ^= 1) {
+    commit();
+    WSL_WAIT_ALL();        // this chunk's DMA has landed
+    __syncthreads();
+    if (c0 + KC < Ci) issue(c0 + KC, bsel ^ 1);   // next chunk streams into the other buffer during the MFMA loop
+    conv2_mfma_stages<typename C::B, KS, KC, KC / 4>(in_b + bsel * C::IN_FLOATS, w_t, abase, bbase, acc);
+    __syncthreads();
+  }
+
+  // ---- epilogue: as conv_mfma2l_kernel
+  float bsum[C::NT];
+  {
+    constexpr int RPW = C::MT / C::SEGS;
+    float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
+      float* yj = yb + (int64_t)j * 16 * HW;
+      float bs = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i) {
+        v4f v = acc[i][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bias;
+        acc[i][j] = v;
+        *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16) = make_float4(v[0], v[1], v[2], v[3]);
+        bs += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      bsum[j] = bs;
+    }
+  }
+  if (p.stat_part) {
+    float* red1 = in_b;
+    float* red2 = in_b + 4 * CO_T;
+    constexpr float cnt = (float)(TH * TW);
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int col = j * 16 + (lane & 15);
+      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][j][r] - mean_b;
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) {
+        const int col = j * 16 + lane, co = co0 + col;
+        float* dst = p.stat_part + ((int64_t)co * ((int64_t)nb * p.slots) + (int64_t)tile_id * p.slots) * 2;
+        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+      }
+      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
+    }
+  }
+}
+
+template <int KS, int TH, int TW, int CO_T>
+static int launch_conv2r(Conv2P& p, int wmode_for_prof, void* stream) {
+  using C = Conv2RCfg<KS, TH, TW, CO_T, 8>;
+  auto kern = conv_mfma2r_kernel<KS, TH, TW, CO_T, 8>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_mfma2r_kernel");
+}
+
 // packed[tap][ci][co] = wmode 0: w[co][ci][tap]   |   wmode 1 (data gradient): w[ci][co][KK-1-tap]
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* wp, int Co, int Ci, int KK, int wmode) {
   const int64_t total = (int64_t)KK * Ci * Co;
@@ -619,8 +809,15 @@ static int launch_conv2(Conv2P& p, int wmode_for_prof, void* stream) {
   static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
   const int64_t span = (int64_t)(p.a.C > p.b.C ? p.a.C : p.b.C) * p.H * p.W;
   if (lean_on && p.Ci % 8 == 0 && (p.b.C == 0 || p.a.C % 8 == 0) && p.Co % CO_T == 0 && p.H % TH == 0 && p.W % TW == 0 &&
-      span < (int64_t(1) << 31) && (int64_t)KS * KS * p.Ci * p.Co < (int64_t(1) << 31))
+      span < (int64_t(1) << 31) && (int64_t)KS * KS * p.Ci * p.Co < (int64_t(1) << 31)) {
+    // measured neutral (+-3 % per layer, +0.2 % per step: profiles/r1g_conv_timeline.md), so it stays opt-in
+    static const bool dma_on = getenv("WSL_CONV_DMA") && atoi(getenv("WSL_CONV_DMA")) != 0;
+    const bool raw = !p.a.scale && !p.a.emask && !p.a.cmask && (p.b.C == 0 || (!p.b.scale && !p.b.emask && !p.b.cmask));
+    if constexpr (KS == 3) {   // (1x1 tiles are padded per plane: their slots are not lane-contiguous)
+      if (dma_on && raw) return launch_conv2r<KS, TH, TW, CO_T>(p, wmode_for_prof, stream);   // plain sources: LDS DMA
+    }
     return launch_conv2l<KS, TH, TW, CO_T>(p, wmode_for_prof, stream);
+  }
   auto kern = conv_mfma2_kernel<KS, TH, TW, CO_T, 8>;
   static bool attr_done = false;
   if (!attr_done) {

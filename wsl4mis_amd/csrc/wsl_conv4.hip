@@ -427,6 +427,23 @@ __global__ __launch_bounds__(256) void mfma_stream_kernel(float* out, int iters)
 }
 #endif
 
+// Destination-layout probe of global_load_lds_dwordx4 (LDS DMA): every lane fetches its own 16 bytes; where do they land?
+#ifndef WSL_HOST_EMUL
+__global__ void lds_dma_probe_kernel(const float* g, float* out) {
+  __shared__ __attribute__((aligned(16))) float lds[2048];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = -1.f;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) != 5)    // one lane masked off: its slot must stay untouched
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + threadIdx.x * 4), (lptr_t)(lds + wave * 256 + 8), 16, 0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256) out[i] = lds[i];
+}
+#endif
+
 // Operand-layout probe of the 4x4x1 (16 blocks) f32 MFMA used by the classifier forward: d[lane][r] for given a, b.
 #ifndef WSL_HOST_EMUL
 __global__ void mfma4_probe_kernel(const float* a, const float* b, float* d) {
@@ -438,6 +455,16 @@ __global__ void mfma4_probe_kernel(const float* a, const float* b, float* d) {
 #endif
 
 }  // namespace wsl
+
+extern "C" int wsl_debug_lds_dma_probe(const float* g, float* out, void* stream) {
+#ifndef WSL_HOST_EMUL
+  WSL_LAUNCH(wsl::lds_dma_probe_kernel, dim3(1), dim3(256), 0, stream, g, out);
+  return wsl::check_launch("lds_dma_probe_kernel");
+#else
+  (void)g, (void)out, (void)stream;
+  return WSL_EUNSUPPORTED;
+#endif
+}
 
 extern "C" int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* out, void* stream) {
 #ifndef WSL_HOST_EMUL

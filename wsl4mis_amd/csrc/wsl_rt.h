@@ -15,6 +15,8 @@
 typedef wsl_v4f v4f;
 #define WSL_MFMA16(a, b, c) wsl_emu_mfma16(a, b, c)
 #define WSL_MFMA4(a, b, c) wsl_emu_mfma4(a, b, c)
+#define WSL_LDS_DMA16(gsrc, lds_wave_base) wsl_emu_lds_dma16(gsrc, lds_wave_base)
+#define WSL_WAIT_ALL()
 #define WSL_SCHED_BARRIER()
 #else
 #include <hip/hip_runtime.h>
@@ -28,6 +30,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define WSL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 // v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products; block = l >> 2, D[l][r] = A[4*block + r] * B[l] + C[l][r]
 #define WSL_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0)
+// global_load_lds_dwordx4: every active lane fetches 16 bytes at its own global address; they land at the wave-uniform LDS
+// base + lane * 16 (probed: tools/probe_lds_dma.py), bypassing the VGPRs.  Counted in vmcnt; WSL_WAIT_ALL() before the
+// barrier that publishes the tile.
+#define WSL_LDS_DMA16(gsrc, lds_wave_base)                                                             \
+  __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(gsrc),              \
+                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+#define WSL_WAIT_ALL() __builtin_amdgcn_s_waitcnt(0)
 // keeps the instruction scheduler from moving LDS reads / MFMAs across a software-pipeline stage boundary
 #define WSL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
