@@ -562,6 +562,54 @@ def gen_curve_and_ddp():
     save("g8_ddp", **out)
 
 
+
+def gen_crf_curve():
+    """G9: the headline composition on the reference's own modules -- UNet_CCT, 0.5*(ce1+ce2) + 0.1*GatedCRF(beta*s1 +
+    (1-beta)*s2) (train_ACDC_scribblevc.py:171-206, kernels_desc / radius of ..._pCE_GatedCRFLoss_2D.py:103-123), torch SGD
+    + poly LR, 6 steps on a fixed synthetic batch stream (bs 4, 32x32), with recorded masks; gradients of step 0."""
+    out = {}
+    N, H, W, steps = 4, 32, 32, 6
+    torch.manual_seed(2023)
+    random.seed(2023)
+    model = UNet_CCT(1, 4).train()
+    load_det(model, 9)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    ce = torch.nn.CrossEntropyLoss(ignore_index=4)
+    crf = ModelLossSemsegGatedCRF()
+    gen = torch.Generator().manual_seed(2)
+    xs = torch.rand(steps, N, 1, H, W, generator=gen)
+    labs = np.stack([scribble_labels(N, H, W, seed=300 + s) for s in range(steps)])
+    losses, betas, emasks, cmasks = [], [], [], []
+    for it in range(steps):
+        with DropoutRecorder() as rec:
+            o1, o2 = model(xs[it])
+        beta = random.random() + 1e-10
+        lab = torch.from_numpy(labs[it]).long()
+        s1, s2 = torch.softmax(o1, 1), torch.softmax(o2, 1)
+        loss_ce = 0.5 * (ce(o1, lab) + ce(o2, lab))
+        y = beta * s1 + (1.0 - beta) * s2
+        loss_crf = crf(y, [{"weight": 1, "xy": 6, "rgb": 0.1}], 5, xs[it].clone(), H, W)["loss"]
+        loss = loss_ce + 0.1 * loss_crf
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            pack_param_grads(model, out, "")
+        opt.step()
+        lr_ = 0.01 * (1.0 - it / 60000) ** 0.9
+        for g in opt.param_groups:
+            g["lr"] = lr_
+        losses.append([loss.item(), loss_ce.item(), loss_crf.item()])
+        betas.append(beta)
+        emasks.append([np.packbits(m.ravel()) for m, _ in rec.elem])
+        cmasks.append(rec.chan)
+    out.update(xs=xs.numpy(), labels=labs, betas=np.array(betas), losses=np.array(losses, dtype=np.float32))
+    for it in range(steps):
+        for i in range(5):
+            out[f"em{it}_{i}"] = emasks[it][i]
+            out[f"cm{it}_{i}"] = cmasks[it][i]
+    save("g9_crf_curve", **out)
+
+
 def gen_init_digest():
     """net_factory parity of the *default* torch initialisation (net_factory.py:6-22 builds the module under the
     global torch seed): digest of the reference state_dict for seed 2022."""
@@ -577,9 +625,9 @@ def gen_init_digest():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["init", "convblock", "pool_up", "head", "crf", "tv_ms", "sgd", "net", "curve"]
+    which = sys.argv[1:] or ["init", "convblock", "pool_up", "head", "crf", "tv_ms", "sgd", "net", "curve", "crf_curve"]
     fns = dict(init=gen_init_digest, convblock=gen_convblock, pool_up=gen_pool_up, head=gen_head, crf=gen_crf,
-               tv_ms=gen_tv_ms, sgd=gen_sgd_ema, net=gen_net, curve=gen_curve_and_ddp)
+               tv_ms=gen_tv_ms, sgd=gen_sgd_ema, net=gen_net, curve=gen_curve_and_ddp, crf_curve=gen_crf_curve)
     for w in which:
         print(w)
         fns[w]()

@@ -250,6 +250,43 @@ def test_engine_loss_curve_start(mode):
             assert rel_err(sd[k].cpu().numpy().ravel()[:256], g[f"final.{k}"]) < 5e-2, k
 
 
+def test_engine_gatedcrf_curve_against_reference(mode):
+    """G9: the headline composition -- unet_cct, 0.5 (ce1 + ce2) + 0.1 GatedCRF(beta s1 + (1 - beta) s2), r = 5 -- through
+    the fused engine vs the reference's own modules + torch SGD (train_ACDC_scribblevc.py:171-206 with the GatedCRF term of
+    ..._pCE_GatedCRFLoss_2D.py:103-123): every parameter gradient of the first step, then the loss curve."""
+    from wsl4mis_amd.engine import TrainEngine
+    g = golden("g9_crf_curve")
+    steps = 1 if mode == "emul" else g["xs"].shape[0]
+    eng = TrainEngine("unet_cct", 1, 4, base_lr=0.01, max_iterations=60000, loss="pce_gatedcrf", crf_radius=5)
+    load_det(eng.model, 9)
+    got = []
+    for it in range(steps):
+        xs = T(g["xs"][it])
+        N, _, H, W = xs.shape
+        em = [T(np.unpackbits(g[f"em{it}_{l}"])[:N * (16 << l) * (H >> l) * (W >> l)].reshape(N, 16 << l, H >> l, W >> l))
+              for l in range(5)]
+        cm = [T(g[f"cm{it}_{l}"]) for l in range(5)]
+        eng.model.set_dropout_masks(em, cm)
+        eng.forward_backward(xs, T(g["labels"][it]), float(g["betas"][it]))
+        if it == 0:
+            flat = eng.model.flat_grads().cpu().numpy()
+            off = 0
+            for k, p in eng.model.named_parameters():
+                gr, ref = flat[off:off + p.numel()], g[f"g.{k}"]
+                off += p.numel()
+                assert np.max(np.abs(gr[sample_index(gr.size)] - ref)) <= grad_tol(k, ref), k
+                if not k.endswith(("conv_conv.0.bias", "conv_conv.4.bias")):
+                    assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - g[f"gn.{k}"][0]) <= 1e-4 * g[f"gn.{k}"][0] + 1e-9, k
+            assert off == flat.size
+        eng.optimizer_step()
+        o = eng.losses()
+        got.append([o["loss"], o["ce"], o["crf"]])
+    got, ref = np.array(got), g["losses"][:steps]
+    rel = np.abs(got - ref) / np.abs(ref)
+    assert np.max(rel[:min(2, steps)]) < 1e-4, (got, ref)
+    assert np.max(rel) < 3e-2, (got, ref)                       # (tail: kink flips, as for G7)
+
+
 def test_two_stream_decoders_are_bit_identical_to_one_stream(mode):
     """unet_cct runs its auxiliary decoder on a side stream (wsl_debug_net_concurrent): same bits either way"""
     if mode != "hip":
