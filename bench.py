@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce", "mean_teacher", "ustm", "pce_tv", "pce_ms", "pce_entropy"])
+    ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce", "mean_teacher", "ustm", "pce_tv", "pce_ms", "pce_entropy", "ce_dice"])
     ap.add_argument("--crf-radius", type=int, default=5, help="reference default 5 (11x11); 2 = the 5x5 of BASELINE.json")
     ap.add_argument("--net", default="unet_cct", choices=["unet_cct", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,7 +115,7 @@ def cpu_baseline_subprocess(args):
 
 def main():
     args = parse()
-    if args.loss in ("mean_teacher", "ustm", "pce_tv", "pce_ms", "pce_entropy"):
+    if args.loss in ("mean_teacher", "ustm", "pce_tv", "pce_ms", "pce_entropy", "ce_dice"):
         args.net, args.no_cpu_baseline = "unet", True      # config 4 (and USTM): single-decoder student + EMA teacher
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)

@@ -29,7 +29,7 @@ def main(argv=None):
     ap.add_argument("--fold", default="fold1")
     ap.add_argument("--sup_type", default="scribble")
     ap.add_argument("--model", default="unet_cct", choices=["unet_cct", "unet"])
-    ap.add_argument("--loss", default="ours_proposed", choices=["ours_proposed", "pce", "pce_gatedcrf", "pce_tv", "pce_ms", "pce_entropy", "mean_teacher", "ustm"])
+    ap.add_argument("--loss", default="ours_proposed", choices=["ours_proposed", "pce", "pce_gatedcrf", "pce_tv", "pce_ms", "pce_entropy", "ce_dice", "mean_teacher", "ustm"])
     ap.add_argument("--num_classes", type=int, default=4)
     ap.add_argument("--max_iterations", type=int, default=60000)
     ap.add_argument("--batch_size", type=int, default=12)

@@ -444,7 +444,7 @@ def test_ustm_step_against_oracle(mode):
         off += g.size
 
 
-@pytest.mark.parametrize("kind", ["pce_tv", "pce_ms", "pce_entropy"])
+@pytest.mark.parametrize("kind", ["pce_tv", "pce_ms", "pce_entropy", "ce_dice"])
 def test_regularised_pce_steps_against_oracle(mode, kind):
     """the single-branch pCE + regulariser scripts (TV / Mumford-Shah / entropy minimisation): losses and gradients of one
     engine step vs the oracle's pinned pieces composed like the scripts"""
@@ -456,6 +456,8 @@ def test_regularised_pce_steps_against_oracle(mode, kind):
     gen = torch.Generator().manual_seed(5)
     x = torch.rand((N, 1, S, S), generator=gen)
     lab = torch.from_numpy(scribble_labels(N, S, S, 4, share=0.08))
+    if kind == "ce_dice":                                       # dense labels (fully supervised / random-walker pseudo labels)
+        lab = torch.randint(0, 4, (N, S, S), generator=torch.Generator().manual_seed(6)).to(torch.uint8)
     masks = [(torch.rand((N, 16 << l, S >> l, S >> l), generator=gen) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
     eng = TrainEngine("unet", 1, 4, loss=kind)
     load_det(eng.model, 41)
@@ -472,12 +474,17 @@ def test_regularised_pce_steps_against_oracle(mode, kind):
         reg, w = R.tv_loss(s[1:]), 1e-2
     elif kind == "pce_ms":
         reg, w = R.mumford_shah(x, s), 1e-6
+    elif kind == "ce_dice":
+        reg, w = R.dice(s, lab.long().unsqueeze(1)), 0.5        # train_fully_supervised_2D.py:100-102
+        ce_w = 0.5
     else:
         reg, w = torch.mean(-1 * torch.sum(s * torch.log(s + 1e-6), dim=1) / math.log(4)), 0.1      # losses.py:30-36
-    (ce + w * reg).backward()
+    ce_w = 0.5 if kind == "ce_dice" else 1.0
+    (ce_w * ce + w * reg).backward()
     eng.forward_backward(T(x), T(lab), 0.5)
     o = eng.losses()
-    assert rel_err([o["loss"], o["ce"], o["reg"]], [(ce + w * reg).item(), ce.item(), reg.item()]) < TOL
+    assert rel_err([o["loss"], o["ce"], o["dice" if kind == "ce_dice" else "reg"]],
+                   [(ce_w * ce + w * reg).item(), ce.item(), reg.item()]) < TOL
     flat = eng.model.flat_grads().cpu().numpy()
     off = 0
     for k in pk:

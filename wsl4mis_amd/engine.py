@@ -35,10 +35,12 @@ from .networks.net_factory import net_factory
 
 class TrainEngine:
     # pCE + weight * regulariser(softmax(outputs)) of the single-branch scripts: (weight, reference lines)
-    REGULARISED = ("pce_tv", "pce_ms", "pce_entropy")
+    REGULARISED = ("pce_tv", "pce_ms", "pce_entropy", "ce_dice")
     REG_WEIGHT = {"pce_tv": 1e-2,        # train_weakly_supervised_pCE_TV_2D.py:113-114 (tv_loss on outputs_soft[1:])
                   "pce_ms": 1e-6,        # ..._pCE_MumfordShah_Loss_2D.py:102-103 (MumfordShah_Loss(image, softmax))
-                  "pce_entropy": 0.1}    # ..._pCE_Entropy_Mini_2D.py:99-102 (entropy_loss(softmax, C=4))
+                  "pce_entropy": 0.1,    # ..._pCE_Entropy_Mini_2D.py:99-102 (entropy_loss(softmax, C=4))
+                  "ce_dice": 0.5}        # train_fully_supervised_2D.py:100-102 and ..._pCE_random_walker_2D.py:99-101:
+    #                                      0.5 * (CE(outputs, label) + DiceLoss(softmax, label.unsqueeze(1))) on dense labels
 
     def __init__(self, net_type="unet_cct", in_chns=1, class_num=4, base_lr=0.01, max_iterations=60000, momentum=0.9,
                  weight_decay=1e-4, loss="ours_proposed", w_pse=0.5, crf_radius=5, crf_weight=0.1,
@@ -144,13 +146,15 @@ class TrainEngine:
         return zt
 
     def _regularised_losses(self, x, label_u8, z, t):
-        """pCE + weight * R(softmax(z)) with R = tv_loss([1:]) | MumfordShah(image, .) | entropy_loss(., C)."""
+        """pCE + weight * R(softmax(z)) with R = tv_loss([1:]) | MumfordShah(image, .) | entropy_loss(., C), and the dense-label
+        0.5 * (CE + DiceLoss) of the fully-supervised / random-walker scripts."""
         N, H, W = x.shape[0], x.shape[2], x.shape[3]
         HW, C_ = H * W, self.model.class_num
         nl = rt.L().wsl_loss_ws_bytes(N, C_, HW)
         lws = rt.workspace("loss", nl)
         lo, w = self.loss_out, self.REG_WEIGHT[self.loss_kind]
-        rt.call("wsl_head_fwd_bwd", rt.ptr(z), None, rt.ptr(label_u8), self.ignore, 0.0, 0.0, 1.0, rt.ptr(lo), None,
+        w_ce = 0.5 if self.loss_kind == "ce_dice" else 1.0
+        rt.call("wsl_head_fwd_bwd", rt.ptr(z), None, rt.ptr(label_u8), self.ignore, 0.0, 0.0, w_ce, rt.ptr(lo), None,
                 rt.ptr(t["dz1"]), None, N, C_, HW, rt.ptr(lws), nl, rt.stream())
         rt.call("wsl_softmax_fwd", rt.ptr(z), rt.ptr(t["s"]), N, C_, HW, rt.stream())
         if self.loss_kind == "pce_tv":
@@ -158,6 +162,15 @@ class TrainEngine:
         elif self.loss_kind == "pce_ms":
             rt.call("wsl_mumford_shah_fwd_bwd", rt.ptr(x), rt.ptr(t["s"]), rt.ptr(lo[4:]), rt.ptr(t["ds"]), w, N, C_, H, W,
                     rt.ptr(lws), nl, rt.stream())
+        elif self.loss_kind == "ce_dice":
+            if "dice" not in t:
+                t["dice"] = (torch.empty(3 * C_, dtype=torch.float32, device=z.device),
+                             torch.full((1,), w, dtype=torch.float32, device=z.device))
+            sums, gout = t["dice"]
+            rt.call("wsl_pdice_fwd", rt.ptr(t["s"]), rt.ptr(label_u8), 0, -1, rt.ptr(lo[4:]), rt.ptr(sums), N, C_, HW,
+                    rt.ptr(lws), nl, rt.stream())
+            rt.call("wsl_pdice_bwd", rt.ptr(t["s"]), rt.ptr(label_u8), 0, -1, rt.ptr(sums), rt.ptr(gout), rt.ptr(t["ds"]),
+                    N, C_, HW, rt.stream())
         else:
             rt.call("wsl_entropy_fwd_bwd", rt.ptr(t["s"]), rt.ptr(lo[4:]), rt.ptr(t["ds"]), w, N, C_, HW, rt.ptr(lws), nl, rt.stream())
         rt.call("wsl_softmax_bwd", rt.ptr(t["s"]), rt.ptr(t["ds"]), rt.ptr(t["dzx"]), N, C_, HW, rt.stream())
@@ -292,6 +305,8 @@ class TrainEngine:
         o = self.loss_out.tolist()
         if self.loss_kind == "pce_gatedcrf":
             return {"loss": o[1] + self.crf_weight * o[4], "ce": o[1], "crf": o[4], "n_valid": o[3]}
+        if self.loss_kind == "ce_dice":
+            return {"loss": 0.5 * (o[1] + o[4]), "ce": o[1], "dice": o[4], "n_valid": o[3]}
         if self.loss_kind in self.REGULARISED:  # reg is the raw (unweighted) regulariser
             return {"loss": o[1] + self.REG_WEIGHT[self.loss_kind] * o[4], "ce": o[1], "reg": o[4], "n_valid": o[3]}
         if self.loss_kind == "ustm":           # cons is the raw (unweighted) masked consistency; n_certain = sum(mask)
