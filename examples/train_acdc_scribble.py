@@ -38,6 +38,9 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=2022)
     ap.add_argument("--val_every", type=int, default=200)
     ap.add_argument("--labeled_type", default="labeled")
+    ap.add_argument("--snapshot_path", default=None, help="write the reference's checkpoints here (state_dict .pth files)")
+    ap.add_argument("--save_every", type=int, default=3000)
+    ap.add_argument("--resume", default=None, help="a state_dict .pth (the reference's or ours: same keys) to start from")
     args = ap.parse_args(argv)
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -54,6 +57,10 @@ def main(argv=None):
     aug = BatchRandomGenerator(args.patch_size)
     eng = TrainEngine(args.model, 1, args.num_classes, base_lr=args.base_lr, max_iterations=args.max_iterations,
                       loss=args.loss)
+    if args.resume:
+        eng.model.load_state_dict(torch.load(args.resume, map_location="cpu"))
+    if args.snapshot_path and rank == 0:
+        os.makedirs(args.snapshot_path, exist_ok=True)
     torch.manual_seed(args.seed + 1000 * rank)          # dropout masks differ per rank; beta is shared (python RNG)
     order = np.random.RandomState(args.seed + rank)
     it, best, history = 0, 0.0, []
@@ -73,9 +80,14 @@ def main(argv=None):
             if rank == 0 and len(val) and it % args.val_every == 0:
                 m = np.array([[d for d, _ in val_2D.test_single_volume_cct(v["image"], v["label"], eng.model, args.num_classes,
                                                                           args.patch_size)] for v in (val[i] for i in range(len(val)))])
+                if float(m.mean()) > best and args.snapshot_path:      # ..._ours_proposed.py:174-182
+                    for name in ("iter_{}_dice_{}.pth".format(it, round(float(m.mean()), 4)), "{}_best_model.pth".format(args.model)):
+                        torch.save(eng.model.state_dict(), os.path.join(args.snapshot_path, name))
                 best = max(best, float(m.mean()))
                 print("iteration %d : mean_dice %.4f (best %.4f)" % (it, m.mean(), best), flush=True)
                 eng.model.train()
+            if rank == 0 and args.snapshot_path and it % args.save_every == 0:     # ..._ours_proposed.py:194-198
+                torch.save(eng.model.state_dict(), os.path.join(args.snapshot_path, "iter_" + str(it) + ".pth"))
             if it >= args.max_iterations:
                 break
     return history

@@ -159,8 +159,9 @@ def test_base_datasets_folds_and_samples(mode):
 
 
 @pytest.mark.gpu
-def test_example_trainer_runs_on_the_fixture_files():
-    """data files -> h5lite -> device augmentation -> engine -> validation metrics, end to end on the GPU"""
+def test_example_trainer_runs_on_the_fixture_files(tmp_path):
+    """data files -> h5lite -> device augmentation -> engine -> validation metrics -> the reference's checkpoint files,
+    end to end on the GPU; a second run resumes from the written .pth"""
     import importlib.util
     from wsl4mis_amd import _lib, runtime
     _lib._reset_for_tests()
@@ -170,8 +171,17 @@ def test_example_trainer_runs_on_the_fixture_files():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     hist = mod.main(["--root_path", ACDC, "--fold", "fold3", "--labeled_type", "unlabeled", "--max_iterations", "40",
-                     "--batch_size", "3", "--patch_size", "64", "64", "--val_every", "20"])
+                     "--batch_size", "3", "--patch_size", "64", "64", "--val_every", "20", "--snapshot_path", str(tmp_path),
+                     "--save_every", "40"])
     assert len(hist) == 3 and all(np.isfinite(l) for _, l in hist) and hist[-1][1] < hist[0][1]
+    import torch
+    sd = torch.load(os.path.join(str(tmp_path), "iter_40.pth"), map_location="cpu")        # test_2D_fully_sps.py:147-150
+    assert len(sd) == 202 and sd["encoder.in_conv.conv_conv.1.num_batches_tracked"].dtype == torch.int64
+    assert int(sd["encoder.in_conv.conv_conv.1.num_batches_tracked"]) == 40
+    hist2 = mod.main(["--root_path", ACDC, "--fold", "fold3", "--labeled_type", "unlabeled", "--max_iterations", "20",
+                      "--batch_size", "3", "--patch_size", "64", "64", "--val_every", "50",
+                      "--resume", os.path.join(str(tmp_path), "iter_40.pth")])
+    assert hist2[0][1] < hist[0][1]                                    # starts from the trained weights, not from scratch
 
 
 def test_two_stream_batch_sampler_matches_the_reference_semantics():
