@@ -569,15 +569,30 @@ def gen_crf_curve():
     + poly LR, 6 steps on a fixed synthetic batch stream (bs 4, 32x32), with recorded masks; gradients of step 0."""
     out = {}
     N, H, W, steps = 4, 32, 32, 6
-    torch.manual_seed(2023)
+    best = None
+    for attempt in range(400):     # step 0 carries the strict gradient check: keep its forward clear of the kinks (see gen_net)
+        seed = 2023 + 1000 * attempt
+        torch.manual_seed(seed)
+        model = UNet_CCT(1, 4).train()
+        load_det(model, 9)
+        x0 = torch.rand(steps, N, 1, H, W, generator=torch.Generator().manual_seed(seed))[0]
+        with torch.no_grad(), DropoutRecorder(), KinkMargins() as km:
+            model(x0)
+        if best is None or min(km.leaky, 4 * km.pool) > best[0]:
+            best = (min(km.leaky, 4 * km.pool), seed, km.leaky, km.pool)
+        if km.leaky > 3e-6 and km.pool > 7.5e-7:
+            break
+    seed = best[1]
+    print(f"    crf_curve: seed {seed}, leaky margin {best[2]:.2e}, pool margin {best[3]:.2e}")
+    out["margins"] = np.array([best[2], best[3]])
+    torch.manual_seed(seed)
     random.seed(2023)
     model = UNet_CCT(1, 4).train()
     load_det(model, 9)
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     ce = torch.nn.CrossEntropyLoss(ignore_index=4)
     crf = ModelLossSemsegGatedCRF()
-    gen = torch.Generator().manual_seed(2)
-    xs = torch.rand(steps, N, 1, H, W, generator=gen)
+    xs = torch.rand(steps, N, 1, H, W, generator=torch.Generator().manual_seed(seed))
     labs = np.stack([scribble_labels(N, H, W, seed=300 + s) for s in range(steps)])
     losses, betas, emasks, cmasks = [], [], [], []
     for it in range(steps):

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import ROOT, get_backend, golden, grad_tol
 
@@ -40,3 +41,38 @@ def test_two_rank_gloo_matches_ddp_fixture(tmp_path):
                 bad.append((k, err, float(np.max(np.abs(g[k])))))
     assert not bad, bad[:6]
     assert np.array_equal(r0["params_after"], r1["params_after"])   # replicas stay bit-identical after the step
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_single_rank_rccl_group_takes_the_dp_route_and_changes_nothing():
+    """The N>1 route of bench.py on the real box: RCCL ("nccl") process group, split backward, both gradient buckets
+    all-reduced on the side stream -- in a 1-rank group the result must be bit-identical to the plain step."""
+    code = r"""
+import os, sys, random, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from wsl4mis_amd.engine import TrainEngine
+from wsl4mis_amd.synthetic import batch
+outs = []
+for force in (False, True):
+    torch.manual_seed(5)
+    eng = TrainEngine("unet_cct", 1, 4, loss="pce_gatedcrf", force_dp=force)
+    assert eng.dp == force and (eng.comm is not None) == force
+    x, lab = batch(4, 64, 64, 11, torch.device("cuda", 0))
+    random.seed(3)
+    for _ in range(3):
+        eng.step(x, lab, random.random() + 1e-10)
+    outs.append((eng.model.flat_params().clone(), eng.losses()))
+dist.barrier()
+t = torch.ones(1, device="cuda") * 3
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t) == 3.0
+assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1], (outs[0][1], outs[1][1])
+dist.destroy_process_group()
+print("DP_ROUTE_OK")
+""" % (ROOT, free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "DP_ROUTE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

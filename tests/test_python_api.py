@@ -298,6 +298,7 @@ def test_engine_gatedcrf_curve_against_reference(mode):
             for k, p in eng.model.named_parameters():
                 gr, ref = flat[off:off + p.numel()], g[f"g.{k}"]
                 off += p.numel()
+                # strict: the generator searched step 0 for LeakyReLU / max-pool margins clear of fp32 noise (g["margins"])
                 assert np.max(np.abs(gr[sample_index(gr.size)] - ref)) <= grad_tol(k, ref), k
                 if not k.endswith(("conv_conv.0.bias", "conv_conv.4.bias")):
                     assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - g[f"gn.{k}"][0]) <= 1e-4 * g[f"gn.{k}"][0] + 1e-9, k

@@ -44,7 +44,7 @@ class TrainEngine:
 
     def __init__(self, net_type="unet_cct", in_chns=1, class_num=4, base_lr=0.01, max_iterations=60000, momentum=0.9,
                  weight_decay=1e-4, loss="ours_proposed", w_pse=0.5, crf_radius=5, crf_weight=0.1,
-                 crf_desc=None, ignore_index=4, model=None):
+                 crf_desc=None, ignore_index=4, model=None, force_dp=False):
         if loss not in ("ours_proposed", "pce", "pce_gatedcrf", "mean_teacher", "ustm") + self.REGULARISED:
             raise NotImplementedError(f"loss composition '{loss}'")
         self.model = model if model is not None else net_factory(net_type, in_chns, class_num)
@@ -66,7 +66,9 @@ class TrainEngine:
         self.mom = torch.zeros(self.n + 64, dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(8, dtype=torch.float32, device=dev)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.comm = torch.cuda.Stream() if (self.world > 1 and dev.type == "cuda") else None
+        # force_dp: take the data-parallel route (split backward, bucketed all-reduce on the side stream) in a 1-rank group too
+        self.dp = self.world > 1 or (force_dp and dist.is_available() and dist.is_initialized())
+        self.comm = torch.cuda.Stream() if (self.dp and dev.type == "cuda") else None
         if self.world > 1:   # identical start on every rank
             dist.broadcast(self.model._param_arena, src=0)
             dist.broadcast(self.model._buf_arena, src=0)
@@ -280,7 +282,7 @@ class TrainEngine:
         m = self.model
         g = [t["dz1"], t["dz2"]]
         flat_g = m.flat_grads()
-        if self.world > 1:
+        if self.dp:
             m._run_backward(x, g, phase=1)
             self._allreduce(flat_g[m.n_enc_param:])
             m._run_backward(x, g, phase=2)
