@@ -122,6 +122,34 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
         be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), be.ptr(d["bias"]), be.ptr(y3), Co * H * W, N, H, W, Co, ks, 2,
                 None, None, be.stream)
         assert rel_err(be.np(y3), y_ref.detach().numpy()) < TOL
+    # ---- Winograd F(2x2, 3x3) path for the layers it fits: same outputs and statistics
+    def wino_shape(Ca_, Cb_, Co_):
+        return (ks == 3 and (Ca_ + Cb_) % 8 == 0 and Ca_ + Cb_ <= 256 and (Cb_ == 0 or Ca_ % 8 == 0) and Co_ % 16 == 0
+                and ((H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0)))
+    wino = bool(be.lib.wsl_conv2d_wino_ok(N, H, W, Ca, Cb, Co, ks))
+    assert wino == (variant == 2 and wino_shape(Ca, Cb, Co))
+    if wino:
+        u, y4 = be.zeros((16, Ci, Co)), be.zeros((N, Co, H, W))
+        part4, cnt4 = be.zeros((Co, nblk, 2)), be.zeros((nblk,))
+        be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(u), Co, Ci, ks, 2, be.stream)
+        be.call("wsl_conv2d_fwd", sa, sb, be.ptr(u), be.ptr(d["bias"]), be.ptr(y4), Co * H * W, N, H, W, Co, ks, 4,
+                be.ptr(part4), be.ptr(cnt4), be.stream)
+        assert rel_err(be.np(y4), y_ref.detach().numpy()) < TOL
+        assert rel_err(be.np(y4), be.np(y2)) < 1e-5                     # vs the direct MFMA kernel: fp32 round-off only
+        assert float(be.np(cnt4).sum()) == N * H * W
+        mean4, invstd4, sc4, sh4 = (be.zeros((Co,)) for _ in range(4))
+        g4, b4 = be.arr(np.ones(Co, np.float32)), be.arr(np.zeros(Co, np.float32))
+        be.call("wsl_bn_stats_finalize", be.ptr(part4), be.ptr(cnt4), nblk, Co, be.ptr(g4), be.ptr(b4), 1e-5, 0.1,
+                None, None, None, be.ptr(mean4), be.ptr(invstd4), be.ptr(sc4), be.ptr(sh4), be.stream)
+        yr4 = y_ref.detach()
+        assert rel_err(be.np(mean4), yr4.mean((0, 2, 3)).numpy()) < 1e-5
+        assert rel_err(be.np(invstd4), (1 / torch.sqrt(yr4.var((0, 2, 3), unbiased=False) + 1e-5)).numpy()) < 1e-5
+        y5 = be.zeros((N, Co, H, W))                                     # without statistics / bias
+        be.call("wsl_conv2d_fwd", sa, sb, be.ptr(u), None, be.ptr(y5), Co * H * W, N, H, W, Co, ks, 4, None, None, be.stream)
+        assert rel_err(be.np(y5), (y_ref.detach() - torch.from_numpy(bias)[None, :, None, None]).numpy()) < TOL
+    elif fast and ks == 3:
+        with pytest.raises(Exception, match="wino_ok"):
+            be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), None, be.ptr(y2), Co * H * W, N, H, W, Co, ks, 4, None, None, be.stream)
     # BatchNorm statistics from the epilogue partials
     gamma, beta = be.arr(np.linspace(0.5, 1.5, Co, dtype=np.float32)), be.arr(np.linspace(-0.2, 0.2, Co, dtype=np.float32))
     rm, rv = be.arr(np.full(Co, 0.1, np.float32)), be.arr(np.full(Co, 0.9, np.float32))
@@ -155,6 +183,15 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
         be.call("wsl_conv2d_fwd", sr, be.src(), be.ptr(wpd), None, be.ptr(dx2), Ci * H * W, N, H, W, Ci, ks, 3, None, None,
                 be.stream)
         assert rel_err(be.np(dx2), vin.grad.numpy()) < TOL
+        if bool(be.lib.wsl_conv2d_wino_ok(N, H, W, Co, 0, Ci, ks)):
+            assert variant == 2 and wino_shape(Co, 0, Ci)
+            ud, dx4 = be.zeros((16, Co, Ci)), be.zeros((N, Ci, H, W))
+            be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(ud), Ci, Co, ks, 3, be.stream)
+            be.call("wsl_conv2d_fwd", sr, be.src(), be.ptr(ud), None, be.ptr(dx4), Ci * H * W, N, H, W, Ci, ks, 5, None, None,
+                    be.stream)
+            assert rel_err(be.np(dx4), vin.grad.numpy()) < TOL
+        else:
+            assert not (variant == 2 and wino_shape(Co, 0, Ci))
     # ---- weight / bias gradient
     nws = be.lib.wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks)
     ws, dw, db = be.ws(nws), be.zeros((Co, Ci, ks, ks)), be.zeros((Co,))

@@ -218,13 +218,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 
 struct FwdPlan {
   int th, tw, co_t;
+  bool wino;   // the layer has a Winograd shape and the Winograd kernels are enabled
 };
 // Tile shape of one layer.  Table from tools/sweep_conv_plans.py on MI355X (batch 64; profiles/r1g_conv_timeline.md):
 // 64-pixel-wide tiles only pay for <= 16 output channels; wider layers take 8x32 pixels x as many channels as one
 // workgroup can hold (halves the staging per MFMA); at 16x16 resolution the channel block shrinks until the launch
 // has >= 2 workgroups per CU (a 128-workgroup launch leaves half the chip idle).
 static int g_forced_plan[3] = {-1, 0, 0};   // th, tw, co_t; th < 0: environment not read yet, 0: none
-static FwdPlan fwd_plan(int N, int H, int W, int Co) {
+bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, int* th, int* tw, int* co_t);   // wsl_conv5.hip
+// Winograd F(2x2,3x3) for the 3x3 layers it fits (wsl_conv5.hip): env WSL_CONV_WINO=0|1, wsl_debug_conv_wino()
+#define WSL_WINO_DEFAULT 1
+static int g_wino = -1;
+static bool wino_enabled() {
+  if (g_wino < 0) {
+    const char* e = getenv("WSL_CONV_WINO");
+    g_wino = e ? (atoi(e) != 0) : WSL_WINO_DEFAULT;
+  }
+  return g_wino != 0;
+}
+static FwdPlan fwd_plan(int N, int H, int W, int Co, int Ci, int ks) {
   FwdPlan f;
   // tuning / test aid: WSL_CONV_PLAN=th,tw,co_t or wsl_debug_conv_plan() force one tile shape wherever it divides the layer
   if (g_forced_plan[0] < 0) {
@@ -236,16 +248,20 @@ static FwdPlan fwd_plan(int N, int H, int W, int Co) {
   if (g_forced_plan[0] > 0) {
     const int th = g_forced_plan[0], tw = g_forced_plan[1], ct = g_forced_plan[2];
     if (tw > 0 && W % tw == 0 && ct > 0 && Co % ct == 0) {
-      f.th = th, f.tw = tw, f.co_t = ct;
+      f.th = th, f.tw = tw, f.co_t = ct, f.wino = false;
       return f;
     }
   }
+  f.wino = false;
   if (Co <= 16) {
     f.co_t = 16;
     if (W >= 64) f.th = 8, f.tw = 64; else if (W >= 32) f.th = 8, f.tw = 32; else f.th = 16, f.tw = 16;
+    // a Winograd-shaped layer keeps the Winograd tile in the direct kernels too: one BatchNorm-partial count per layer
+    if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, &f.th, &f.tw, nullptr)) f.wino = true;
     return f;
   }
   if (W >= 32) f.th = 8, f.tw = 32; else f.th = 16, f.tw = 16;
+  if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, &f.th, &f.tw, nullptr)) f.wino = true;
   const int64_t tiles = (int64_t)N * cdiv(H, f.th) * cdiv(W, f.tw);
   const int64_t enough = 2 * (int64_t)device_cu_count();
   f.co_t = Co <= 32 ? 32 : 64;
@@ -540,6 +556,9 @@ bool conv_cls_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t
                        const float* stat_part);                                              // wsl_conv4.hip
 int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H, int W,
                     void* stream);
+int wino_pack(const float* w, float* u, int Co, int Ci, int dgrad, void* stream);   // wsl_conv5.hip
+int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias, float* y, int64_t y_bs, int N, int H,
+             int W, int Co, int is_dgrad, float* stat_part, float* stat_cnt, int slots, void* stream);
 bool conv3_enabled();
 void conv_set_variant(int v);
 int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
@@ -559,6 +578,17 @@ extern "C" int wsl_debug_conv_plan(int th, int tw, int co_t) {
   return WSL_OK;
 }
 
+extern "C" int wsl_debug_conv_wino(int on) {
+  g_wino = on < 0 ? -1 : (on != 0);
+  return WSL_OK;
+}
+
+extern "C" int wsl_conv2d_wino_ok(int N, int H, int W, int Ca, int Cb, int Co, int ks) {
+  if (N <= 0 || Ca <= 0 || Cb < 0) return 0;
+  if (Cb > 0 && (Ca % 8)) return 0;   // a channel chunk never straddles the two sources
+  return fwd_plan(N, H, W, Co, Ca + Cb, ks).wino && !conv3_enabled() ? 1 : 0;
+}
+
 extern "C" int wsl_debug_conv_variant(int v) {
   WSL_REQUIRE(v == 2 || v == 3, "debug_conv_variant: 2 (lock-step, default) or 3 (wave-specialised, experimental)");
   conv_set_variant(v);
@@ -566,8 +596,12 @@ extern "C" int wsl_debug_conv_variant(int v) {
 }
 
 extern "C" int wsl_conv2d_pack_weights(const float* w, float* packed, int Co, int Ci, int ks, int wmode_raw, void* stream) {
-  WSL_REQUIRE(w && packed && Co > 0 && Ci > 0 && (ks == 1 || ks == 3) && (wmode_raw == 0 || wmode_raw == 1),
+  WSL_REQUIRE(w && packed && Co > 0 && Ci > 0 && (ks == 1 || ks == 3) && wmode_raw >= 0 && wmode_raw <= 3,
               "conv2d_pack_weights: bad args");
+  if (wmode_raw >= 2) {   // Winograd image U = G g G^T, [16][Ci][Co]
+    WSL_REQUIRE(ks == 3, "conv2d_pack_weights: the Winograd image exists for 3x3 filters only");
+    return wino_pack(w, packed, Co, Ci, wmode_raw == 3, stream);
+  }
   return conv2_pack(w, packed, Co, Ci, ks, wmode_raw, stream);
 }
 
@@ -578,10 +612,8 @@ extern "C" int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float*
 }
 
 extern "C" int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int ks) {
-  (void)Ci;
-  (void)ks;
   if (N <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
-  const FwdPlan f = fwd_plan(N, H, W, Co);
+  const FwdPlan f = fwd_plan(N, H, W, Co, Ci, ks);
   // one partial per tile; the (opt-in) wave-specialised kernel emits one per MFMA wave = four slots per tile
   return (conv3_enabled() ? 4 : 1) * N * cdiv(H, f.th) * cdiv(W, f.tw);
 }
@@ -592,7 +624,7 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
   WSL_REQUIRE(a && w && y, "conv2d_fwd: null argument");
   WSL_REQUIRE(N > 0 && H > 0 && W > 0 && Co > 0, "conv2d_fwd: bad shape N=%d H=%d W=%d Co=%d", N, H, W, Co);
   WSL_REQUIRE(ks == 1 || ks == 3, "conv2d_fwd: kernel size %d not built (1 and 3 are)", ks);
-  WSL_REQUIRE(wmode >= 0 && wmode <= 3, "conv2d_fwd: wmode %d", wmode);
+  WSL_REQUIRE(wmode >= 0 && wmode <= 5, "conv2d_fwd: wmode %d", wmode);
   WSL_REQUIRE((stat_part == nullptr) == (stat_cnt == nullptr), "conv2d_fwd: stat_part and stat_cnt come together");
   if (int rc = check_src(a, H * W, "conv2d_fwd(a)")) return rc;
   ConvP p;
@@ -608,11 +640,15 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
   p.w = w, p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.Co = Co, p.wmode = wmode;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
   p.slots = conv3_enabled() ? 4 : 1;
-  const FwdPlan f = fwd_plan(N, H, W, Co);
+  const FwdPlan f = fwd_plan(N, H, W, Co, p.in.Ci, ks);
   if (wmode >= 2) {
     if (!conv2_eligible(p.in.a, &p.in.b, y, y_bs, W, p.in.Ci)) {
       set_error("conv2d_fwd: packed weights (wmode %d) need W %% 4 == 0 and 16-byte aligned tensors", wmode);
       return WSL_EINVAL;
+    }
+    if (wmode >= 4) {   // `w` is the Winograd image of wsl_conv2d_pack_weights(wmode_raw 2 | 3)
+      WSL_REQUIRE(f.wino && !conv3_enabled(), "conv2d_fwd: wmode %d needs wsl_conv2d_wino_ok() != 0 for this layer", wmode);
+      return wino_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, wmode == 5, stat_part, stat_cnt, p.slots, stream);
     }
     static const bool cls_on = !(getenv("WSL_CONV_CLS") && atoi(getenv("WSL_CONV_CLS")) == 0);
     if (cls_on && wmode == 2 && conv_cls_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, stat_part))

@@ -1,0 +1,436 @@
+// Winograd F(2x2, 3x3) convolution on the f32 matrix cores (forward and data-gradient of every 3x3 layer whose channel
+// counts are multiples of 8 / 16).  The direct implicit-GEMM kernels (wsl_conv2.hip) are bound by the f32 MFMA rate:
+// 9 * Ci * Co multiply-adds per output pixel.  The minimal-filtering form spends 16 * Ci * Co per 2x2 output tile = 4 per
+// pixel, i.e. 2.25x fewer matrix instructions, for one extra pass over the staged tile:
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//
+//   * U = G g G^T is computed once per optimiser step and layer by wino_pack_table_kernel ([16][Ci][Co], fp32; G holds
+//     0, 1, +-1/2 only);
+//   * a workgroup owns TH x TW output pixels = 64 tiles and CO_T output channels.  Per chunk of 8 input channels it stages
+//     the raw halo tile exactly like conv_mfma2l_kernel (producer BatchNorm + LeakyReLU + dropout masks applied on the
+//     way, aligned float4 loads, register prefetch across the MFMA phase), then every thread transforms the 4x6 patch of
+//     one tile PAIR of one channel (B^T d B: adds only) and writes V[xi][ci][tile] to LDS;
+//   * for each of the 16 transform positions xi the MFMA phase runs D_xi[tile][co] += V_xi[tile][ci] * U_xi[ci][co]
+//     (v_mfma_f32_16x16x4_f32; a wave owns 16 tiles x CO_T channels for all xi = 16 * CO_T/16 accumulator tiles);
+//   * MFMA output element (tile, co) sits in the same lane and register for every xi, so the output transform A^T M A is
+//     register-only; the epilogue adds the bias, stores 2 rows x 8 pixels per lane and channel as float4 and emits the
+//     BatchNorm partials (sum, M2) like the direct kernels.
+// V is stored with an XOR swizzle (tile ^ 16 * (ci & 3)) instead of padding, so the A-operand reads are conflict-free
+// and two workgroups fit the 160 KB LDS of a CU.
+#include <stdlib.h>
+
+#include "wsl_rt.h"
+
+namespace wsl {
+
+struct WSrc {            // one source, device view (as Src2 of wsl_conv2.hip)
+  const float* x;
+  const uint8_t* emask;
+  const float* scale;
+  const float* shift;
+  const float* cmask;
+  int64_t bs;
+  int C;
+  float es;
+};
+
+struct WinoP {
+  WSrc a, b;
+  const float* u;        // [16][Ci][Co]
+  const float* bias;
+  float* y;
+  int64_t y_bs;
+  int N, H, W, Ci, Co, tiles_x, tiles_y;
+  float* stat_part;
+  float* stat_cnt;
+  int slots;
+};
+
+template <int TH, int TW, int CO_T>
+struct WinoCfg {
+  static constexpr int KC = 8, PADL = 4;
+  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4;
+  static constexpr int G = 256 / POS, NLD = KC / G;
+  static constexpr int PLANE = ((ROWS * ROWP - 16 + 31) / 32) * 32 + 16;   // == 16 (mod 32)
+  static constexpr int TTY = TH / 2, TTX = TW / 2, TILES = TTY * TTX;
+  static constexpr int NT = CO_T / 16;
+  static constexpr int CSTR = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;
+  static constexpr int IN_FLOATS = KC * PLANE, V_FLOATS = 16 * KC * TILES, W_FLOATS = 16 * KC * CSTR;
+  static constexpr int WQ = CO_T / 4, WF4 = 16 * KC * WQ, NWL = WF4 / 256;
+  static constexpr int MAXC = 256;
+  static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + V_FLOATS + W_FLOATS + 3 * MAXC);
+  static_assert(TILES == 64 && POS <= 256 && KC % G == 0 && WF4 % 256 == 0 && TTX % 4 == 0, "tile shape");
+  static_assert(8 * CO_T <= IN_FLOATS, "reduction scratch");
+};
+
+template <int TH, int TW, int CO_T>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
+  using C = WinoCfg<TH, TW, CO_T>;
+  constexpr int KC = C::KC;
+  WSL_DYN_SMEM(smem);
+  float* in_t = reinterpret_cast<float*>(smem);                 // raw (transformed-on-load) halo tile [KC][PLANE]
+  float* v_t = in_t + C::IN_FLOATS;                             // B^T d B: [16][KC][TILES], swizzled
+  float* w_t = v_t + C::V_FLOATS;                               // U chunk: [16 * KC][CSTR]
+  float2* tab = reinterpret_cast<float2*>(w_t + C::W_FLOATS);   // [Ci] {scale, shift}
+  float* cm_l = w_t + C::W_FLOATS + 2 * C::MAXC;                // [Ci] channel multiplier of this sample
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD-aware tile order, as conv_mfma2_kernel
+  const int tile_id = bid;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = blockIdx.y * CO_T;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
+  const int HW = H * W;
+
+  // ---- staging position of this thread (as conv_mfma2l_kernel)
+  const int grp = tid / C::POS, pos = tid - grp * C::POS;
+  const int pty = pos / C::ROWP4, ptx4 = pos - pty * C::ROWP4;
+  const int gy = y0 + pty - 1, gx = x0 + ptx4 * 4 - C::PADL;
+  const bool owner = grp < C::G;
+  const bool pvalid = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
+  const uint32_t toff = pvalid ? (uint32_t)(grp * HW + gy * W + gx) : 0u;
+  const int loff = grp * C::PLANE + pty * C::ROWP + ptx4 * 4;
+  const int64_t gstride = (int64_t)C::G * HW;
+  const float* xa_n = p.a.x + n * p.a.bs;
+  const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
+  const uint8_t* ma_n = p.a.emask ? p.a.emask + (int64_t)n * p.a.C * HW : nullptr;
+  const uint8_t* mb_n = (p.b.C && p.b.emask) ? p.b.emask + (int64_t)n * p.b.C * HW : nullptr;
+
+  // U rows of a chunk: row = (xi, c), this thread copies float4 #(tid + i * 256)
+  uint32_t woff[C::NWL];
+  int wl[C::NWL];
+#pragma unroll
+  for (int i = 0; i < C::NWL; ++i) {
+    const int f = tid + i * kThreads;
+    const int row = f / C::WQ, q = f - row * C::WQ;
+    const int xi = row / KC, c = row - xi * KC;
+    woff[i] = (uint32_t)((xi * Ci + c) * Co + q * 4);
+    wl[i] = row * C::CSTR + q * 4;
+  }
+  const float* w_n = p.u + co0;
+
+  float4 pre[C::NLD];
+  uint32_t prm[C::NLD];
+  v4f prw[C::NWL];
+
+  auto issue = [&](int c0) __attribute__((always_inline)) {
+    const bool ina = c0 < p.a.C;                                   // uniform
+    const int chb = ina ? c0 : c0 - p.a.C;
+    const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
+    const uint8_t* mb = ina ? ma_n : mb_n;
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + i * gstride + toff);
+    if (mb) {
+      mb += (int64_t)chb * HW;
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * gstride + toff);
+    }
+    const float* wb = w_n + (int64_t)c0 * Co;
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) prw[i] = *reinterpret_cast<const v4f*>(wb + woff[i]);
+  };
+
+  auto commit = [&](int c0) __attribute__((always_inline)) {
+    if (pvalid) {
+      const bool ina = c0 < p.a.C;
+      const bool has_scale = (ina ? p.a.scale : p.b.scale) != nullptr;
+      const bool has_mask = (ina ? p.a.emask : p.b.emask) != nullptr;
+      const bool has_cm = (ina ? p.a.cmask : p.b.cmask) != nullptr;
+      const float es = ina ? p.a.es : p.b.es;
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) {
+        wsl_v2f lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
+        const int c = c0 + grp + i * C::G;
+        if (has_scale) {
+          const float2 t = tab[c];
+          xform_bn_leaky(lo, hi, t.x, t.y);
+        }
+        if (has_mask) xform_mask(lo, hi, prm[i], es);
+        if (has_cm) {
+          const float cm = cm_l[c];
+          lo = lo * cm, hi = hi * cm;
+        }
+        *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) *reinterpret_cast<v4f*>(w_t + wl[i]) = prw[i];
+  };
+
+  // ---- input transform: this thread owns the tile pair `pr` of channel `tci` of the chunk
+  const int pr = tid & 31, tci = tid >> 5;
+  const int ptyy = pr / (C::TTX / 2), ptx0 = 2 * (pr % (C::TTX / 2));
+  const int roff = tci * C::PLANE + (2 * ptyy) * C::ROWP + (C::PADL - 1) + 2 * ptx0;   // patch origin in the raw tile
+  const int voff = tci * C::TILES + ((ptyy * C::TTX + ptx0) ^ ((tci & 3) << 4));
+  auto wino_in = [&]() __attribute__((always_inline)) {
+    float rt[4][6];
+    {
+      float d[4][6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* r = in_t + roff + i * C::ROWP;
+        const float2 m0 = *reinterpret_cast<const float2*>(r + 1), m1 = *reinterpret_cast<const float2*>(r + 3);
+        d[i][0] = r[0], d[i][1] = m0.x, d[i][2] = m0.y, d[i][3] = m1.x, d[i][4] = m1.y, d[i][5] = r[5];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        rt[0][c] = d[0][c] - d[2][c];
+        rt[1][c] = d[1][c] + d[2][c];
+        rt[2][c] = d[2][c] - d[1][c];
+        rt[3][c] = d[1][c] - d[3][c];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // the two tiles of the pair ride in the two halves of a packed-f32 register pair
+      const wsl_v2f x0 = {rt[i][0], rt[i][2]}, x1 = {rt[i][1], rt[i][3]}, x2 = {rt[i][2], rt[i][4]}, x3 = {rt[i][3], rt[i][5]};
+      const wsl_v2f o0 = x0 - x2, o1 = x1 + x2, o2 = x2 - x1, o3 = x1 - x3;
+      float* vb = v_t + (4 * i) * (KC * C::TILES) + voff;
+      *reinterpret_cast<float2*>(vb) = make_float2(o0[0], o0[1]);
+      *reinterpret_cast<float2*>(vb + KC * C::TILES) = make_float2(o1[0], o1[1]);
+      *reinterpret_cast<float2*>(vb + 2 * KC * C::TILES) = make_float2(o2[0], o2[1]);
+      *reinterpret_cast<float2*>(vb + 3 * KC * C::TILES) = make_float2(o3[0], o3[1]);
+    }
+  };
+
+  issue(0);
+  for (int c = tid; c < Ci; c += kThreads) {
+    const bool ina = c < p.a.C;
+    const WSrc& s = ina ? p.a : p.b;
+    const int ch = ina ? c : c - p.a.C;
+    tab[c] = s.scale ? make_float2(s.scale[ch], s.shift[ch]) : make_float2(1.f, 0.f);
+    cm_l[c] = s.cmask ? s.cmask[(int64_t)n * s.C + ch] : 1.f;
+  }
+  if (owner && !pvalid) {   // positions outside the image stay zero for good
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i)
+      *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  v4f acc[16][C::NT];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  const int a_off = (lane >> 4) * C::TILES + ((16 * wave + (lane & 15)) ^ ((lane >> 4) << 4));
+  const int b_off = (lane >> 4) * C::CSTR + (lane & 15);
+  __syncthreads();   // tables visible
+
+  for (int c0 = 0; c0 < Ci; c0 += KC) {
+    commit(c0);
+    __syncthreads();
+    wino_in();
+    __syncthreads();
+    if (c0 + KC < Ci) issue(c0 + KC);   // in flight during the MFMA phase
+    {
+      constexpr int NS = 16 * (KC / 4);   // stages: all 16 positions of channel group 0, then of group 1
+      float av[2], bv[2][C::NT];
+      auto load = [&](int s, int buf) __attribute__((always_inline)) {
+        const int kg = s >> 4, xi = s & 15;
+        av[buf] = v_t[(xi * KC + kg * 4) * C::TILES + a_off];
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) bv[buf][j] = w_t[(xi * KC + kg * 4) * C::CSTR + j * 16 + b_off];
+      };
+      load(0, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) load(s + 1, (s + 1) & 1);
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) acc[s & 15][j] = WSL_MFMA16(av[s & 1], bv[s & 1][j], acc[s & 15][j]);
+        WSL_SCHED_BARRIER();
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: output transform (register-only), bias, float4 stores, BatchNorm partials
+  const int tb = 16 * wave + 4 * (lane >> 4);          // first of this lane's 4 consecutive tiles
+  const int tyy = tb / C::TTX, txb = tb % C::TTX;
+  float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
+  float o[C::NT][16];
+  float bsum[C::NT];
+#pragma unroll
+  for (int j = 0; j < C::NT; ++j) {
+    const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
+    float bs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s0[4], s1[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float m0 = acc[c][j][r], m1 = acc[4 + c][j][r], m2 = acc[8 + c][j][r], m3 = acc[12 + c][j][r];
+        s0[c] = (m0 + m1) + m2;
+        s1[c] = (m1 - m2) - m3;
+      }
+      const float y00 = ((s0[0] + s0[1]) + s0[2]) + bias, y01 = ((s0[1] - s0[2]) - s0[3]) + bias;
+      const float y10 = ((s1[0] + s1[1]) + s1[2]) + bias, y11 = ((s1[1] - s1[2]) - s1[3]) + bias;
+      o[j][2 * r] = y00, o[j][2 * r + 1] = y01, o[j][8 + 2 * r] = y10, o[j][8 + 2 * r + 1] = y11;
+      bs += (y00 + y01) + (y10 + y11);
+    }
+    float* yj = yb + (int64_t)j * 16 * HW;
+    *reinterpret_cast<float4*>(yj) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+    *reinterpret_cast<float4*>(yj + 4) = make_float4(o[j][4], o[j][5], o[j][6], o[j][7]);
+    *reinterpret_cast<float4*>(yj + W) = make_float4(o[j][8], o[j][9], o[j][10], o[j][11]);
+    *reinterpret_cast<float4*>(yj + W + 4) = make_float4(o[j][12], o[j][13], o[j][14], o[j][15]);
+    bsum[j] = bs;
+  }
+  if (p.stat_part) {
+    float* red1 = in_t;
+    float* red2 = in_t + 4 * CO_T;
+    constexpr float cnt = (float)(TH * TW);
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int col = j * 16 + (lane & 15);
+      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float d = o[j][e] - mean_b;
+        q = fmaf(d, d, q);
+      }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) {
+        const int col = j * 16 + lane, co = co0 + col;
+        float* dst = p.stat_part + ((int64_t)co * ((int64_t)nb * p.slots) + (int64_t)tile_id * p.slots) * 2;   // [Co][slots][2]
+        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+      }
+      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ filter transform
+// U[xi = 4 r + c][ci][co] = (G g G^T)[r][c], g = w[co][ci][:, :] (forward) or the flipped, transposed filter of the
+// data gradient (w[ci][co][2-ky][2-kx] with the GEMM's in/out roles swapped, as pack_weights_kernel's wmode 1).
+__device__ __forceinline__ void wino_filter(const float* w, float* u, int Co, int Ci, int dgrad, int64_t i) {
+  const int co = (int)(i % Co), ci = (int)(i / Co);
+  float g[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+    g[tap] = dgrad ? w[((int64_t)ci * Co + co) * 9 + (8 - tap)] : w[((int64_t)co * Ci + ci) * 9 + tap];
+  float t[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    t[0][c] = g[c];
+    t[1][c] = 0.5f * ((g[c] + g[3 + c]) + g[6 + c]);
+    t[2][c] = 0.5f * ((g[c] - g[3 + c]) + g[6 + c]);
+    t[3][c] = g[6 + c];
+  }
+  const int64_t plane = (int64_t)Ci * Co;
+  float* dst = u + (int64_t)ci * Co + co;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    dst[(4 * r + 0) * plane] = t[r][0];
+    dst[(4 * r + 1) * plane] = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]);
+    dst[(4 * r + 2) * plane] = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]);
+    dst[(4 * r + 3) * plane] = t[r][2];
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* w, float* u, int Co, int Ci, int dgrad) {
+  const int64_t total = (int64_t)Ci * Co;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads)
+    wino_filter(w, u, Co, Ci, dgrad, i);
+}
+
+// every 3x3 layer of a network in ONE launch: blockIdx.y = layer, blockIdx.z = 0 forward image / 1 data-gradient image;
+// the images live at twice the raw weight's arena offset (16/9 of its size)
+__global__ __launch_bounds__(256) void wino_pack_table_kernel(PackTable t, const float* params, float* uf, float* ud) {
+  const PackEntry e = t.e[blockIdx.y];
+  if (e.KK != 9) return;
+  const int dgrad = blockIdx.z;
+  const int Co = dgrad ? e.Ci : e.Co, Ci = dgrad ? e.Co : e.Ci;
+  const int64_t total = (int64_t)Ci * Co;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads)
+    wino_filter(params + e.w, (dgrad ? ud : uf) + 2 * e.w, Co, Ci, dgrad, i);
+}
+
+int wino_pack_table(const PackTable& t, const float* params, float* uf, float* ud, int with_dgrad, void* stream) {
+  WSL_LAUNCH(wino_pack_table_kernel, dim3(16, t.n, with_dgrad ? 2 : 1), dim3(kThreads), 0, stream, t, params, uf, ud);
+  return check_launch("wino_pack_table_kernel");
+}
+
+int wino_pack(const float* w, float* u, int Co, int Ci, int dgrad, void* stream) {
+  int64_t blocks = ((int64_t)Ci * Co + kThreads - 1) / kThreads;
+  if (blocks > 256) blocks = 256;
+  WSL_LAUNCH(wino_pack_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, w, u, Co, Ci, dgrad);
+  return check_launch("wino_pack_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------ launch
+static WSrc to_wsrc(const WslSrc& s) { return WSrc{s.x, s.emask, s.scale, s.shift, s.cmask, s.bs, s.C, s.emask_scale}; }
+
+// shapes the Winograd kernels take; the tile (th x tw pixels) is also what the direct kernels use for such a layer, so
+// the number of BatchNorm partial blocks does not depend on which of the two runs (wsl_conv2d_stat_blocks)
+bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, int* th, int* tw, int* co_t) {
+  if (ks != 3 || Ci % 8 || Ci > 256 || Co % 16 || H <= 0 || W <= 0) return false;
+  int h = 0, w = 0;
+  if (W % 32 == 0 && H % 8 == 0) h = 8, w = 32;
+  else if (W % 16 == 0 && H % 16 == 0) h = 16, w = 16;
+  else return false;
+  if ((int64_t)Ci * H * W >= (int64_t(1) << 31) || (int64_t)16 * Ci * Co >= (int64_t(1) << 31)) return false;
+  if (th) *th = h;
+  if (tw) *tw = w;
+  if (co_t) *co_t = Co % 32 == 0 ? 32 : 16;
+  return true;
+}
+
+template <int TH, int TW, int CO_T>
+static int launch_wino(WinoP& p, int is_dgrad, void* stream) {
+  using C = WinoCfg<TH, TW, CO_T>;
+  auto kern = conv_wino_kernel<TH, TW, CO_T>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
+  const double px = (double)p.N * p.H * p.W;
+  // priced at the DIRECT algorithm's flops (9 multiply-adds per pixel and channel pair): the algorithmic work
+  void* tok = prof_begin(is_dgrad ? 1 : 0, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_wino_kernel");
+}
+
+int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias, float* y, int64_t y_bs, int N, int H,
+             int W, int Co, int is_dgrad, float* stat_part, float* stat_cnt, int slots, void* stream) {
+  WinoP p;
+  p.a = to_wsrc(a);
+  p.b = (b && b->C > 0) ? to_wsrc(*b) : WSrc{};
+  p.u = u, p.bias = bias, p.y = y, p.y_bs = y_bs;
+  p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
+  p.stat_part = stat_part, p.stat_cnt = stat_cnt, p.slots = slots;
+  int th = 0, tw = 0, co_t = 0;
+  if (!wino_shape_ok(H, W, p.Ci, Co, 3, &th, &tw, &co_t) || (p.b.C && (p.a.C % 8))) {
+    set_error("conv2d_fwd: shape N=%d H=%d W=%d Ci=%d(+%d) Co=%d is not a Winograd shape", N, H, W, p.a.C, p.b.C, Co);
+    return WSL_EINVAL;
+  }
+  p.tiles_x = W / tw, p.tiles_y = H / th;
+  if (th == 8 && co_t == 32) return launch_wino<8, 32, 32>(p, is_dgrad, stream);
+  if (th == 8 && co_t == 16) return launch_wino<8, 32, 16>(p, is_dgrad, stream);
+  if (th == 16 && co_t == 32) return launch_wino<16, 16, 32>(p, is_dgrad, stream);
+  return launch_wino<16, 16, 16>(p, is_dgrad, stream);
+}
+
+}  // namespace wsl

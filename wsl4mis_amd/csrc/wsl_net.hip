@@ -35,6 +35,7 @@ struct Plan {
   // scratch reused from layer to layer; a second set lets the two decoders of unet_cct run on two streams
   struct Scratch { size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws; } scr[2];
   size_t packf, packd;
+  size_t winof, winod;   // Winograd filter images [16][Ci][Co] of the 3x3 layers, at twice the raw weight's offset
   size_t wg_bytes, bn_bytes, total_floats;
 };
 
@@ -136,6 +137,7 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   }
   if (d->n_dec == 1) P.scr[1] = P.scr[0];
   P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);  // packed [tap][ci][co] weight images (fwd / data-gradient)
+  P.winof = B.take(2 * P.n_param), P.winod = B.take(2 * P.n_param);
   P.total_floats = B.off;
   return WSL_OK;
 }
@@ -178,9 +180,13 @@ static WslSrc act_src(const Ctx& c, size_t y, size_t st, int C, int HW, const ui
 static int conv_any(const Ctx& c, const ConvRef& cv, int dgrad, const WslSrc* a, const WslSrc* b, const float* bias,
                     float* y, int64_t y_bs, int H, int W, float* stp, float* stc) {
   const int N = c.P.d.N, Co = dgrad ? cv.Ci : cv.Co;
-  if (wsl_conv2d_fast_ok(a, b, y, y_bs, W))
+  if (wsl_conv2d_fast_ok(a, b, y, y_bs, W)) {
+    if (wsl_conv2d_wino_ok(N, H, W, a->C, b ? b->C : 0, Co, cv.ks))
+      return wsl_conv2d_fwd(a, b, c.ws + (dgrad ? c.P.winod : c.P.winof) + 2 * cv.w, bias, y, y_bs, N, H, W, Co, cv.ks,
+                            dgrad ? 5 : 4, stp, stc, c.stream);
     return wsl_conv2d_fwd(a, b, c.ws + (dgrad ? c.P.packd : c.P.packf) + cv.w, bias, y, y_bs, N, H, W, Co, cv.ks,
                           dgrad ? 3 : 2, stp, stc, c.stream);
+  }
   return wsl_conv2d_fwd(a, b, c.params + cv.w, bias, y, y_bs, N, H, W, Co, cv.ks, dgrad, stp, stc, c.stream);
 }
 
@@ -194,7 +200,8 @@ static int pack_all(const Ctx& c, int with_dgrad) {
     for (int i = 0; i < 4; ++i) one(P.dec[k].c1x1[i]), one(P.dec[k].blk[i].c1), one(P.dec[k].blk[i].c2);
     one(P.dec[k].out);
   }
-  return conv2_pack_table(t, c.params, c.ws + P.packf, c.ws + P.packd, with_dgrad, c.stream);
+  WSL_TRY(conv2_pack_table(t, c.params, c.ws + P.packf, c.ws + P.packd, with_dgrad, c.stream));
+  return wino_pack_table(t, c.params, c.ws + P.winof, c.ws + P.winod, with_dgrad, c.stream);
 }
 
 // conv + (train: batch statistics -> BN coefficients | eval: running statistics)

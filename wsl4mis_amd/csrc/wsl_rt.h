@@ -126,5 +126,7 @@ struct PackTable {
   PackEntry e[40];
 };
 int conv2_pack_table(const PackTable& t, const float* params, float* packf, float* packd, int with_dgrad, void* stream);
+// Winograd filter images of the 3x3 entries (wsl_conv5.hip); image of entry e at uf/ud + 2 * e.w
+int wino_pack_table(const PackTable& t, const float* params, float* uf, float* ud, int with_dgrad, void* stream);
 
 }  // namespace wsl
