@@ -171,8 +171,8 @@ def main():
     losses = eng.losses()
 
     def report():
-        rows = (_lib.WslProfRow * 6)()
-        L.wsl_prof_report(rows, 6)
+        rows = (_lib.WslProfRow * 8)()
+        L.wsl_prof_report(rows, 8)
         L.wsl_prof_enable(0)
         fams = {}
         for r in rows:
@@ -187,31 +187,45 @@ def main():
         conv = [r for r in rows if r.calls and r.flops > 0]
         if not conv:
             return None
-        # families 0 and 1 are ONE kernel template (conv_mfma2l_kernel: forward and data-gradient mode; the few
-        # layers outside its shape contract -- first conv, 4-channel classifiers -- run conv_mfma2_kernel)
+        # one entry per kernel template: the direct MFMA convolution (forward + data-gradient launches; the first conv and
+        # the 4-channel classifiers run their own small kernels inside these families), the Winograd F(2x2,3x3) convolution
+        # (the 3x3 layers with >= 32 output channels) and the weight gradient.  The dominant one = most time per step.
+        # Flops are the ALGORITHMIC ones (direct convolution: 2 * 9 * Ci * Co per pixel) for all of them -- the Winograd
+        # kernel issues 2.25x fewer matrix instructions for the same result, so its fraction can pass what a direct kernel
+        # could reach.
         kern = {"conv_mfma2l_kernel (fwd + data-gradient launches)": [r for r in rows[:2] if r.calls],
-                "wgrad_mfma2l_kernel": [r for r in rows[2:3] if r.calls]}
+                "conv_wino_kernel (fwd + data-gradient launches)": [r for r in rows[6:8] if r.calls],
+                "wgrad_mfma2s_kernel": [r for r in rows[2:3] if r.calls]}
+        per_kernel = {k: {"ms_per_step": round(sum(r.ms for r in v) / nsteps, 3), "launches": int(sum(r.calls for r in v)),
+                          "avg_launch_us": round(1e3 * sum(r.ms for r in v) / sum(r.calls for r in v), 2),
+                          "achieved": round(sum(r.flops for r in v) / (sum(r.ms for r in v) * 1e-3) / 1e12, 2),
+                          "frac": round(sum(r.flops for r in v) / (sum(r.ms for r in v) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                      for k, v in kern.items() if v}
         name, grp = max(((k, v) for k, v in kern.items() if v), key=lambda kv: sum(r.ms for r in kv[1]))
         ms, fl, calls = sum(r.ms for r in grp), sum(r.flops for r in grp), sum(r.calls for r in grp)
         ach = fl / (ms * 1e-3) / 1e12
         traffic = None     # HBM bytes per launch of that kernel family from the committed rocprofv3 PMC passes
         try:               # (FETCH_SIZE / WRITE_SIZE, separate runs of this same command -- tools/pmc_traffic.py)
-            with open(os.path.join(ROOT, "profiles", "r1h_pmc_traffic.json")) as fh:
+            tfile = next(f for f in ("r1t_pmc_traffic.json", "r1h_pmc_traffic.json")
+                         if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            with open(os.path.join(ROOT, "profiles", tfile)) as fh:
                 tj = json.load(fh)["kernels"]
-            keys = ("conv_mfma2l_kernel", "conv_mfma2_kernel") if name.startswith("conv") else \
-                   ("wgrad_mfma2l_kernel", "wgrad_mfma2_kernel")
+            keys = ("conv_wino_kernel",) if name.startswith("conv_wino") else \
+                   ("conv_mfma2l_kernel", "conv_mfma2_kernel") if name.startswith("conv") else \
+                   ("wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel")
             nl = sum(tj[k]["launches_sampled"] for k in keys if k in tj)
             traffic = {"hbm_bytes_per_launch": sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["launches_sampled"]
                                                    for k in keys if k in tj) / nl,
                        "algorithmic_bytes_per_launch": sum(r.bytes for r in grp) / calls,
-                       "source": "profiles/r1h_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
-        except (OSError, KeyError, ValueError, ZeroDivisionError):
+                       "source": f"profiles/{tfile} (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+        except (OSError, KeyError, ValueError, ZeroDivisionError, StopIteration):
             pass
         return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,     # HBM bytes per launch (PMC)
                 "traffic_detail": traffic,
                 "launches": int(calls), "avg_launch_us": round(1e3 * ms / calls, 2), "flops_per_launch": fl / calls,
+                "flops_counted": "algorithmic (direct convolution)", "kernels": per_kernel,
                 "all_mfma_kernels_tflops": round(sum(r.flops for r in conv) / (sum(r.ms for r in conv) * 1e-3) / 1e12, 2),
                 "all_mfma_kernels_ms_per_step": round(sum(r.ms for r in conv) / nsteps, 3)}
 

@@ -37,7 +37,7 @@ const char* wsl_build_info(void);   /* "gfx950 hipcc ..." or "HOST-EMULATION (te
 /* Opt-in measurement: HIP events bracket every launch of the heavy kernel families on the launch stream while
  * enabled; wsl_prof_report() waits for those events (the library's only synchronising call) and fills one row per
  * family with the launch count, summed duration and the ALGORITHMIC flops / bytes those launches covered. */
-#define WSL_PROF_FAMILIES 6
+#define WSL_PROF_FAMILIES 8
 typedef struct WslProfRow {
   char name[48];
   int64_t calls;
@@ -84,13 +84,15 @@ int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int ks);
 int wsl_conv2d_pack_weights(const float* w, float* packed, int Co, int Ci, int ks, int wmode_raw, void* stream);
 int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int W);
 /* Winograd F(2x2, 3x3) path (2.25x fewer matrix instructions than the direct form; fp32 throughout): wmode 4 (forward) /
- * 5 (data gradient) take `w` = the filter image U = G g G^T, [16][Ci][Co], produced by
- * wsl_conv2d_pack_weights(w_raw, U, Co, Ci, 3, wmode_raw = 2 | 3) (16 * Ci * Co floats).  Available for the layers with
- * wsl_conv2d_wino_ok() != 0: ks 3, (Ca + Cb) % 8 == 0 and <= 256, Ca % 8 == 0 when there are two sources, Co % 16 == 0,
+ * 5 (data gradient) take `w` = the filter image U = G g G^T produced by
+ * wsl_conv2d_pack_weights(w_raw, U, Co, Ci, 3, wmode_raw = 2 | 3): 16 * Ci * Co floats in the kernel's operand order
+ * (opaque to the caller; needs Ci % 8 == 0 and Co % 16 == 0).  Available for the layers with
+ * wsl_conv2d_wino_ok() != 0: ks 3, (Ca + Cb) % 8 == 0 and <= 256, Ca % 8 == 0 when there are two sources, Co % 32 == 0,
  * (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0), plus the wsl_conv2d_fast_ok() alignment.  Results agree
  * with the direct kernels to fp32 round-off (~1e-6 relative); same BatchNorm partial layout and block count.
- * Env WSL_CONV_WINO=0 / wsl_debug_conv_wino(0) switch it off (wino_ok() then returns 0); wsl_debug_conv_wino(-1) re-reads
- * the environment. */
+ * Env WSL_CONV_WINO / wsl_debug_conv_wino(): 0 off (wino_ok() returns 0), 1 default, 2 also layers with Co % 16 == 0
+ * (measured slower than the direct kernel at 256x256; kept for tests and tuning); wsl_debug_conv_wino(-1) re-reads the
+ * environment. */
 int wsl_conv2d_wino_ok(int N, int H, int W, int Ca, int Cb, int Co, int ks);
 int wsl_debug_conv_wino(int on);
 /* Debug / experiments: which packed-path kernel wsl_conv2d_fwd(wmode 2|3) launches: 2 = lock-step workgroups with a

@@ -64,8 +64,10 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
 def variant(request, be):
     """packed-path kernel: 2 = lock-step (default), 3 = wave-specialised persistent (experimental)"""
     be.call("wsl_debug_conv_variant", request.param)
+    be.call("wsl_debug_conv_wino", 2)          # Winograd wherever it fits, including the 16-channel blocks
     yield request.param
     be.call("wsl_debug_conv_variant", 2)
+    be.call("wsl_debug_conv_wino", -1)
 
 
 @pytest.mark.parametrize("case", CASES)

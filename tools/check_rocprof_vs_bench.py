@@ -6,9 +6,16 @@ import json
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-fam = [r for r in rows if "conv_mfma2l_kernel" in r["Name"] or "conv_mfma2_kernel" in r["Name"]]
-t, c = sum(int(r["TotalDurationNs"]) for r in fam), sum(int(r["Calls"]) for r in fam)
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 r = d["roofline"]
-print(f"rocprofv3: {c} launches, avg {t / c / 1e3:.2f} us | bench.py events: {r['launches']} launches, avg {r['avg_launch_us']} us, "
-      f"{r['achieved']} TFLOP/s | value {d['value']} slices/s")
+# rocprofv3 kernel names that bench.py's event families cover (the small first-conv / classifier kernels ride in the conv
+# and weight-gradient families of the library's event bracketing)
+NAMES = {"conv_mfma2l_kernel": ("conv_mfma2l_kernel", "conv_mfma2_kernel", "conv_cls_kernel"),
+         "conv_wino_kernel": ("conv_wino_kernel",),
+         "wgrad_mfma2s_kernel": ("wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel", "wgrad_small_kernel")}
+for kname, k in r.get("kernels", {r["kernel"]: r}).items():
+    fam = [x for x in rows if any(n in x["Name"] for n in NAMES[kname.split()[0]])]
+    t, c = sum(int(x["TotalDurationNs"]) for x in fam), sum(int(x["Calls"]) for x in fam)
+    print(f"{kname.split()[0]:22s} rocprofv3: {c} launches, avg {t / max(c, 1) / 1e3:.2f} us | bench.py events: {k['launches']} launches, "
+          f"avg {k['avg_launch_us']} us, {k['achieved']} TFLOP/s")
+print(f"dominant: {r['kernel']} | value {d['value']} slices/s")

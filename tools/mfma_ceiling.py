@@ -26,3 +26,19 @@ for shape in (0, 1, 2):
         ms = e0.elapsed_time(e1)
         fl = blocks * 4 * iters * 16 * FL[shape]
         print(f"{NAME[shape]:18s} {wg_per_cu} waves/SIMD: {ms:7.2f} ms  {fl / ms / 1e9:7.1f} TFLOP/s")
+
+# f32 VALU work next to the MFMA stream (16x16x4): K v_fma_f32 per MFMA in the same wave (100 + K) or in the SIMD's
+# second wave (200 + K, 8-wave workgroups: waves 0-3 MFMA, waves 4-7 VALU).  MFMA TFLOP/s only (the FMAs are not counted).
+for shape in (102, 104, 108, 116, 202, 204, 208, 216):
+    blocks, iters = 256, 20000
+    for _ in range(2):
+        _lib.check(L.wsl_debug_mfma_stream(shape, blocks, iters, out.data_ptr(), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(L.wsl_debug_mfma_stream(shape, blocks, iters, out.data_ptr(), st))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    fl = blocks * 4 * iters * 16 * FL[0]
+    print(f"16x16x4 + {shape % 100:2d} v_fma_f32 per MFMA in the {'same' if shape < 200 else 'partner'} wave: {ms:7.2f} ms  "
+          f"{fl / ms / 1e9:7.1f} TFLOP/s (MFMA flops)")

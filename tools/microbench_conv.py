@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times one conv layer through the C ABI (packed fast path) with HIP events on the launch stream.
-   python tools/microbench_conv.py N Ci Co H W [ks] [dgrad]      (WSL_CONV_ABLATE=1|2|4 for phase ablations)"""
+   python tools/microbench_conv.py N Ci Co H W [ks] [dgrad]      (WSL_CONV_ABLATE=1|2|4 for phase ablations;
+   MB_WINO=1: the Winograd kernel (wmode 4) where the layer has a Winograd shape; MB_RAW=1: a plain source)"""
 import ctypes as C
 import os
 import sys
@@ -26,11 +27,14 @@ if not os.environ.get("MB_RAW"):          # MB_RAW=1: a plain source (what every
 nblk = L.wsl_conv2d_stat_blocks(N, H, W, Ci, Co, ks)
 part, cnt = torch.zeros(max(nblk * Co * 2, nblk * 64), device=dev), torch.empty(nblk, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-_lib.check(L.wsl_conv2d_pack_weights(w.data_ptr(), wp.data_ptr(), Co, Ci, ks, 0, st))
+wino = bool(os.environ.get("MB_WINO")) and bool(L.wsl_conv2d_wino_ok(N, H, W, Ci, 0, Co, ks))
+if wino:
+    wp = torch.empty(16 * Ci * Co, device=dev)
+_lib.check(L.wsl_conv2d_pack_weights(w.data_ptr(), wp.data_ptr(), Co, Ci, ks, 2 if wino else 0, st))
 
 
 def run():
-    _lib.check(L.wsl_conv2d_fwd(C.byref(s), None, wp.data_ptr(), None, y.data_ptr(), Co * H * W, N, H, W, Co, ks, 2,
+    _lib.check(L.wsl_conv2d_fwd(C.byref(s), None, wp.data_ptr(), None, y.data_ptr(), Co * H * W, N, H, W, Co, ks, 4 if wino else 2,
                                 part.data_ptr(), cnt.data_ptr(), st))
 
 
@@ -45,7 +49,7 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / R
 fl = 2.0 * N * H * W * Co * Ci * ks * ks
-print(f"ablate={os.environ.get('WSL_CONV_ABLATE','0')} N={N} {Ci}->{Co} {H}x{W} k{ks}: {us:8.1f} us  {fl/us/1e6:7.1f} TFLOP/s  "
+print(f"{'wino ' if wino else 'direct '}ablate={os.environ.get('WSL_CONV_ABLATE','0')} N={N} {Ci}->{Co} {H}x{W} k{ks}: {us:8.1f} us  {fl/us/1e6:7.1f} TFLOP/s  "
       f"in+out {4.0*N*H*W*(Ci+Co)/us/1e3:7.1f} GB/s")
 
 if int(os.environ.get('WSL_CONV_ABLATE', '0')) & 64:
@@ -69,6 +73,8 @@ if int(os.environ.get('WSL_CONV_ABLATE', '0')) & 128:
     print(f'{len(t)} workgroups stamped; shader clock {f:.0f} MHz; kernel span {(t[:, 30].max() - rt0) / 100.0:.1f} us')
     nch = min((Ci + 7) // 8, 4)
     names = ['prologue(issue0+tables)'] + sum([[f'c{c}:wait-data', f'c{c}:commit', f'c{c}:barrier', f'c{c}:issue', f'c{c}:mfma', f'c{c}:barrier2'] for c in range(nch)], []) + ['epilogue']
+    if wino:
+        names = ['prologue(issue0+tables)'] + sum([[f'c{c}:barrier+wait-data', f'c{c}:commit+issue', f'c{c}:barrier', f'c{c}:input transform', f'c{c}:barrier', f'c{c}:mfma'] for c in range(nch)], []) + ['barrier+out transform+stores']
     idx = [0, 1] + sum([[2 + 6 * c + j for j in range(6)] for c in range(nch)], []) + [26]
     d = np.diff(t[:, idx], axis=1)
     slot = hw & 0xf

@@ -20,9 +20,8 @@ def per_kernel(d, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        fam = ("conv_mfma2l_kernel" if "conv_mfma2l_kernel" in k else "wgrad_mfma2l_kernel" if "wgrad_mfma2l_kernel" in k
-               else "conv_mfma2_kernel" if "conv_mfma2_kernel" in k else "wgrad_mfma2_kernel" if "wgrad_mfma2_kernel" in k
-               else None)
+        fam = next((f for f in ("conv_wino_kernel", "conv_mfma2l_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel",
+                                "conv_mfma2_kernel", "wgrad_mfma2_kernel") if f in k), None)
         if fam is None:
             continue
         key = (r["Dispatch_Id"], fam)

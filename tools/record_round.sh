@@ -13,7 +13,11 @@ O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd "$R"
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_serial" -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --serial-decoders > "$R/$O/bench_serial_under_rocprof.log" 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_default" -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+# HBM traffic of the MFMA kernels: two counter-only passes (never combined with a trace domain)
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$O/pmc_fetch" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --serial-decoders --no-prof > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/$O/pmc_write" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --serial-decoders --no-prof > /dev/null 2>&1
 cd "$R"; rm -f "$O"/prof_*/*/*kernel_trace.csv
+python tools/pmc_traffic.py "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_traffic.json" > /dev/null 2>&1; rm -rf "$O/pmc_fetch" "$O/pmc_write"
 tail -1 "$O/pytest_gpu.log"; cat "$O/smoke.log"
 for f in default ours crf_r2 mt serial; do python - "$O/bench_$f.json" "$f" <<'PY'
 import json, sys

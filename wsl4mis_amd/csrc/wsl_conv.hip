@@ -225,14 +225,16 @@ struct FwdPlan {
 // workgroup can hold (halves the staging per MFMA); at 16x16 resolution the channel block shrinks until the launch
 // has >= 2 workgroups per CU (a 128-workgroup launch leaves half the chip idle).
 static int g_forced_plan[3] = {-1, 0, 0};   // th, tw, co_t; th < 0: environment not read yet, 0: none
-bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, int* th, int* tw, int* co_t);   // wsl_conv5.hip
-// Winograd F(2x2,3x3) for the 3x3 layers it fits (wsl_conv5.hip): env WSL_CONV_WINO=0|1, wsl_debug_conv_wino()
+bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, int* tw, int* co_t);   // wsl_conv5.hip
+// Winograd F(2x2,3x3) for the 3x3 layers it fits (wsl_conv5.hip): env WSL_CONV_WINO / wsl_debug_conv_wino():
+// 0 off, 1 layers with Co % 32 == 0 (default), 2 also Co % 16 == 0
 #define WSL_WINO_DEFAULT 1
 static int g_wino = -1;
 static bool wino_enabled() {
   if (g_wino < 0) {
     const char* e = getenv("WSL_CONV_WINO");
-    g_wino = e ? (atoi(e) != 0) : WSL_WINO_DEFAULT;
+    g_wino = e ? atoi(e) : WSL_WINO_DEFAULT;
+    if (g_wino < 0 || g_wino > 2) g_wino = WSL_WINO_DEFAULT;
   }
   return g_wino != 0;
 }
@@ -257,11 +259,11 @@ static FwdPlan fwd_plan(int N, int H, int W, int Co, int Ci, int ks) {
     f.co_t = 16;
     if (W >= 64) f.th = 8, f.tw = 64; else if (W >= 32) f.th = 8, f.tw = 32; else f.th = 16, f.tw = 16;
     // a Winograd-shaped layer keeps the Winograd tile in the direct kernels too: one BatchNorm-partial count per layer
-    if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, &f.th, &f.tw, nullptr)) f.wino = true;
+    if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, g_wino == 2, &f.th, &f.tw, nullptr)) f.wino = true;
     return f;
   }
   if (W >= 32) f.th = 8, f.tw = 32; else f.th = 16, f.tw = 16;
-  if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, &f.th, &f.tw, nullptr)) f.wino = true;
+  if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, g_wino == 2, &f.th, &f.tw, nullptr)) f.wino = true;
   const int64_t tiles = (int64_t)N * cdiv(H, f.th) * cdiv(W, f.tw);
   const int64_t enough = 2 * (int64_t)device_cu_count();
   f.co_t = Co <= 32 ? 32 : 64;
@@ -579,7 +581,7 @@ extern "C" int wsl_debug_conv_plan(int th, int tw, int co_t) {
 }
 
 extern "C" int wsl_debug_conv_wino(int on) {
-  g_wino = on < 0 ? -1 : (on != 0);
+  g_wino = on < 0 ? -1 : (on > 2 ? 2 : on);
   return WSL_OK;
 }
 

@@ -425,6 +425,47 @@ __global__ __launch_bounds__(256) void mfma_stream_kernel(float* out, int iters)
   }
   if (r == 123.456f) out[0] = r;
 }
+
+// Does ordinary f32 VALU work overlap with the f32 MFMA stream?  MODE 0: every wave issues K independent v_fma_f32 after
+// each MFMA (same wave).  MODE 1: 8-wave workgroups, waves 0-3 run the pure MFMA stream, waves 4-7 (the second wave of
+// each SIMD) run K v_fma_f32 per MFMA-time slot -- tools/mfma_ceiling.py prints the MFMA rate each way.
+template <int MODE, int K>
+__global__ __launch_bounds__(512) void mfma_valu_mix_kernel(float* out, int iters) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+  v4 acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = v4{0.f, 0.f, 0.f, 0.f};
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = a + i;
+  const bool mfma_wave = MODE == 0 || (threadIdx.x >> 6) < 4;
+  const bool valu_wave = MODE == 0 || (threadIdx.x >> 6) >= 4;
+  if (mfma_wave && valu_wave) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[k & 7] = __builtin_fmaf(x[k & 7], 1.0001f, 0.5f);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, K, 0);
+      }
+    }
+  } else if (mfma_wave) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16 * K; ++i) x[i & 7] = __builtin_fmaf(x[i & 7], 1.0001f, 0.5f);
+    }
+  }
+  float r = 0.f;
+  for (int i = 0; i < 16; ++i) r += acc[i][0];
+  for (int i = 0; i < 8; ++i) r += x[i];
+  if (r == 123.456f) out[0] = r;
+}
 #endif
 
 // Destination-layout probe of global_load_lds_dwordx4 (LDS DMA): every lane fetches its own 16 bytes; where do they land?
@@ -470,7 +511,20 @@ extern "C" int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* ou
 #ifndef WSL_HOST_EMUL
   if (shape == 0) WSL_LAUNCH(wsl::mfma_stream_kernel<0>, dim3(blocks), dim3(256), 0, stream, out, iters);
   else if (shape == 1) WSL_LAUNCH(wsl::mfma_stream_kernel<1>, dim3(blocks), dim3(256), 0, stream, out, iters);
-  else WSL_LAUNCH(wsl::mfma_stream_kernel<2>, dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 2) WSL_LAUNCH(wsl::mfma_stream_kernel<2>, dim3(blocks), dim3(256), 0, stream, out, iters);
+  // 100 + K: K v_fma_f32 per MFMA in the same wave; 200 + K: in the partner wave of the SIMD (8-wave workgroups)
+  else if (shape == 102) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<0, 2>), dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 104) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<0, 4>), dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 108) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<0, 8>), dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 116) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<0, 16>), dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 202) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<1, 2>), dim3(blocks), dim3(512), 0, stream, out, iters);
+  else if (shape == 204) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<1, 4>), dim3(blocks), dim3(512), 0, stream, out, iters);
+  else if (shape == 208) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<1, 8>), dim3(blocks), dim3(512), 0, stream, out, iters);
+  else if (shape == 216) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<1, 16>), dim3(blocks), dim3(512), 0, stream, out, iters);
+  else {
+    wsl::set_error("debug_mfma_stream: shape %d", shape);
+    return WSL_EINVAL;
+  }
   return wsl::check_launch("mfma_stream_kernel");
 #else
   (void)shape, (void)blocks, (void)iters, (void)out, (void)stream;

@@ -37,7 +37,7 @@ struct WSrc {            // one source, device view (as Src2 of wsl_conv2.hip)
 
 struct WinoP {
   WSrc a, b;
-  const float* u;        // [16][Ci][Co]
+  const float* u;        // 16 * Ci * Co floats, blocked operand order (wino_filter)
   const float* bias;
   float* y;
   int64_t y_bs;
@@ -45,6 +45,7 @@ struct WinoP {
   float* stat_part;
   float* stat_cnt;
   int slots;
+  int ablate;   // debug (env WSL_CONV_ABLATE): 128 = per-workgroup timeline stamps into stat_part (tools/microbench_conv.py)
 };
 
 template <int TH, int TW, int CO_T>
@@ -55,9 +56,8 @@ struct WinoCfg {
   static constexpr int PLANE = ((ROWS * ROWP - 16 + 31) / 32) * 32 + 16;   // == 16 (mod 32)
   static constexpr int TTY = TH / 2, TTX = TW / 2, TILES = TTY * TTX;
   static constexpr int NT = CO_T / 16;
-  static constexpr int CSTR = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;
-  static constexpr int IN_FLOATS = KC * PLANE, V_FLOATS = 16 * KC * TILES, W_FLOATS = 16 * KC * CSTR;
-  static constexpr int WQ = CO_T / 4, WF4 = 16 * KC * WQ, NWL = WF4 / 256;
+  static constexpr int IN_FLOATS = KC * PLANE, V_FLOATS = 16 * KC * TILES, W_FLOATS = 16 * KC * CO_T;
+  static constexpr int WF4 = W_FLOATS / 4, NWL = WF4 / 256;
   static constexpr int MAXC = 256;
   static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + V_FLOATS + W_FLOATS + 3 * MAXC);
   static_assert(TILES == 64 && POS <= 256 && KC % G == 0 && WF4 % 256 == 0 && TTX % 4 == 0, "tile shape");
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
   WSL_DYN_SMEM(smem);
   float* in_t = reinterpret_cast<float*>(smem);                 // raw (transformed-on-load) halo tile [KC][PLANE]
   float* v_t = in_t + C::IN_FLOATS;                             // B^T d B: [16][KC][TILES], swizzled
-  float* w_t = v_t + C::V_FLOATS;                               // U chunk: [16 * KC][CSTR]
+  float* w_t = v_t + C::V_FLOATS;                               // U chunk, operand order: [16 xi][4 k][16 col][2 kg][NT j]
   float2* tab = reinterpret_cast<float2*>(w_t + C::W_FLOATS);   // [Ci] {scale, shift}
   float* cm_l = w_t + C::W_FLOATS + 2 * C::MAXC;                // [Ci] channel multiplier of this sample
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,18 +102,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
   const uint8_t* ma_n = p.a.emask ? p.a.emask + (int64_t)n * p.a.C * HW : nullptr;
   const uint8_t* mb_n = (p.b.C && p.b.emask) ? p.b.emask + (int64_t)n * p.b.C * HW : nullptr;
 
-  // U rows of a chunk: row = (xi, c), this thread copies float4 #(tid + i * 256)
-  uint32_t woff[C::NWL];
-  int wl[C::NWL];
-#pragma unroll
-  for (int i = 0; i < C::NWL; ++i) {
-    const int f = tid + i * kThreads;
-    const int row = f / C::WQ, q = f - row * C::WQ;
-    const int xi = row / KC, c = row - xi * KC;
-    woff[i] = (uint32_t)((xi * Ci + c) * Co + q * 4);
-    wl[i] = row * C::CSTR + q * 4;
-  }
-  const float* w_n = p.u + co0;
+  // U block of a chunk and channel block: W_FLOATS contiguous floats in the packed image (wino_filter), copied verbatim
+  const float* w_n = p.u + (int64_t)blockIdx.y * C::W_FLOATS + 4 * tid;
+  const int64_t w_cstride = (int64_t)(Co / CO_T) * C::W_FLOATS;   // floats between the blocks of consecutive chunks
 
   float4 pre[C::NLD];
   uint32_t prm[C::NLD];
@@ -131,9 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 #pragma unroll
       for (int i = 0; i < C::NLD; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * gstride + toff);
     }
-    const float* wb = w_n + (int64_t)c0 * Co;
+    const float* wb = w_n + (c0 / KC) * w_cstride;
 #pragma unroll
-    for (int i = 0; i < C::NWL; ++i) prw[i] = *reinterpret_cast<const v4f*>(wb + woff[i]);
+    for (int i = 0; i < C::NWL; ++i) prw[i] = *reinterpret_cast<const v4f*>(wb + i * (4 * kThreads));
   };
 
   auto commit = [&](int c0) __attribute__((always_inline)) {
@@ -143,24 +134,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
       const bool has_mask = (ina ? p.a.emask : p.b.emask) != nullptr;
       const bool has_cm = (ina ? p.a.cmask : p.b.cmask) != nullptr;
       const float es = ina ? p.a.es : p.b.es;
+      // all table reads of the chunk up front (one LDS round trip instead of one per load: only two waves per SIMD hide it)
+      float2 tb[C::NLD];
+      float cmv[C::NLD];
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) tb[i] = tab[c0 + grp + i * C::G], cmv[i] = cm_l[c0 + grp + i * C::G];
 #pragma unroll
       for (int i = 0; i < C::NLD; ++i) {
         wsl_v2f lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
-        const int c = c0 + grp + i * C::G;
-        if (has_scale) {
-          const float2 t = tab[c];
-          xform_bn_leaky(lo, hi, t.x, t.y);
-        }
+        if (has_scale) xform_bn_leaky(lo, hi, tb[i].x, tb[i].y);
         if (has_mask) xform_mask(lo, hi, prm[i], es);
-        if (has_cm) {
-          const float cm = cm_l[c];
-          lo = lo * cm, hi = hi * cm;
-        }
+        if (has_cm) lo = lo * cmv[i], hi = hi * cmv[i];
         *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < C::NWL; ++i) *reinterpret_cast<v4f*>(w_t + wl[i]) = prw[i];
+    for (int i = 0; i < C::NWL; ++i) *reinterpret_cast<v4f*>(w_t + 4 * tid + i * (4 * kThreads)) = prw[i];
   };
 
   // ---- input transform: this thread owns the tile pair `pr` of channel `tci` of the chunk
@@ -198,6 +187,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
     }
   };
 
+#ifndef WSL_HOST_EMUL
+  uint64_t* tl = (p.ablate & 128) ? reinterpret_cast<uint64_t*>(p.stat_part) + (int64_t)tile_id * 32 : nullptr;
+#define WSL_MARK(k) do { if (tl && tid == 0) tl[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  if (tl && tid == 0) tl[29] = __builtin_amdgcn_s_memrealtime(), tl[28] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#else
+#define WSL_MARK(k)
+#endif
+  WSL_MARK(0);
   issue(0);
   for (int c = tid; c < Ci; c += kThreads) {
     const bool ina = c < p.a.C;
@@ -218,33 +215,56 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 #pragma unroll
     for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
   const int a_off = (lane >> 4) * C::TILES + ((16 * wave + (lane & 15)) ^ ((lane >> 4) << 4));
-  const int b_off = (lane >> 4) * C::CSTR + (lane & 15);
+  const int b_off = lane * (2 * C::NT);   // ((k = lane >> 4) * 16 + (col = lane & 15)) * (2 kg * NT j)
   __syncthreads();   // tables visible
+  WSL_MARK(1);
 
   for (int c0 = 0; c0 < Ci; c0 += KC) {
+#ifndef WSL_HOST_EMUL
+    const int mk = 2 + 6 * (c0 / KC < 4 ? c0 / KC : 3);
+    if (tl) __builtin_amdgcn_s_waitcnt(0);   // prefetched data has arrived
+#endif
+    WSL_MARK(mk);
     commit(c0);
+    // the MFMA phase of a chunk is 2.25x shorter than the direct kernel's and no longer covers the HBM latency by itself:
+    // the next chunk's loads go out as soon as the staging registers are free and fly across transform + MFMA phase
+    if (c0 + KC < Ci) issue(c0 + KC);
+    WSL_MARK(mk + 1);
     __syncthreads();
+    WSL_MARK(mk + 2);
     wino_in();
+    WSL_MARK(mk + 3);
     __syncthreads();
-    if (c0 + KC < Ci) issue(c0 + KC);   // in flight during the MFMA phase
+    WSL_MARK(mk + 4);
     {
-      constexpr int NS = 16 * (KC / 4);   // stages: all 16 positions of channel group 0, then of group 1
-      float av[2], bv[2][C::NT];
-      auto load = [&](int s, int buf) __attribute__((always_inline)) {
-        const int kg = s >> 4, xi = s & 15;
-        av[buf] = v_t[(xi * KC + kg * 4) * C::TILES + a_off];
-#pragma unroll
-        for (int j = 0; j < C::NT; ++j) bv[buf][j] = w_t[(xi * KC + kg * 4) * C::CSTR + j * 16 + b_off];
+      // one stage per transform position: both channel groups (kg) and all channel tiles (j) of the B operand arrive in
+      // ONE LDS read (the packed image stores them next to each other); the A operand takes one read per channel group
+      float av[2][2];
+      float bv[2][2 * C::NT];
+      auto load = [&](int xi, int buf) __attribute__((always_inline)) {
+        av[buf][0] = v_t[(xi * KC) * C::TILES + a_off];
+        av[buf][1] = v_t[(xi * KC + 4) * C::TILES + a_off];
+        const float* bp = w_t + xi * (4 * 16 * 2 * C::NT) + b_off;
+        if constexpr (C::NT == 2) {
+          const v4f b4 = *reinterpret_cast<const v4f*>(bp);
+          bv[buf][0] = b4[0], bv[buf][1] = b4[1], bv[buf][2] = b4[2], bv[buf][3] = b4[3];
+        } else {
+          const float2 b2 = *reinterpret_cast<const float2*>(bp);
+          bv[buf][0] = b2.x, bv[buf][1] = b2.y;
+        }
       };
       load(0, 0);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (s + 1 < NS) load(s + 1, (s + 1) & 1);
+      for (int xi = 0; xi < 16; ++xi) {
+        if (xi + 1 < 16) load(xi + 1, (xi + 1) & 1);
 #pragma unroll
-        for (int j = 0; j < C::NT; ++j) acc[s & 15][j] = WSL_MFMA16(av[s & 1], bv[s & 1][j], acc[s & 15][j]);
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+          for (int j = 0; j < C::NT; ++j) acc[xi][j] = WSL_MFMA16(av[xi & 1][kg], bv[xi & 1][kg * C::NT + j], acc[xi][j]);
         WSL_SCHED_BARRIER();
       }
     }
+    WSL_MARK(mk + 5);
     __syncthreads();
   }
 
@@ -279,6 +299,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
     *reinterpret_cast<float4*>(yj + W + 4) = make_float4(o[j][12], o[j][13], o[j][14], o[j][15]);
     bsum[j] = bs;
   }
+#ifndef WSL_HOST_EMUL
+  if (tl) {
+    __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
+    WSL_MARK(26);
+    if (tid == 0) tl[30] = __builtin_amdgcn_s_memrealtime();
+    return;
+  }
+#endif
+#undef WSL_MARK
   if (p.stat_part) {
     float* red1 = in_t;
     float* red2 = in_t + 4 * CO_T;
@@ -320,8 +349,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 }
 
 // ------------------------------------------------------------------------------------------------ filter transform
-// U[xi = 4 r + c][ci][co] = (G g G^T)[r][c], g = w[co][ci][:, :] (forward) or the flipped, transposed filter of the
-// data gradient (w[ci][co][2-ky][2-kx] with the GEMM's in/out roles swapped, as pack_weights_kernel's wmode 1).
+// U(xi = 4 r + c, ci, co) = (G g G^T)[r][c], g = w[co][ci][:, :] (forward) or the flipped, transposed filter of the
+// data gradient (w[ci][co][2-ky][2-kx] with the GEMM's in/out roles swapped, as pack_weights_kernel's wmode 1), stored in
+// the order the kernel's B-operand reads want (below): a chunk's block is one contiguous 16 * 8 * co_t float copy.
 __device__ __forceinline__ void wino_filter(const float* w, float* u, int Co, int Ci, int dgrad, int64_t i) {
   const int co = (int)(i % Co), ci = (int)(i / Co);
   float g[9];
@@ -336,14 +366,18 @@ __device__ __forceinline__ void wino_filter(const float* w, float* u, int Co, in
     t[2][c] = 0.5f * ((g[c] - g[3 + c]) + g[6 + c]);
     t[3][c] = g[6 + c];
   }
-  const int64_t plane = (int64_t)Ci * Co;
-  float* dst = u + (int64_t)ci * Co + co;
+  // operand order of conv_wino_kernel: [chunk = ci / 8][channel block = co / co_t][xi][k = ci % 4][col = co % 16]
+  //                                     [kg = (ci / 4) % 2][j = (co % co_t) / 16], co_t = 32 (16 when Co % 32 != 0)
+  const int co_t = (Co % 32 == 0) ? 32 : 16, nt = co_t / 16;
+  const int chunk = ci >> 3, kg = (ci >> 2) & 1, k = ci & 3, cob = co / co_t, j = (co % co_t) >> 4, col = co & 15;
+  float* dst = u + ((int64_t)chunk * (Co / co_t) + cob) * (16 * 8 * co_t) + (k * 16 + col) * (2 * nt) + kg * nt + j;
+  const int xs = 4 * 16 * 2 * nt;   // floats per transform position
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    dst[(4 * r + 0) * plane] = t[r][0];
-    dst[(4 * r + 1) * plane] = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]);
-    dst[(4 * r + 2) * plane] = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]);
-    dst[(4 * r + 3) * plane] = t[r][2];
+    dst[(4 * r + 0) * xs] = t[r][0];
+    dst[(4 * r + 1) * xs] = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]);
+    dst[(4 * r + 2) * xs] = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]);
+    dst[(4 * r + 3) * xs] = t[r][2];
   }
 }
 
@@ -360,6 +394,7 @@ __global__ __launch_bounds__(256) void wino_pack_table_kernel(PackTable t, const
   if (e.KK != 9) return;
   const int dgrad = blockIdx.z;
   const int Co = dgrad ? e.Ci : e.Co, Ci = dgrad ? e.Co : e.Ci;
+  if (Ci % 8 || Co % 16) return;   // not a Winograd layer in this direction (the blocked image needs whole blocks)
   const int64_t total = (int64_t)Ci * Co;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads)
     wino_filter(params + e.w, (dgrad ? ud : uf) + 2 * e.w, Co, Ci, dgrad, i);
@@ -371,6 +406,10 @@ int wino_pack_table(const PackTable& t, const float* params, float* uf, float* u
 }
 
 int wino_pack(const float* w, float* u, int Co, int Ci, int dgrad, void* stream) {
+  if (Ci % 8 || Co % 16) {
+    set_error("conv2d_pack_weights: the Winograd image needs Ci %% 8 == 0 and Co %% 16 == 0 (got %d, %d)", Ci, Co);
+    return WSL_EINVAL;
+  }
   int64_t blocks = ((int64_t)Ci * Co + kThreads - 1) / kThreads;
   if (blocks > 256) blocks = 256;
   WSL_LAUNCH(wino_pack_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, w, u, Co, Ci, dgrad);
@@ -382,8 +421,10 @@ static WSrc to_wsrc(const WslSrc& s) { return WSrc{s.x, s.emask, s.scale, s.shif
 
 // shapes the Winograd kernels take; the tile (th x tw pixels) is also what the direct kernels use for such a layer, so
 // the number of BatchNorm partial blocks does not depend on which of the two runs (wsl_conv2d_stat_blocks)
-bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, int* th, int* tw, int* co_t) {
-  if (ks != 3 || Ci % 8 || Ci > 256 || Co % 16 || H <= 0 || W <= 0) return false;
+// (16-channel blocks keep the staging + input transform of a 32-channel block for half the matrix work: measured slower
+// than the direct kernel on the 256x256 layers, so they are taken only when asked for -- WSL_CONV_WINO=2)
+bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, int* tw, int* co_t) {
+  if (ks != 3 || Ci % 8 || Ci > 256 || Co % (allow16 ? 16 : 32) || H <= 0 || W <= 0) return false;
   int h = 0, w = 0;
   if (W % 32 == 0 && H % 8 == 0) h = 8, w = 32;
   else if (W % 16 == 0 && H % 16 == 0) h = 16, w = 16;
@@ -407,7 +448,7 @@ static int launch_wino(WinoP& p, int is_dgrad, void* stream) {
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
   const double px = (double)p.N * p.H * p.W;
   // priced at the DIRECT algorithm's flops (9 multiply-adds per pixel and channel pair): the algorithmic work
-  void* tok = prof_begin(is_dgrad ? 1 : 0, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(is_dgrad ? 7 : 6, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_wino_kernel");
@@ -421,8 +462,10 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
   p.u = u, p.bias = bias, p.y = y, p.y_bs = y_bs;
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt, p.slots = slots;
+  static const int ablate = getenv("WSL_CONV_ABLATE") ? atoi(getenv("WSL_CONV_ABLATE")) : 0;
+  p.ablate = ablate;
   int th = 0, tw = 0, co_t = 0;
-  if (!wino_shape_ok(H, W, p.Ci, Co, 3, &th, &tw, &co_t) || (p.b.C && (p.a.C % 8))) {
+  if (!wino_shape_ok(H, W, p.Ci, Co, 3, true, &th, &tw, &co_t) || (p.b.C && (p.a.C % 8))) {
     set_error("conv2d_fwd: shape N=%d H=%d W=%d Ci=%d(+%d) Co=%d is not a Winograd shape", N, H, W, p.a.C, p.b.C, Co);
     return WSL_EINVAL;
   }

@@ -45,7 +45,7 @@ namespace wsl {
 
 void set_error(const char* fmt, ...);
 // opt-in HIP-event bracketing of one launch (wsl_api.hip); fam: 0 conv fwd, 1 conv dgrad, 2 wgrad, 3 wgrad reduce,
-// 4 gatedcrf, 5 other
+// 4 gatedcrf, 5 other, 6 Winograd conv fwd, 7 Winograd conv dgrad
 void* prof_begin(int fam, double flops, double bytes, void* stream);
 void prof_end(void* tok, void* stream);
 int check_launch(const char* what);
