@@ -1595,6 +1595,11 @@ bool wgrad2s_wide_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int
   return span < (int64_t(1) << 31) && (int64_t)Co * H * W < (int64_t(1) << 31);
 }
 
+bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib);
+int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
+                      int H, int W, int Co, int th, int nsplit, int items, int tiles_x, int tiles_y, int co_blocks,
+                      int ci_blocks, void* stream);
+
 int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                   int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
                   int tiles_y, int co_blocks, int ci_blocks, void* stream) {
@@ -1606,6 +1611,10 @@ int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
   static const int ablate = getenv("WSL_WGRAD_ABLATE") ? atoi(getenv("WSL_WGRAD_ABLATE")) : 0;
   p.ablate = ablate;
+  static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
+  if (lean_on && !ablate && wgrad_wino_ok(a, b, H, W, Co, ks, th, tw, cb, ib))   // Winograd form (wsl_conv5.hip)
+    return wgrad_wino_launch(a, b, dy, dy_bs, part_dw, part_db, N, H, W, Co, th, nsplit, items, tiles_x, tiles_y, co_blocks,
+                             ci_blocks, stream);
   if (cb == 64 && ib == 32) {   // two output-channel tiles per wave: only the split-halo kernel is built for this blocking
     if (ks == 3 && th == 4 && tw == 32) return launch_wgrad2s<3, 4, 32, 64, 32, 1>(p, ci_blocks, stream);
     if (ks == 3 && th == 8 && tw == 16) return launch_wgrad2s<3, 8, 16, 64, 32, 1>(p, ci_blocks, stream);

@@ -476,4 +476,303 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
   return launch_wino<16, 16, 16>(p, is_dgrad, stream);
 }
 
+// ================================================================================================ Winograd weight gradient
+// The adjoint of the kernel above:  dL/dg = G^T [ sum over tiles (A dY A^T) .* (B^T d B) ] G, i.e. per tile and channel
+// pair 16 multiply-adds instead of the direct form's 36.  The transforms never touch LDS: lane (c = l & 15, t = l >> 4) of
+// a wave reads the 2x2 output gradients of channels (c, 16 + c) and the 4x4 input patch of ONE input channel for tile t
+// of a group of four from the staged raw tiles, forms Z = A dY A^T (12 adds each) and V = B^T d B (32 adds) in registers --
+// which IS the operand layout of v_mfma_f32_16x16x4_f32 with K = the four tiles (A operand: Z[xi][co = c][k = t], B operand:
+// V[xi][k = t][ci = c]) -- and issues 16 x 2 MFMAs: M_xi[32 co][16 ci] += Z_xi V_xi^T.  56 vector instructions per 32
+// MFMAs.  A workgroup = 32 x 32 channels x (4 x 32 | 8 x 16) pixels per step of its persistent tile loop (same plan,
+// splits and partial layout as wgrad_mfma2s_kernel: wgrad_reduce_kernel is unchanged); wave = (input-channel tile, half
+// of the tile groups).  Epilogue: G^T M G per lane (all 16 positions of a channel pair sit in one lane), the two halves
+// merged through LDS in a fixed order, 9 taps stored; db = sum of Z[1][1] (= the 2x2 sum of dY).
+struct WgWinoP {
+  WSrc a, b;
+  const float* dy;
+  int64_t dy_bs;
+  float* part_dw;   // [nsplit][9][Co][Ci]
+  float* part_db;   // [nsplit][Co]
+  int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, co_blocks;
+};
+
+template <int TH, int TW>
+struct WgWinoCfg {
+  static constexpr int CB = 32, IB = 32, PADL = 4;
+  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, PA = ROWS * ROWP4, GA = 256 / PA, NA = IB / GA;
+  static constexpr int SD = TH * TW, PD = SD / 4, GD = 256 / PD, ND = CB / GD;
+  static constexpr int PLD = ((SD - 2 + 31) / 32) * 32 + 2;             // == 2 (mod 32)
+  static constexpr int PLA = ((ROWS * ROWP - 2 + 31) / 32) * 32 + 2;    // == 2 (mod 32)
+  static constexpr int TTX = TW / 2, TILES = (TH / 2) * TTX, GROUPS = TILES / 4;
+  static constexpr int DY_FLOATS = CB * PLD, A_FLOATS = IB * PLA;
+  static constexpr int RED_FLOATS = 2 * 64 * 74;                         // two waves x (2 x 4 x 9 taps + 2 db) per lane
+  static constexpr int MAIN_FLOATS = DY_FLOATS + A_FLOATS > RED_FLOATS ? DY_FLOATS + A_FLOATS : RED_FLOATS;
+  static constexpr size_t SMEM = sizeof(float) * (MAIN_FLOATS + 2 * IB);
+  static_assert(PA <= 256 && PD <= 256 && IB % GA == 0 && CB % GD == 0 && GROUPS % 2 == 0 && TTX % 4 == 0, "tile shape");
+};
+
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
+  using C = WgWinoCfg<TH, TW>;
+  WSL_DYN_SMEM(smem);
+  float* dy_t = reinterpret_cast<float*>(smem);
+  float* a_t = dy_t + C::DY_FLOATS;
+  float2* tab = reinterpret_cast<float2*>(dy_t + C::MAIN_FLOATS);   // [IB] {scale, shift} of this block's channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = blockIdx.x % p.co_blocks, ib = blockIdx.x / p.co_blocks, split = blockIdx.y;
+  const int co0 = cb * C::CB, ci0 = ib * C::IB;
+  const int H = p.H, W = p.W, Ci = p.Ci;
+  const int HW = H * W;
+
+  const bool ina = ci0 < p.a.C;                          // the source of this block of input channels (uniform)
+  const WSrc& s = ina ? p.a : p.b;
+  const int chb0 = ina ? ci0 : ci0 - p.a.C;
+  const bool has_scale = s.scale != nullptr, has_mask = s.emask != nullptr, has_cm = s.cmask != nullptr;
+  const float es = s.es;
+  for (int c = tid; c < C::IB; c += kThreads)
+    tab[c] = has_scale ? make_float2(s.scale[chb0 + c], s.shift[chb0 + c]) : make_float2(1.f, 0.f);
+
+  // fixed staging positions of this thread
+  const int gd = tid / C::PD, pd = tid - gd * C::PD;             // dy: float4 #pd of the TH x TW tile of channel gd (+ i * GD)
+  const int dty = (pd * 4) / TW, dtx = (pd * 4) - dty * TW;
+  const int tdconst = gd * HW + dty * W + dtx;
+  const int dloff = gd * C::PLD + pd * 4;
+  const int ga = tid / C::PA, pa = tid - ga * C::PA;             // input: float4 #pa of the (TH+2) x (TW+8) halo tile
+  const int aty = pa / C::ROWP4, atx4 = pa - aty * C::ROWP4;
+  const bool owner_a = ga < C::GA;
+  const int aloff = ga * C::PLA + aty * C::ROWP + atx4 * 4;
+  const int64_t dstride = (int64_t)C::GD * HW, astride = (int64_t)C::GA * HW;
+
+  v4f acc[16][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i][0] = v4f{0.f, 0.f, 0.f, 0.f}, acc[i][1] = v4f{0.f, 0.f, 0.f, 0.f};
+  float accb[2] = {0.f, 0.f};
+  const int cit = wave & 1, sub = wave >> 1;
+  const bool dbw = (ib == 0) && (p.part_db != nullptr) && cit == 0;
+  const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
+  int nx_tx, nx_ty, nx_n;
+  {
+    int q = it0;
+    nx_tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    nx_ty = q % p.tiles_y;
+    nx_n = q / p.tiles_y;
+  }
+  const int c16 = lane & 15, t4 = lane >> 4;
+  __syncthreads();   // BN table visible
+
+  for (int item = it0; item < it1; ++item) {
+    // ---- stage the two raw tiles (no prefetch registers are held across the compute phase: a step is ~5000 cycles of
+    // matrix work per wave, the co-resident workgroup covers this one's load latency)
+    {
+      const int n = nx_n, y0 = nx_ty * TH, x0 = nx_tx * TW;
+      if (++nx_tx == p.tiles_x) {
+        nx_tx = 0;
+        if (++nx_ty == p.tiles_y) nx_ty = 0, ++nx_n;
+      }
+      float4 prd[C::ND], pra[C::NA];
+      uint32_t prm[C::NA];
+      float prc[C::NA];
+      const float* dyb = p.dy + n * p.dy_bs + (int64_t)co0 * HW + (uint32_t)(tdconst + y0 * W + x0);
+#pragma unroll
+      for (int i = 0; i < C::ND; ++i) prd[i] = *reinterpret_cast<const float4*>(dyb + i * dstride);
+      const int gy = y0 + aty - 1, gx = x0 + atx4 * 4 - C::PADL;
+      const bool aok = owner_a && gx >= 0 && gx < W && gy >= 0 && gy < H;
+      const uint32_t taoff = aok ? (uint32_t)(ga * HW + gy * W + gx) : 0u;
+      const float* xb = s.x + n * s.bs + (int64_t)chb0 * HW;
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) pra[i] = *reinterpret_cast<const float4*>(xb + i * astride + taoff);
+      if (has_mask) {
+        const uint8_t* mb = s.emask + ((int64_t)n * s.C + chb0) * HW;
+#pragma unroll
+        for (int i = 0; i < C::NA; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * astride + taoff);
+      }
+      if (has_cm) {
+        const float* cmb = s.cmask + (int64_t)n * s.C + chb0 + (owner_a ? ga : 0);
+#pragma unroll
+        for (int i = 0; i < C::NA; ++i) prc[i] = cmb[i * C::GA];
+      }
+#pragma unroll
+      for (int i = 0; i < C::ND; ++i) {   // plane stride == 2 (mod 32): 8-byte aligned, not 16
+        float* dst = dy_t + i * (C::GD * C::PLD) + dloff;
+        *reinterpret_cast<float2*>(dst) = make_float2(prd[i].x, prd[i].y);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(prd[i].z, prd[i].w);
+      }
+      if (owner_a) {
+#pragma unroll
+        for (int i = 0; i < C::NA; ++i) {
+          wsl_v2f lo = {pra[i].x, pra[i].y}, hi = {pra[i].z, pra[i].w};
+          if (has_scale) {
+            const float2 t = tab[ga + i * C::GA];
+            xform_bn_leaky(lo, hi, t.x, t.y);
+          }
+          if (has_mask) xform_mask(lo, hi, prm[i], es);
+          if (has_cm) lo = lo * prc[i], hi = hi * prc[i];
+          if (!aok) lo = wsl_v2f{0.f, 0.f}, hi = wsl_v2f{0.f, 0.f};
+          float* dst = a_t + i * (C::GA * C::PLA) + aloff;
+          *reinterpret_cast<float2*>(dst) = make_float2(lo[0], lo[1]);
+          *reinterpret_cast<float2*>(dst + 2) = make_float2(hi[0], hi[1]);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- compute: this wave's half of the tile groups
+#pragma unroll 1
+    for (int g = sub * (C::GROUPS / 2); g < (sub + 1) * (C::GROUPS / 2); ++g) {
+      const int tau = g * 4 + t4, tyy = tau / C::TTX, txx = tau - tyy * C::TTX;
+      float z[2][16];
+#pragma unroll
+      for (int jc = 0; jc < 2; ++jc) {
+        const float* dp = dy_t + (jc * 16 + c16) * C::PLD + (2 * tyy) * TW + 2 * txx;
+        const float2 r0 = *reinterpret_cast<const float2*>(dp), r1 = *reinterpret_cast<const float2*>(dp + TW);
+        float q[4][2];
+        q[0][0] = r0.x, q[0][1] = r0.y;
+        q[1][0] = r0.x + r1.x, q[1][1] = r0.y + r1.y;
+        q[2][0] = r0.x - r1.x, q[2][1] = r0.y - r1.y;
+        q[3][0] = -r1.x, q[3][1] = -r1.y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          z[jc][4 * i + 0] = q[i][0];
+          z[jc][4 * i + 1] = q[i][0] + q[i][1];
+          z[jc][4 * i + 2] = q[i][0] - q[i][1];
+          z[jc][4 * i + 3] = -q[i][1];
+        }
+        if (dbw) accb[jc] += z[jc][5];
+      }
+      float v[16];
+      {
+        const float* ap = a_t + (cit * 16 + c16) * C::PLA + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
+        float rt[4][4];
+        {
+          float d[4][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float* r = ap + i * C::ROWP;
+            const float2 m = *reinterpret_cast<const float2*>(r + 1);
+            d[i][0] = r[0], d[i][1] = m.x, d[i][2] = m.y, d[i][3] = r[3];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            rt[0][c] = d[0][c] - d[2][c];
+            rt[1][c] = d[1][c] + d[2][c];
+            rt[2][c] = d[2][c] - d[1][c];
+            rt[3][c] = d[1][c] - d[3][c];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[4 * i + 0] = rt[i][0] - rt[i][2];
+          v[4 * i + 1] = rt[i][1] + rt[i][2];
+          v[4 * i + 2] = rt[i][2] - rt[i][1];
+          v[4 * i + 3] = rt[i][1] - rt[i][3];
+        }
+      }
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) {
+        acc[xi][0] = WSL_MFMA16(z[0][xi], v[xi], acc[xi][0]);
+        acc[xi][1] = WSL_MFMA16(z[1][xi], v[xi], acc[xi][1]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: dg = G^T M G per lane, merge the two tile halves (fixed order), store the 9 taps
+  float dg[2][4][9];
+#pragma unroll
+  for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t[3][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float m0 = acc[q][jc][r], m1 = acc[4 + q][jc][r], m2 = acc[8 + q][jc][r], m3 = acc[12 + q][jc][r];
+        t[0][q] = m0 + 0.5f * (m1 + m2);
+        t[1][q] = 0.5f * (m1 - m2);
+        t[2][q] = 0.5f * (m1 + m2) + m3;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        dg[jc][r][3 * a + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+        dg[jc][r][3 * a + 1] = 0.5f * (t[a][1] - t[a][2]);
+        dg[jc][r][3 * a + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+      }
+    }
+  float dbv[2];
+#pragma unroll
+  for (int jc = 0; jc < 2; ++jc) {
+    float b = accb[jc];
+    b += __shfl_xor(b, 16);
+    b += __shfl_xor(b, 32);
+    dbv[jc] = b;   // sum over this wave's tiles for channel jc * 16 + c16
+  }
+  float* red = reinterpret_cast<float*>(smem);   // the tiles are dead: every wave passed the loop's last barrier
+  if (sub == 1) {
+    float* mine = red + (cit * 64 + lane) * 74;
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) mine[(jc * 4 + r) * 9 + t] = dg[jc][r][t];
+      mine[72 + jc] = dbv[jc];
+    }
+  }
+  __syncthreads();
+  if (sub == 0) {
+    const float* other = red + (cit * 64 + lane) * 74;
+    const int ci = ci0 + cit * 16 + c16;
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + jc * 16 + t4 * 4 + r;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          p.part_dw[(((int64_t)split * 9 + t) * p.Co + co) * Ci + ci] = dg[jc][r][t] + other[(jc * 4 + r) * 9 + t];
+      }
+      if (dbw && lane < 16) p.part_db[(int64_t)split * p.Co + co0 + jc * 16 + lane] = dbv[jc] + other[72 + jc];
+    }
+  }
+}
+
+template <int TH, int TW>
+static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
+  using C = WgWinoCfg<TH, TW>;
+  auto kern = wgrad_wino_kernel<TH, TW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("wgrad_wino_kernel");
+}
+
+// takes the launches wgrad_mfma2s_kernel<3, 4|8, 32|16, 32, 32, 1> would get (same plan): 3x3, 32 x 32 channel blocks
+bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib) {
+  static const int on = getenv("WSL_WGRAD_WINO") ? atoi(getenv("WSL_WGRAD_WINO")) : 1;
+  if (!on || ks != 3 || cb != 32 || ib != 32 || !((th == 4 && tw == 32) || (th == 8 && tw == 16))) return false;
+  const int bC = b ? b->C : 0, Ci = a.C + bC;
+  if ((Co % 32) || (Ci % 32) || (bC > 0 && (a.C % 32)) || (H % th) || (W % tw)) return false;
+  const int64_t span = (int64_t)(a.C > bC ? a.C : bC) * H * W;
+  return span < (int64_t(1) << 31) && (int64_t)Co * H * W < (int64_t(1) << 31);
+}
+
+int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
+                      int H, int W, int Co, int th, int nsplit, int items, int tiles_x, int tiles_y, int co_blocks,
+                      int ci_blocks, void* stream) {
+  WgWinoP p;
+  p.a = to_wsrc(a);
+  p.b = (b && b->C > 0) ? to_wsrc(*b) : WSrc{};
+  p.dy = dy, p.dy_bs = dy_bs, p.part_dw = part_dw, p.part_db = part_db;
+  p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
+  p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
+  return th == 4 ? launch_wgrad_wino<4, 32>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16>(p, ci_blocks, stream);
+}
+
+
 }  // namespace wsl
