@@ -568,6 +568,7 @@ int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
               void* stream);
 bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, int W);
 bool wgrad2s_wide_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks);
+bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib);   // wsl_conv5.hip
 int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                   int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
                   int tiles_y, int co_blocks, int ci_blocks, void* stream);
@@ -693,7 +694,14 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   WSL_REQUIRE(dy_bs >= (int64_t)Co * H * W, "conv2d_wgrad: dy batch stride too small");
   const bool v2 = wgrad2_eligible(p.in.a, &p.in.b, dy, dy_bs, W);
   const bool wide = v2 && wgrad2s_wide_ok(p.in.a, &p.in.b, H, W, Co, ks);
-  const WgPlan g = wgrad_plan(N, H, W, Ci, Co, v2, wide);
+  WgPlan g = wgrad_plan(N, H, W, Ci, Co, v2, wide);
+  if (v2 && wgrad_wino_ok(p.in.a, &p.in.b, H, W, Co, ks, g.th, g.tw, g.cb, g.ib)) {
+    // the Winograd weight gradient holds 128 accumulator registers: 2 resident workgroups per CU, so 512 persistent ones
+    static const int wgs = getenv("WSL_WGRAD_WINO_WGS") ? atoi(getenv("WSL_WGRAD_WINO_WGS")) : 512;
+    int want = wgs / (g.co_blocks * g.ci_blocks);
+    if (want < 1) want = 1;
+    if (want < g.nsplit) g.nsplit = want;   // never more partials than the workspace was sized for
+  }
   const size_t need = wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks);
   if (ws_bytes < need) {
     set_error("conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);

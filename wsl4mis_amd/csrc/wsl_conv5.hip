@@ -616,49 +616,47 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
       }
     }
     __syncthreads();
-    // ---- compute: this wave's half of the tile groups
-#pragma unroll 1
-    for (int g = sub * (C::GROUPS / 2); g < (sub + 1) * (C::GROUPS / 2); ++g) {
+    // ---- compute: this wave's half of the tile groups.  Raw operands of group g+1 are read from LDS before the MFMAs of
+    // group g issue.  Z is formed WITHOUT the two negations of A (rows/columns with index 3 carry the opposite sign:
+    // Z'[p][q] = s_p s_q Z[p][q], s_3 = -1); the epilogue puts the signs back into M -- 10 instead of 16 adds per channel.
+    float2 rdy[2][2];   // [jc][row]
+    v4f rd[4];          // the 4 x 4 input patch, one row per vector
+    auto fetch = [&](int g) __attribute__((always_inline)) {
       const int tau = g * 4 + t4, tyy = tau / C::TTX, txx = tau - tyy * C::TTX;
-      float z[2][16];
 #pragma unroll
       for (int jc = 0; jc < 2; ++jc) {
         const float* dp = dy_t + (jc * 16 + c16) * C::PLD + (2 * tyy) * TW + 2 * txx;
-        const float2 r0 = *reinterpret_cast<const float2*>(dp), r1 = *reinterpret_cast<const float2*>(dp + TW);
-        float q[4][2];
-        q[0][0] = r0.x, q[0][1] = r0.y;
-        q[1][0] = r0.x + r1.x, q[1][1] = r0.y + r1.y;
-        q[2][0] = r0.x - r1.x, q[2][1] = r0.y - r1.y;
-        q[3][0] = -r1.x, q[3][1] = -r1.y;
+        rdy[jc][0] = *reinterpret_cast<const float2*>(dp), rdy[jc][1] = *reinterpret_cast<const float2*>(dp + TW);
+      }
+      const float* ap = a_t + (cit * 16 + c16) * C::PLA + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* r = ap + i * C::ROWP;
+        const float2 m = *reinterpret_cast<const float2*>(r + 1);
+        rd[i] = v4f{r[0], m.x, m.y, r[3]};
+      }
+    };
+    constexpr int G0 = 0, GN = C::GROUPS / 2;
+    fetch(sub * GN + G0);
+#pragma unroll 1
+    for (int gi = 0; gi < GN; ++gi) {
+      float z[2][16];
+#pragma unroll
+      for (int jc = 0; jc < 2; ++jc) {
+        const wsl_v2f r0 = {rdy[jc][0].x, rdy[jc][0].y}, r1 = {rdy[jc][1].x, rdy[jc][1].y};
+        const wsl_v2f q[4] = {r0, r0 + r1, r0 - r1, r1};   // q[3] = +dY[1] (sign folded)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           z[jc][4 * i + 0] = q[i][0];
           z[jc][4 * i + 1] = q[i][0] + q[i][1];
           z[jc][4 * i + 2] = q[i][0] - q[i][1];
-          z[jc][4 * i + 3] = -q[i][1];
+          z[jc][4 * i + 3] = q[i][1];                       // sign folded
         }
         if (dbw) accb[jc] += z[jc][5];
       }
       float v[16];
       {
-        const float* ap = a_t + (cit * 16 + c16) * C::PLA + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
-        float rt[4][4];
-        {
-          float d[4][4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float* r = ap + i * C::ROWP;
-            const float2 m = *reinterpret_cast<const float2*>(r + 1);
-            d[i][0] = r[0], d[i][1] = m.x, d[i][2] = m.y, d[i][3] = r[3];
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            rt[0][c] = d[0][c] - d[2][c];
-            rt[1][c] = d[1][c] + d[2][c];
-            rt[2][c] = d[2][c] - d[1][c];
-            rt[3][c] = d[1][c] - d[3][c];
-          }
-        }
+        const v4f rt[4] = {rd[0] - rd[2], rd[1] + rd[2], rd[2] - rd[1], rd[1] - rd[3]};   // packed over the 4 columns
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           v[4 * i + 0] = rt[i][0] - rt[i][2];
@@ -667,6 +665,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
           v[4 * i + 3] = rt[i][1] - rt[i][3];
         }
       }
+      if (gi + 1 < GN) fetch(sub * GN + gi + 1);
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) {
         acc[xi][0] = WSL_MFMA16(z[0][xi], v[xi], acc[xi][0]);
@@ -685,7 +684,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
       float t[3][4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float m0 = acc[q][jc][r], m1 = acc[4 + q][jc][r], m2 = acc[8 + q][jc][r], m3 = acc[12 + q][jc][r];
+        // (undo the folded signs: M[p][q] = s_p s_q M'[p][q], s_3 = -1)
+        const float sq = q == 3 ? -1.f : 1.f;
+        const float m0 = sq * acc[q][jc][r], m1 = sq * acc[4 + q][jc][r], m2 = sq * acc[8 + q][jc][r], m3 = -sq * acc[12 + q][jc][r];
         t[0][q] = m0 + 0.5f * (m1 + m2);
         t[1][q] = 0.5f * (m1 - m2);
         t[2][q] = 0.5f * (m1 + m2) + m3;
