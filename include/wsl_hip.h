@@ -87,12 +87,12 @@ int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t
  * 5 (data gradient) take `w` = the filter image U = G g G^T produced by
  * wsl_conv2d_pack_weights(w_raw, U, Co, Ci, 3, wmode_raw = 2 | 3): 16 * Ci * Co floats in the kernel's operand order
  * (opaque to the caller; needs Ci % 8 == 0 and Co % 16 == 0).  Available for the layers with
- * wsl_conv2d_wino_ok() != 0: ks 3, (Ca + Cb) % 8 == 0 and <= 256, Ca % 8 == 0 when there are two sources, Co % 32 == 0,
+ * wsl_conv2d_wino_ok() != 0: ks 3, (Ca + Cb) % 8 == 0 and <= 256, Ca % 8 == 0 when there are two sources, Co % 16 == 0,
  * (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0), plus the wsl_conv2d_fast_ok() alignment.  Results agree
  * with the direct kernels to fp32 round-off (~1e-6 relative); same BatchNorm partial layout and block count.
- * Env WSL_CONV_WINO / wsl_debug_conv_wino(): 0 off (wino_ok() returns 0), 1 default, 2 also layers with Co % 16 == 0
- * (measured slower than the direct kernel at 256x256; kept for tests and tuning); wsl_debug_conv_wino(-1) re-reads the
- * environment. */
+ * Env WSL_CONV_WINO / wsl_debug_conv_wino(): 0 off (wino_ok() returns 0), 1 only layers with Co % 32 == 0, 2 (default)
+ * also layers with Co % 16 == 0; wsl_debug_conv_wino(-1) re-reads the environment.  Env WSL_WINO_FORM=1 selects the first
+ * form of the kernel (input transform through LDS) instead of the register-resident one. */
 int wsl_conv2d_wino_ok(int N, int H, int W, int Ca, int Cb, int Co, int ks);
 int wsl_debug_conv_wino(int on);
 /* Debug / experiments: which packed-path kernel wsl_conv2d_fwd(wmode 2|3) launches: 2 = lock-step workgroups with a

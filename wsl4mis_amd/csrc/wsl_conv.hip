@@ -227,8 +227,8 @@ struct FwdPlan {
 static int g_forced_plan[3] = {-1, 0, 0};   // th, tw, co_t; th < 0: environment not read yet, 0: none
 bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, int* tw, int* co_t);   // wsl_conv5.hip
 // Winograd F(2x2,3x3) for the 3x3 layers it fits (wsl_conv5.hip): env WSL_CONV_WINO / wsl_debug_conv_wino():
-// 0 off, 1 layers with Co % 32 == 0 (default), 2 also Co % 16 == 0
-#define WSL_WINO_DEFAULT 1
+// 0 off, 1 only layers with Co % 32 == 0, 2 also Co % 16 == 0 (default)
+#define WSL_WINO_DEFAULT 2
 static int g_wino = -1;
 static bool wino_enabled() {
   if (g_wino < 0) {

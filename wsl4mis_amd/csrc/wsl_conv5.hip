@@ -348,6 +348,273 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ second form
+// conv_wino_kernel with the input transform moved INTO the MFMA operand: lane (tile = l & 15, k = l >> 4) of a wave is
+// exactly the A-operand slot of (tile, input channel k of the current group of four), so it reads that channel's 4x4 patch
+// of its tile from the staged raw halo tile and forms B^T d B in registers (8 packed + 16 scalar adds) -- no V buffer in
+// LDS, no transform pass, two barriers per chunk instead of three, 24 instead of 64 LDS reads + 16 writes per chunk.
+// A wave owns MTW row-groups of 16 tiles and NT channel tiles (MTW * NT = 2: 64 tiles x 32 channels, or -- for the
+// 16-channel layers -- 128 tiles = 8 x 64 pixels x 16 channels, twice the matrix work per staged chunk of the first form).
+template <int TH, int TW, int NT>
+struct Wino2Cfg {
+  static constexpr int KC = 8, PADL = 4, CO_T = 16 * NT;
+  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4;
+  static constexpr int G = 256 / POS, NLD = KC / G;
+  static constexpr int PLANE = ((ROWS * ROWP - 16 + 31) / 32) * 32 + 16;   // == 16 (mod 32)
+  static constexpr int TTY = TH / 2, TTX = TW / 2, TILES = TTY * TTX, MTW = TILES / 64, NA = MTW * NT;
+  static constexpr int IN_FLOATS = KC * PLANE, W_FLOATS = 16 * KC * CO_T;
+  static constexpr int WF4 = W_FLOATS / 4, NWL = WF4 / 256;
+  static constexpr int MAXC = 256;
+  static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + W_FLOATS + 3 * MAXC);
+  static_assert(TILES % 64 == 0 && NA == 2 && POS <= 256 && KC % G == 0 && WF4 % 256 == 0 && TTX % 4 == 0, "tile shape");
+  static_assert(8 * CO_T <= IN_FLOATS && (TTX % 16 == 0 || MTW == 1), "reduction scratch / row groups");
+};
+
+template <int TH, int TW, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
+  using C = Wino2Cfg<TH, TW, NT>;
+  constexpr int KC = C::KC, CO_T = C::CO_T, MTW = C::MTW;
+  WSL_DYN_SMEM(smem);
+  float* in_t = reinterpret_cast<float*>(smem);                 // raw (transformed-on-load) halo tile [KC][PLANE]
+  float* w_t = in_t + C::IN_FLOATS;                             // U chunk, operand order: [16 xi][4 k][16 col][2 kg][NT j]
+  float2* tab = reinterpret_cast<float2*>(w_t + C::W_FLOATS);   // [Ci] {scale, shift}
+  float* cm_l = w_t + C::W_FLOATS + 2 * C::MAXC;                // [Ci] channel multiplier of this sample
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD-aware tile order, as conv_mfma2_kernel
+  const int tile_id = bid;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = blockIdx.y * CO_T;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
+  const int HW = H * W;
+
+  // ---- staging position of this thread (as conv_mfma2l_kernel)
+  const int grp = tid / C::POS, pos = tid - grp * C::POS;
+  const int pty = pos / C::ROWP4, ptx4 = pos - pty * C::ROWP4;
+  const int gy = y0 + pty - 1, gx = x0 + ptx4 * 4 - C::PADL;
+  const bool owner = grp < C::G;
+  const bool pvalid = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
+  const uint32_t toff = pvalid ? (uint32_t)(grp * HW + gy * W + gx) : 0u;
+  const int loff = grp * C::PLANE + pty * C::ROWP + ptx4 * 4;
+  const int64_t gstride = (int64_t)C::G * HW;
+  const float* xa_n = p.a.x + n * p.a.bs;
+  const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
+  const uint8_t* ma_n = p.a.emask ? p.a.emask + (int64_t)n * p.a.C * HW : nullptr;
+  const uint8_t* mb_n = (p.b.C && p.b.emask) ? p.b.emask + (int64_t)n * p.b.C * HW : nullptr;
+  const float* w_n = p.u + (int64_t)blockIdx.y * C::W_FLOATS + 4 * tid;
+  const int64_t w_cstride = (int64_t)(Co / CO_T) * C::W_FLOATS;
+
+  float4 pre[C::NLD];
+  uint32_t prm[C::NLD];
+  v4f prw[C::NWL];
+
+  auto issue = [&](int c0) __attribute__((always_inline)) {
+    const bool ina = c0 < p.a.C;                                   // uniform
+    const int chb = ina ? c0 : c0 - p.a.C;
+    const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
+    const uint8_t* mb = ina ? ma_n : mb_n;
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + i * gstride + toff);
+    if (mb) {
+      mb += (int64_t)chb * HW;
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * gstride + toff);
+    }
+    const float* wb = w_n + (c0 / KC) * w_cstride;
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) prw[i] = *reinterpret_cast<const v4f*>(wb + i * (4 * kThreads));
+  };
+
+  auto commit = [&](int c0) __attribute__((always_inline)) {
+    if (pvalid) {
+      const bool ina = c0 < p.a.C;
+      const bool has_scale = (ina ? p.a.scale : p.b.scale) != nullptr;
+      const bool has_mask = (ina ? p.a.emask : p.b.emask) != nullptr;
+      const bool has_cm = (ina ? p.a.cmask : p.b.cmask) != nullptr;
+      const float es = ina ? p.a.es : p.b.es;
+      float2 tb[C::NLD];
+      float cmv[C::NLD];
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) tb[i] = tab[c0 + grp + i * C::G], cmv[i] = cm_l[c0 + grp + i * C::G];
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) {
+        wsl_v2f lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
+        if (has_scale) xform_bn_leaky(lo, hi, tb[i].x, tb[i].y);
+        if (has_mask) xform_mask(lo, hi, prm[i], es);
+        if (has_cm) lo = lo * cmv[i], hi = hi * cmv[i];
+        *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) *reinterpret_cast<v4f*>(w_t + 4 * tid + i * (4 * kThreads)) = prw[i];
+  };
+
+  issue(0);
+  for (int c = tid; c < Ci; c += kThreads) {
+    const bool ina = c < p.a.C;
+    const WSrc& s = ina ? p.a : p.b;
+    const int ch = ina ? c : c - p.a.C;
+    tab[c] = s.scale ? make_float2(s.scale[ch], s.shift[ch]) : make_float2(1.f, 0.f);
+    cm_l[c] = s.cmask ? s.cmask[(int64_t)n * s.C + ch] : 1.f;
+  }
+  if (owner && !pvalid) {   // positions outside the image stay zero for good
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i)
+      *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  v4f acc[16][2];   // [xi][m * NT + j]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i][0] = v4f{0.f, 0.f, 0.f, 0.f}, acc[i][1] = v4f{0.f, 0.f, 0.f, 0.f};
+  // this lane's A-operand slots: tile (wave * MTW + m) * 16 + (lane & 15), channel (lane >> 4) of a group of four
+  int poff[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int t = (wave * MTW + m) * 16 + (lane & 15), tyy = t / C::TTX, txx = t - tyy * C::TTX;
+    poff[m] = (lane >> 4) * C::PLANE + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
+  }
+  const int b_off = lane * (2 * NT);   // ((k = lane >> 4) * 16 + (col = lane & 15)) * (2 kg * NT j)
+  __syncthreads();   // tables visible
+
+  for (int c0 = 0; c0 < Ci; c0 += KC) {
+    commit(c0);
+    if (c0 + KC < Ci) issue(c0 + KC);   // flies across the whole compute phase
+    __syncthreads();
+    v4f rd[MTW][4];
+    auto fetch = [&](int kg) __attribute__((always_inline)) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float* r = in_t + kg * (4 * C::PLANE) + poff[m] + i * C::ROWP;
+          const float2 mm = *reinterpret_cast<const float2*>(r + 1);
+          rd[m][i] = v4f{r[0], mm.x, mm.y, r[3]};
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      float v[MTW][16];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const v4f rt[4] = {rd[m][0] - rd[m][2], rd[m][1] + rd[m][2], rd[m][2] - rd[m][1], rd[m][1] - rd[m][3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[m][4 * i + 0] = rt[i][0] - rt[i][2];
+          v[m][4 * i + 1] = rt[i][1] + rt[i][2];
+          v[m][4 * i + 2] = rt[i][2] - rt[i][1];
+          v[m][4 * i + 3] = rt[i][1] - rt[i][3];
+        }
+      }
+      if (kg == 0) fetch(1);   // the second channel group's patches are read while the first group's MFMAs issue
+      float bv[2][NT];
+      auto loadb = [&](int xi, int buf) __attribute__((always_inline)) {
+        const float* bp = w_t + xi * (4 * 16 * 2 * NT) + b_off + kg * NT;
+        if constexpr (NT == 2) {
+          const float2 b2 = *reinterpret_cast<const float2*>(bp);
+          bv[buf][0] = b2.x, bv[buf][1] = b2.y;
+        } else {
+          bv[buf][0] = bp[0];
+        }
+      };
+      loadb(0, 0);
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) {
+        if (xi + 1 < 16) loadb(xi + 1, (xi + 1) & 1);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi & 1][j], acc[xi][m * NT + j]);
+        WSL_SCHED_BARRIER();
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: output transform (register-only), bias, float4 stores, BatchNorm partials
+  float o[2][16];
+  float bsum[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int tb = (wave * MTW + m) * 16 + 4 * (lane >> 4);          // first of this lane's 4 consecutive tiles
+    const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
+    float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int a = m * NT + j;
+      const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
+      float bs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float m0 = acc[c][a][r], m1 = acc[4 + c][a][r], m2 = acc[8 + c][a][r], m3 = acc[12 + c][a][r];
+          s0[c] = (m0 + m1) + m2;
+          s1[c] = (m1 - m2) - m3;
+        }
+        const float y00 = ((s0[0] + s0[1]) + s0[2]) + bias, y01 = ((s0[1] - s0[2]) - s0[3]) + bias;
+        const float y10 = ((s1[0] + s1[1]) + s1[2]) + bias, y11 = ((s1[1] - s1[2]) - s1[3]) + bias;
+        o[a][2 * r] = y00, o[a][2 * r + 1] = y01, o[a][8 + 2 * r] = y10, o[a][8 + 2 * r + 1] = y11;
+        bs += (y00 + y01) + (y10 + y11);
+      }
+      float* yj = yb + (int64_t)j * 16 * HW;
+      *reinterpret_cast<float4*>(yj) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
+      *reinterpret_cast<float4*>(yj + 4) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
+      *reinterpret_cast<float4*>(yj + W) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
+      *reinterpret_cast<float4*>(yj + W + 4) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
+      bsum[j] += bs;
+    }
+  }
+  if (p.stat_part) {
+    float* red1 = in_t;
+    float* red2 = in_t + 4 * CO_T;
+    constexpr float cnt = (float)(TH * TW);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = j * 16 + (lane & 15);
+      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float d = o[m * NT + j][e] - mean_b;
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = j * 16 + lane, co = co0 + col;
+        float* dst = p.stat_part + ((int64_t)co * ((int64_t)nb * p.slots) + (int64_t)tile_id * p.slots) * 2;   // [Co][slots][2]
+        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+      }
+      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ filter transform
 // U(xi = 4 r + c, ci, co) = (G g G^T)[r][c], g = w[co][ci][:, :] (forward) or the flipped, transposed filter of the
 // data gradient (w[ci][co][2-ky][2-kx] with the GEMM's in/out roles swapped, as pack_weights_kernel's wmode 1), stored in
@@ -426,7 +693,8 @@ static WSrc to_wsrc(const WslSrc& s) { return WSrc{s.x, s.emask, s.scale, s.shif
 bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, int* tw, int* co_t) {
   if (ks != 3 || Ci % 8 || Ci > 256 || Co % (allow16 ? 16 : 32) || H <= 0 || W <= 0) return false;
   int h = 0, w = 0;
-  if (W % 32 == 0 && H % 8 == 0) h = 8, w = 32;
+  if (Co == 16 && W % 64 == 0 && H % 8 == 0) h = 8, w = 64;   // 16 channels: 128 tiles per workgroup (second form)
+  else if (W % 32 == 0 && H % 8 == 0) h = 8, w = 32;
   else if (W % 16 == 0 && H % 16 == 0) h = 16, w = 16;
   else return false;
   if ((int64_t)Ci * H * W >= (int64_t(1) << 31) || (int64_t)16 * Ci * Co >= (int64_t(1) << 31)) return false;
@@ -434,6 +702,23 @@ bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, 
   if (tw) *tw = w;
   if (co_t) *co_t = Co % 32 == 0 ? 32 : 16;
   return true;
+}
+
+template <int TH, int TW, int NT>
+static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
+  using C = Wino2Cfg<TH, TW, NT>;
+  auto kern = conv_wino2_kernel<TH, TW, NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(is_dgrad ? 7 : 6, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_wino2_kernel");
 }
 
 template <int TH, int TW, int CO_T>
@@ -470,6 +755,12 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
     return WSL_EINVAL;
   }
   p.tiles_x = W / tw, p.tiles_y = H / th;
+  static const int form = getenv("WSL_WINO_FORM") ? atoi(getenv("WSL_WINO_FORM")) : 2;   // 1: V through LDS, 2: V in registers
+  if (tw == 64) return launch_wino2<8, 64, 1>(p, is_dgrad, stream);
+  if (form == 2 && co_t == 32) {
+    if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);
+    return launch_wino2<16, 16, 2>(p, is_dgrad, stream);
+  }
   if (th == 8 && co_t == 32) return launch_wino<8, 32, 32>(p, is_dgrad, stream);
   if (th == 8 && co_t == 16) return launch_wino<8, 32, 16>(p, is_dgrad, stream);
   if (th == 16 && co_t == 32) return launch_wino<16, 16, 32>(p, is_dgrad, stream);
