@@ -695,8 +695,8 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   const bool v2 = wgrad2_eligible(p.in.a, &p.in.b, dy, dy_bs, W);
   const bool wide = v2 && wgrad2s_wide_ok(p.in.a, &p.in.b, H, W, Co, ks);
   WgPlan g = wgrad_plan(N, H, W, Ci, Co, v2, wide);
-  if (v2 && wgrad_wino_ok(p.in.a, &p.in.b, H, W, Co, ks, g.th, g.tw, g.cb, g.ib)) {
-    // the Winograd weight gradient holds 128 accumulator registers: 2 resident workgroups per CU, so 512 persistent ones
+  if (v2 && g.cb == 32 && wgrad_wino_ok(p.in.a, &p.in.b, H, W, Co, ks, g.th, g.tw, g.cb, g.ib)) {
+    // the 32 x 32 Winograd weight gradient holds 128 accumulator registers: 2 resident workgroups per CU -> 512 persistent ones
     static const int wgs = getenv("WSL_WGRAD_WINO_WGS") ? atoi(getenv("WSL_WGRAD_WINO_WGS")) : 512;
     int want = wgs / (g.co_blocks * g.ci_blocks);
     if (want < 1) want = 1;

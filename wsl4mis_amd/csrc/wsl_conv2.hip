@@ -1597,8 +1597,8 @@ bool wgrad2s_wide_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int
 
 bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib);
 int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
-                      int H, int W, int Co, int th, int nsplit, int items, int tiles_x, int tiles_y, int co_blocks,
-                      int ci_blocks, void* stream);
+                      int H, int W, int Co, int th, int tw, int cb, int nsplit, int items, int tiles_x, int tiles_y,
+                      int co_blocks, int ci_blocks, void* stream);
 
 int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                   int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
@@ -1613,8 +1613,8 @@ int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_
   p.ablate = ablate;
   static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
   if (lean_on && !ablate && wgrad_wino_ok(a, b, H, W, Co, ks, th, tw, cb, ib))   // Winograd form (wsl_conv5.hip)
-    return wgrad_wino_launch(a, b, dy, dy_bs, part_dw, part_db, N, H, W, Co, th, nsplit, items, tiles_x, tiles_y, co_blocks,
-                             ci_blocks, stream);
+    return wgrad_wino_launch(a, b, dy, dy_bs, part_dw, part_db, N, H, W, Co, th, tw, cb, nsplit, items, tiles_x, tiles_y,
+                             co_blocks, ci_blocks, stream);
   if (cb == 64 && ib == 32) {   // two output-channel tiles per wave: only the split-halo kernel is built for this blocking
     if (ks == 3 && th == 4 && tw == 32) return launch_wgrad2s<3, 4, 32, 64, 32, 1>(p, ci_blocks, stream);
     if (ks == 3 && th == 8 && tw == 16) return launch_wgrad2s<3, 8, 16, 64, 32, 1>(p, ci_blocks, stream);

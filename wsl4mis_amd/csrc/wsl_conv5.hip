@@ -787,24 +787,26 @@ struct WgWinoP {
   int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, co_blocks;
 };
 
-template <int TH, int TW>
+template <int TH, int TW, int NCO, int NCI>   // NCO channel tiles of dY per wave, NCI input-channel tiles per workgroup
 struct WgWinoCfg {
-  static constexpr int CB = 32, IB = 32, PADL = 4;
+  static constexpr int CB = 16 * NCO, IB = 16 * NCI, NSUB = 4 / NCI, PADL = 4;
   static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, PA = ROWS * ROWP4, GA = 256 / PA, NA = IB / GA;
   static constexpr int SD = TH * TW, PD = SD / 4, GD = 256 / PD, ND = CB / GD;
   static constexpr int PLD = ((SD - 2 + 31) / 32) * 32 + 2;             // == 2 (mod 32)
   static constexpr int PLA = ((ROWS * ROWP - 2 + 31) / 32) * 32 + 2;    // == 2 (mod 32)
   static constexpr int TTX = TW / 2, TILES = (TH / 2) * TTX, GROUPS = TILES / 4;
   static constexpr int DY_FLOATS = CB * PLD, A_FLOATS = IB * PLA;
-  static constexpr int RED_FLOATS = 2 * 64 * 74;                         // two waves x (2 x 4 x 9 taps + 2 db) per lane
+  static constexpr int PER = NCO * 37;                                   // per lane: NCO x (4 x 9 taps + 1 db)
+  static constexpr int RED_FLOATS = (NSUB - 1) * NCI * 64 * PER;
   static constexpr int MAIN_FLOATS = DY_FLOATS + A_FLOATS > RED_FLOATS ? DY_FLOATS + A_FLOATS : RED_FLOATS;
   static constexpr size_t SMEM = sizeof(float) * (MAIN_FLOATS + 2 * IB);
-  static_assert(PA <= 256 && PD <= 256 && IB % GA == 0 && CB % GD == 0 && GROUPS % 2 == 0 && TTX % 4 == 0, "tile shape");
+  static_assert(PA <= 256 && PD <= 256 && IB % GA == 0 && CB % GD == 0 && GROUPS % NSUB == 0 && TTX % 4 == 0 &&
+                    (NCI == 1 || NCI == 2), "tile shape");
 };
 
-template <int TH, int TW>
+template <int TH, int TW, int NCO, int NCI>
 __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
-  using C = WgWinoCfg<TH, TW>;
+  using C = WgWinoCfg<TH, TW, NCO, NCI>;
   WSL_DYN_SMEM(smem);
   float* dy_t = reinterpret_cast<float*>(smem);
   float* a_t = dy_t + C::DY_FLOATS;
@@ -834,11 +836,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
   const int aloff = ga * C::PLA + aty * C::ROWP + atx4 * 4;
   const int64_t dstride = (int64_t)C::GD * HW, astride = (int64_t)C::GA * HW;
 
-  v4f acc[16][2];
+  v4f acc[16][NCO];
+  float accb[NCO];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i][0] = v4f{0.f, 0.f, 0.f, 0.f}, acc[i][1] = v4f{0.f, 0.f, 0.f, 0.f};
-  float accb[2] = {0.f, 0.f};
-  const int cit = wave & 1, sub = wave >> 1;
+  for (int jc = 0; jc < NCO; ++jc) {
+    accb[jc] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i][jc] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+  const int cit = wave % NCI, sub = wave / NCI;
   const bool dbw = (ib == 0) && (p.part_db != nullptr) && cit == 0;
   const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
   int nx_tx, nx_ty, nx_n;
@@ -910,12 +916,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
     // ---- compute: this wave's half of the tile groups.  Raw operands of group g+1 are read from LDS before the MFMAs of
     // group g issue.  Z is formed WITHOUT the two negations of A (rows/columns with index 3 carry the opposite sign:
     // Z'[p][q] = s_p s_q Z[p][q], s_3 = -1); the epilogue puts the signs back into M -- 10 instead of 16 adds per channel.
-    float2 rdy[2][2];   // [jc][row]
+    float2 rdy[NCO][2];   // [jc][row]
     v4f rd[4];          // the 4 x 4 input patch, one row per vector
     auto fetch = [&](int g) __attribute__((always_inline)) {
       const int tau = g * 4 + t4, tyy = tau / C::TTX, txx = tau - tyy * C::TTX;
 #pragma unroll
-      for (int jc = 0; jc < 2; ++jc) {
+      for (int jc = 0; jc < NCO; ++jc) {
         const float* dp = dy_t + (jc * 16 + c16) * C::PLD + (2 * tyy) * TW + 2 * txx;
         rdy[jc][0] = *reinterpret_cast<const float2*>(dp), rdy[jc][1] = *reinterpret_cast<const float2*>(dp + TW);
       }
@@ -927,13 +933,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
         rd[i] = v4f{r[0], m.x, m.y, r[3]};
       }
     };
-    constexpr int G0 = 0, GN = C::GROUPS / 2;
+    constexpr int G0 = 0, GN = C::GROUPS / C::NSUB;
     fetch(sub * GN + G0);
 #pragma unroll 1
     for (int gi = 0; gi < GN; ++gi) {
-      float z[2][16];
+      float z[NCO][16];
 #pragma unroll
-      for (int jc = 0; jc < 2; ++jc) {
+      for (int jc = 0; jc < NCO; ++jc) {
         const wsl_v2f r0 = {rdy[jc][0].x, rdy[jc][0].y}, r1 = {rdy[jc][1].x, rdy[jc][1].y};
         const wsl_v2f q[4] = {r0, r0 + r1, r0 - r1, r1};   // q[3] = +dY[1] (sign folded)
 #pragma unroll
@@ -958,18 +964,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
       }
       if (gi + 1 < GN) fetch(sub * GN + gi + 1);
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi) {
-        acc[xi][0] = WSL_MFMA16(z[0][xi], v[xi], acc[xi][0]);
-        acc[xi][1] = WSL_MFMA16(z[1][xi], v[xi], acc[xi][1]);
-      }
+      for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int jc = 0; jc < NCO; ++jc) acc[xi][jc] = WSL_MFMA16(z[jc][xi], v[xi], acc[xi][jc]);
     }
     __syncthreads();
   }
 
-  // ---- epilogue: dg = G^T M G per lane, merge the two tile halves (fixed order), store the 9 taps
-  float dg[2][4][9];
+  // ---- epilogue: dg = G^T M G per lane, merge the tile subsets (fixed order), store the 9 taps
+  float dg[NCO][4][9];
 #pragma unroll
-  for (int jc = 0; jc < 2; ++jc)
+  for (int jc = 0; jc < NCO; ++jc)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float t[3][4];
@@ -989,48 +994,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
         dg[jc][r][3 * a + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
       }
     }
-  float dbv[2];
+  float dbv[NCO];
 #pragma unroll
-  for (int jc = 0; jc < 2; ++jc) {
+  for (int jc = 0; jc < NCO; ++jc) {
     float b = accb[jc];
     b += __shfl_xor(b, 16);
     b += __shfl_xor(b, 32);
     dbv[jc] = b;   // sum over this wave's tiles for channel jc * 16 + c16
   }
   float* red = reinterpret_cast<float*>(smem);   // the tiles are dead: every wave passed the loop's last barrier
-  if (sub == 1) {
-    float* mine = red + (cit * 64 + lane) * 74;
+  if (sub > 0) {
+    float* mine = red + (((sub - 1) * NCI + cit) * 64 + lane) * C::PER;
 #pragma unroll
-    for (int jc = 0; jc < 2; ++jc) {
+    for (int jc = 0; jc < NCO; ++jc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int t = 0; t < 9; ++t) mine[(jc * 4 + r) * 9 + t] = dg[jc][r][t];
-      mine[72 + jc] = dbv[jc];
+      mine[NCO * 36 + jc] = dbv[jc];
     }
   }
   __syncthreads();
   if (sub == 0) {
-    const float* other = red + (cit * 64 + lane) * 74;
     const int ci = ci0 + cit * 16 + c16;
 #pragma unroll
-    for (int jc = 0; jc < 2; ++jc) {
+    for (int jc = 0; jc < NCO; ++jc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + jc * 16 + t4 * 4 + r;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-          p.part_dw[(((int64_t)split * 9 + t) * p.Co + co) * Ci + ci] = dg[jc][r][t] + other[(jc * 4 + r) * 9 + t];
+        for (int t = 0; t < 9; ++t) {
+          float sum = dg[jc][r][t];
+#pragma unroll
+          for (int k = 1; k < C::NSUB; ++k) sum += red[(((k - 1) * NCI + cit) * 64 + lane) * C::PER + (jc * 4 + r) * 9 + t];
+          p.part_dw[(((int64_t)split * 9 + t) * p.Co + co) * Ci + ci] = sum;
+        }
       }
-      if (dbw && lane < 16) p.part_db[(int64_t)split * p.Co + co0 + jc * 16 + lane] = dbv[jc] + other[72 + jc];
+      if (dbw && lane < 16) {
+        float sum = dbv[jc];
+#pragma unroll
+        for (int k = 1; k < C::NSUB; ++k) sum += red[(((k - 1) * NCI + cit) * 64 + lane) * C::PER + NCO * 36 + jc];
+        p.part_db[(int64_t)split * p.Co + co0 + jc * 16 + lane] = sum;
+      }
     }
   }
 }
 
-template <int TH, int TW>
+template <int TH, int TW, int NCO, int NCI>
 static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
-  using C = WgWinoCfg<TH, TW>;
-  auto kern = wgrad_wino_kernel<TH, TW>;
+  using C = WgWinoCfg<TH, TW, NCO, NCI>;
+  auto kern = wgrad_wino_kernel<TH, TW, NCO, NCI>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
@@ -1044,27 +1057,36 @@ static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
   return check_launch("wgrad_wino_kernel");
 }
 
-// takes the launches wgrad_mfma2s_kernel<3, 4|8, 32|16, 32, 32, 1> would get (same plan): 3x3, 32 x 32 channel blocks
+// takes the launches wgrad_mfma2s_kernel would get with the same plan: 3x3, 32 x 32 channel blocks (two dY tiles per wave,
+// two input-channel tiles per workgroup) or 16 x 16 (the 16-channel layers: one tile each, four tile subsets)
 bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib) {
-  static const int on = getenv("WSL_WGRAD_WINO") ? atoi(getenv("WSL_WGRAD_WINO")) : 1;
-  if (!on || ks != 3 || cb != 32 || ib != 32 || !((th == 4 && tw == 32) || (th == 8 && tw == 16))) return false;
+  static const int on = getenv("WSL_WGRAD_WINO") ? atoi(getenv("WSL_WGRAD_WINO")) : 2;   // 0 off, 1 only 32 x 32 blocks, 2 all
+  if (!on || ks != 3 || cb != ib) return false;
+  if (cb == 32) {
+    if (!((th == 4 && tw == 32) || (th == 8 && tw == 16))) return false;
+  } else if (cb == 16 && on >= 2) {
+    if (!((th == 4 && tw == 64) || (th == 4 && tw == 32) || (th == 8 && tw == 16))) return false;
+  } else {
+    return false;
+  }
   const int bC = b ? b->C : 0, Ci = a.C + bC;
-  if ((Co % 32) || (Ci % 32) || (bC > 0 && (a.C % 32)) || (H % th) || (W % tw)) return false;
+  if ((Co % cb) || (Ci % ib) || (bC > 0 && (a.C % ib)) || (H % th) || (W % tw)) return false;
   const int64_t span = (int64_t)(a.C > bC ? a.C : bC) * H * W;
   return span < (int64_t(1) << 31) && (int64_t)Co * H * W < (int64_t(1) << 31);
 }
 
 int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
-                      int H, int W, int Co, int th, int nsplit, int items, int tiles_x, int tiles_y, int co_blocks,
-                      int ci_blocks, void* stream) {
+                      int H, int W, int Co, int th, int tw, int cb, int nsplit, int items, int tiles_x, int tiles_y,
+                      int co_blocks, int ci_blocks, void* stream) {
   WgWinoP p;
   p.a = to_wsrc(a);
   p.b = (b && b->C > 0) ? to_wsrc(*b) : WSrc{};
   p.dy = dy, p.dy_bs = dy_bs, p.part_dw = part_dw, p.part_db = part_db;
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
-  return th == 4 ? launch_wgrad_wino<4, 32>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16>(p, ci_blocks, stream);
+  if (cb == 32) return th == 4 ? launch_wgrad_wino<4, 32, 2, 2>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2>(p, ci_blocks, stream);
+  if (tw == 64) return launch_wgrad_wino<4, 64, 1, 1>(p, ci_blocks, stream);
+  return th == 4 ? launch_wgrad_wino<4, 32, 1, 1>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 1, 1>(p, ci_blocks, stream);
 }
-
 
 }  // namespace wsl
