@@ -187,15 +187,16 @@ def main():
         conv = [r for r in rows if r.calls and r.flops > 0]
         if not conv:
             return None
-        # one entry per kernel template: the direct MFMA convolution (forward + data-gradient launches; the first conv and
-        # the 4-channel classifiers run their own small kernels inside these families), the Winograd F(2x2,3x3) convolution
-        # (the 3x3 layers with >= 32 output channels) and the weight gradient.  The dominant one = most time per step.
+        # one entry per kernel family: the direct MFMA convolution (1x1 layers, first conv, 4-channel classifiers), the
+        # Winograd F(2x2,3x3) convolution (every other 3x3 layer, forward + data-gradient launches) and the weight gradient
+        # (Winograd form for the 3x3 layers; the 1x1 / first / classifier layers ride in the same event family).  The
+        # dominant one = most time per step.
         # Flops are the ALGORITHMIC ones (direct convolution: 2 * 9 * Ci * Co per pixel) for all of them -- the Winograd
         # kernel issues 2.25x fewer matrix instructions for the same result, so its fraction can pass what a direct kernel
         # could reach.
         kern = {"conv_mfma2l_kernel (fwd + data-gradient launches)": [r for r in rows[:2] if r.calls],
-                "conv_wino_kernel (fwd + data-gradient launches)": [r for r in rows[6:8] if r.calls],
-                "wgrad_mfma2s_kernel": [r for r in rows[2:3] if r.calls]}
+                "conv_wino2_kernel (fwd + data-gradient launches)": [r for r in rows[6:8] if r.calls],
+                "wgrad_wino_kernel": [r for r in rows[2:3] if r.calls]}
         per_kernel = {k: {"ms_per_step": round(sum(r.ms for r in v) / nsteps, 3), "launches": int(sum(r.calls for r in v)),
                           "avg_launch_us": round(1e3 * sum(r.ms for r in v) / sum(r.calls for r in v), 2),
                           "achieved": round(sum(r.flops for r in v) / (sum(r.ms for r in v) * 1e-3) / 1e12, 2),
@@ -206,13 +207,13 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         traffic = None     # HBM bytes per launch of that kernel family from the committed rocprofv3 PMC passes
         try:               # (FETCH_SIZE / WRITE_SIZE, separate runs of this same command -- tools/pmc_traffic.py)
-            tfile = next(f for f in ("r1t_pmc_traffic.json", "r1h_pmc_traffic.json")
+            tfile = next(f for f in ("r1z_pmc_traffic.json", "r1t_pmc_traffic.json", "r1h_pmc_traffic.json")
                          if os.path.exists(os.path.join(ROOT, "profiles", f)))
             with open(os.path.join(ROOT, "profiles", tfile)) as fh:
                 tj = json.load(fh)["kernels"]
-            keys = ("conv_wino_kernel",) if name.startswith("conv_wino") else \
+            keys = ("conv_wino2_kernel", "conv_wino_kernel") if name.startswith("conv_wino") else \
                    ("conv_mfma2l_kernel", "conv_mfma2_kernel") if name.startswith("conv") else \
-                   ("wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel")
+                   ("wgrad_wino_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel")
             nl = sum(tj[k]["launches_sampled"] for k in keys if k in tj)
             traffic = {"hbm_bytes_per_launch": sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["launches_sampled"]
                                                    for k in keys if k in tj) / nl,

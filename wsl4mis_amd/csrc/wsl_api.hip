@@ -93,9 +93,9 @@ namespace wsl {
 struct ProfRec { int fam; double flops, bytes; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
-static const char* kFamNames[WSL_PROF_FAMILIES] = {"conv_mfma2l_kernel(fwd)", "conv_mfma2l_kernel(dgrad)", "wgrad_mfma2s_kernel",
-                                                   "wgrad_reduce_kernel", "gatedcrf_fwd_kernel", "other", "conv_wino_kernel(fwd)",
-                                                   "conv_wino_kernel(dgrad)"};
+static const char* kFamNames[WSL_PROF_FAMILIES] = {"conv_mfma2l_kernel(fwd)", "conv_mfma2l_kernel(dgrad)", "wgrad_wino_kernel",
+                                                   "wgrad_reduce_kernel", "gatedcrf_fwd_kernel", "other", "conv_wino2_kernel(fwd)",
+                                                   "conv_wino2_kernel(dgrad)"};
 void* prof_begin(int fam, double flops, double bytes, void* stream) {
   if (!g_prof_on) return nullptr;
   ProfRec r{fam, flops, bytes, nullptr, nullptr};
