@@ -569,6 +569,7 @@ int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
 bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, int W);
 bool wgrad2s_wide_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks);
 bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib);   // wsl_conv5.hip
+int wgrad_wino_waves();
 int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                   int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
                   int tiles_y, int co_blocks, int ci_blocks, void* stream);
@@ -697,7 +698,8 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   WgPlan g = wgrad_plan(N, H, W, Ci, Co, v2, wide);
   if (v2 && g.cb == 32 && wgrad_wino_ok(p.in.a, &p.in.b, H, W, Co, ks, g.th, g.tw, g.cb, g.ib)) {
     // the 32 x 32 Winograd weight gradient holds 128 accumulator registers: 2 resident workgroups per CU -> 512 persistent ones
-    static const int wgs = getenv("WSL_WGRAD_WINO_WGS") ? atoi(getenv("WSL_WGRAD_WINO_WGS")) : 512;
+    // (256 when it runs as one 8-wave double-buffered workgroup per CU)
+    static const int wgs = getenv("WSL_WGRAD_WINO_WGS") ? atoi(getenv("WSL_WGRAD_WINO_WGS")) : (wgrad_wino_waves() == 8 ? 256 : 512);
     int want = wgs / (g.co_blocks * g.ci_blocks);
     if (want < 1) want = 1;
     if (want < g.nsplit) g.nsplit = want;   // never more partials than the workspace was sized for

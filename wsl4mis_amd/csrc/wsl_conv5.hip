@@ -787,30 +787,33 @@ struct WgWinoP {
   int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, co_blocks;
 };
 
-template <int TH, int TW, int NCO, int NCI>   // NCO channel tiles of dY per wave, NCI input-channel tiles per workgroup
+template <int TH, int TW, int NCO, int NCI, int NW>   // NCO dY channel tiles per wave, NCI input-channel tiles and NW waves per workgroup
 struct WgWinoCfg {
-  static constexpr int CB = 16 * NCO, IB = 16 * NCI, NSUB = 4 / NCI, PADL = 4;
-  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, PA = ROWS * ROWP4, GA = 256 / PA, NA = IB / GA;
-  static constexpr int SD = TH * TW, PD = SD / 4, GD = 256 / PD, ND = CB / GD;
+  static constexpr int THREADS = 64 * NW, CB = 16 * NCO, IB = 16 * NCI, NSUB = NW / NCI, PADL = 4;
+  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, PA = ROWS * ROWP4, GA = THREADS / PA, NA = IB / GA;
+  static constexpr int SD = TH * TW, PD = SD / 4, GD = THREADS / PD, ND = CB / GD;
   static constexpr int PLD = ((SD - 2 + 31) / 32) * 32 + 2;             // == 2 (mod 32)
-  static constexpr int PLA = ((ROWS * ROWP - 2 + 31) / 32) * 32 + 2;    // == 2 (mod 32)
+  static constexpr int PLA = ((ROWS * ROWP - 2 + 31) / 32) * 32 + 2;    // == 2 (mod 32); (== 8 (mod 64) measured 4-7 % slower)
   static constexpr int TTX = TW / 2, TILES = (TH / 2) * TTX, GROUPS = TILES / 4;
-  static constexpr int DY_FLOATS = CB * PLD, A_FLOATS = IB * PLA;
+  static constexpr int DY_FLOATS = CB * PLD, A_FLOATS = IB * PLA, BUF_FLOATS = DY_FLOATS + A_FLOATS;
+  // NW == 8: one 8-wave workgroup per CU with TWO tile buffers -- the next tile's loads are issued before the compute phase
+  // of the current one and written to the other buffer after it (the 4-wave form has no registers left for that and relies
+  // on a second resident workgroup to cover its load latency)
+  static constexpr int NBUF = NW == 8 ? 2 : 1;
   static constexpr int PER = NCO * 37;                                   // per lane: NCO x (4 x 9 taps + 1 db)
   static constexpr int RED_FLOATS = (NSUB - 1) * NCI * 64 * PER;
-  static constexpr int MAIN_FLOATS = DY_FLOATS + A_FLOATS > RED_FLOATS ? DY_FLOATS + A_FLOATS : RED_FLOATS;
+  static constexpr int MAIN_FLOATS = NBUF * BUF_FLOATS > RED_FLOATS ? NBUF * BUF_FLOATS : RED_FLOATS;
   static constexpr size_t SMEM = sizeof(float) * (MAIN_FLOATS + 2 * IB);
-  static_assert(PA <= 256 && PD <= 256 && IB % GA == 0 && CB % GD == 0 && GROUPS % NSUB == 0 && TTX % 4 == 0 &&
-                    (NCI == 1 || NCI == 2), "tile shape");
+  static_assert(PA <= THREADS && PD <= THREADS && IB % GA == 0 && CB % GD == 0 && GROUPS % NSUB == 0 && TTX % 4 == 0 &&
+                    (NCI == 1 || NCI == 2) && (NW == 4 || NW == 8), "tile shape");
 };
 
-template <int TH, int TW, int NCO, int NCI>
-__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
-  using C = WgWinoCfg<TH, TW, NCO, NCI>;
+template <int TH, int TW, int NCO, int NCI, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(WgWinoP p) {
+  using C = WgWinoCfg<TH, TW, NCO, NCI, NW>;
   WSL_DYN_SMEM(smem);
-  float* dy_t = reinterpret_cast<float*>(smem);
-  float* a_t = dy_t + C::DY_FLOATS;
-  float2* tab = reinterpret_cast<float2*>(dy_t + C::MAIN_FLOATS);   // [IB] {scale, shift} of this block's channels
+  float* tiles = reinterpret_cast<float*>(smem);                    // NBUF x {dy tile, input tile}
+  float2* tab = reinterpret_cast<float2*>(tiles + C::MAIN_FLOATS);   // [IB] {scale, shift} of this block's channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = blockIdx.x % p.co_blocks, ib = blockIdx.x / p.co_blocks, split = blockIdx.y;
   const int co0 = cb * C::CB, ci0 = ib * C::IB;
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
   const int chb0 = ina ? ci0 : ci0 - p.a.C;
   const bool has_scale = s.scale != nullptr, has_mask = s.emask != nullptr, has_cm = s.cmask != nullptr;
   const float es = s.es;
-  for (int c = tid; c < C::IB; c += kThreads)
+  for (int c = tid; c < C::IB; c += C::THREADS)
     tab[c] = has_scale ? make_float2(s.scale[chb0 + c], s.shift[chb0 + c]) : make_float2(1.f, 0.f);
 
   // fixed staging positions of this thread
@@ -856,68 +859,69 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
     nx_n = q / p.tiles_y;
   }
   const int c16 = lane & 15, t4 = lane >> 4;
-  __syncthreads();   // BN table visible
 
-  for (int item = it0; item < it1; ++item) {
-    // ---- stage the two raw tiles (no prefetch registers are held across the compute phase: a step is ~5000 cycles of
-    // matrix work per wave, the co-resident workgroup covers this one's load latency)
-    {
-      const int n = nx_n, y0 = nx_ty * TH, x0 = nx_tx * TW;
-      if (++nx_tx == p.tiles_x) {
-        nx_tx = 0;
-        if (++nx_ty == p.tiles_y) nx_ty = 0, ++nx_n;
-      }
-      float4 prd[C::ND], pra[C::NA];
-      uint32_t prm[C::NA];
-      float prc[C::NA];
-      const float* dyb = p.dy + n * p.dy_bs + (int64_t)co0 * HW + (uint32_t)(tdconst + y0 * W + x0);
+  // ---- staging: global -> registers (issue), registers -> transform -> LDS tile buffer (commit)
+  float4 prd[C::ND], pra[C::NA];
+  uint32_t prm[C::NA];
+  float prc[C::NA];
+  bool pr_aok = false;
+  auto issue = [&]() __attribute__((always_inline)) {
+    const int n = nx_n, y0 = nx_ty * TH, x0 = nx_tx * TW;
+    if (++nx_tx == p.tiles_x) {
+      nx_tx = 0;
+      if (++nx_ty == p.tiles_y) nx_ty = 0, ++nx_n;
+    }
+    const float* dyb = p.dy + n * p.dy_bs + (int64_t)co0 * HW + (uint32_t)(tdconst + y0 * W + x0);
 #pragma unroll
-      for (int i = 0; i < C::ND; ++i) prd[i] = *reinterpret_cast<const float4*>(dyb + i * dstride);
-      const int gy = y0 + aty - 1, gx = x0 + atx4 * 4 - C::PADL;
-      const bool aok = owner_a && gx >= 0 && gx < W && gy >= 0 && gy < H;
-      const uint32_t taoff = aok ? (uint32_t)(ga * HW + gy * W + gx) : 0u;
-      const float* xb = s.x + n * s.bs + (int64_t)chb0 * HW;
+    for (int i = 0; i < C::ND; ++i) prd[i] = *reinterpret_cast<const float4*>(dyb + i * dstride);
+    const int gy = y0 + aty - 1, gx = x0 + atx4 * 4 - C::PADL;
+    pr_aok = owner_a && gx >= 0 && gx < W && gy >= 0 && gy < H;
+    const uint32_t taoff = pr_aok ? (uint32_t)(ga * HW + gy * W + gx) : 0u;
+    const float* xb = s.x + n * s.bs + (int64_t)chb0 * HW;
 #pragma unroll
-      for (int i = 0; i < C::NA; ++i) pra[i] = *reinterpret_cast<const float4*>(xb + i * astride + taoff);
-      if (has_mask) {
-        const uint8_t* mb = s.emask + ((int64_t)n * s.C + chb0) * HW;
+    for (int i = 0; i < C::NA; ++i) pra[i] = *reinterpret_cast<const float4*>(xb + i * astride + taoff);
+    if (has_mask) {
+      const uint8_t* mb = s.emask + ((int64_t)n * s.C + chb0) * HW;
 #pragma unroll
-        for (int i = 0; i < C::NA; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * astride + taoff);
-      }
-      if (has_cm) {
-        const float* cmb = s.cmask + (int64_t)n * s.C + chb0 + (owner_a ? ga : 0);
+      for (int i = 0; i < C::NA; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * astride + taoff);
+    }
+    if (has_cm) {
+      const float* cmb = s.cmask + (int64_t)n * s.C + chb0 + (owner_a ? ga : 0);
 #pragma unroll
-        for (int i = 0; i < C::NA; ++i) prc[i] = cmb[i * C::GA];
-      }
+      for (int i = 0; i < C::NA; ++i) prc[i] = cmb[i * C::GA];
+    }
+  };
+  auto commit = [&](float* dy_t, float* a_t) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < C::ND; ++i) {   // plane stride == 2 (mod 32): 8-byte aligned, not 16
-        float* dst = dy_t + i * (C::GD * C::PLD) + dloff;
-        *reinterpret_cast<float2*>(dst) = make_float2(prd[i].x, prd[i].y);
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(prd[i].z, prd[i].w);
-      }
-      if (owner_a) {
+    for (int i = 0; i < C::ND; ++i) {   // plane stride == 2 (mod 32): 8-byte aligned, not 16
+      float* dst = dy_t + i * (C::GD * C::PLD) + dloff;
+      *reinterpret_cast<float2*>(dst) = make_float2(prd[i].x, prd[i].y);
+      *reinterpret_cast<float2*>(dst + 2) = make_float2(prd[i].z, prd[i].w);
+    }
+    if (owner_a) {
 #pragma unroll
-        for (int i = 0; i < C::NA; ++i) {
-          wsl_v2f lo = {pra[i].x, pra[i].y}, hi = {pra[i].z, pra[i].w};
-          if (has_scale) {
-            const float2 t = tab[ga + i * C::GA];
-            xform_bn_leaky(lo, hi, t.x, t.y);
-          }
-          if (has_mask) xform_mask(lo, hi, prm[i], es);
-          if (has_cm) lo = lo * prc[i], hi = hi * prc[i];
-          if (!aok) lo = wsl_v2f{0.f, 0.f}, hi = wsl_v2f{0.f, 0.f};
-          float* dst = a_t + i * (C::GA * C::PLA) + aloff;
-          *reinterpret_cast<float2*>(dst) = make_float2(lo[0], lo[1]);
-          *reinterpret_cast<float2*>(dst + 2) = make_float2(hi[0], hi[1]);
+      for (int i = 0; i < C::NA; ++i) {
+        wsl_v2f lo = {pra[i].x, pra[i].y}, hi = {pra[i].z, pra[i].w};
+        if (has_scale) {
+          const float2 t = tab[ga + i * C::GA];
+          xform_bn_leaky(lo, hi, t.x, t.y);
         }
+        if (has_mask) xform_mask(lo, hi, prm[i], es);
+        if (has_cm) lo = lo * prc[i], hi = hi * prc[i];
+        if (!pr_aok) lo = wsl_v2f{0.f, 0.f}, hi = wsl_v2f{0.f, 0.f};
+        float* dst = a_t + i * (C::GA * C::PLA) + aloff;
+        *reinterpret_cast<float2*>(dst) = make_float2(lo[0], lo[1]);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(hi[0], hi[1]);
       }
     }
-    __syncthreads();
-    // ---- compute: this wave's half of the tile groups.  Raw operands of group g+1 are read from LDS before the MFMAs of
-    // group g issue.  Z is formed WITHOUT the two negations of A (rows/columns with index 3 carry the opposite sign:
-    // Z'[p][q] = s_p s_q Z[p][q], s_3 = -1); the epilogue puts the signs back into M -- 10 instead of 16 adds per channel.
+  };
+
+  // ---- compute on one tile buffer: this wave's subset of the tile groups.  Raw operands of group g+1 are read from LDS
+  // before the MFMAs of group g issue.  Z is formed WITHOUT the two negations of A (rows/columns with index 3 carry the
+  // opposite sign: Z'[p][q] = s_p s_q Z[p][q], s_3 = -1); the epilogue puts the signs back into M.
+  auto compute = [&](const float* dy_t, const float* a_t) __attribute__((always_inline)) {
     float2 rdy[NCO][2];   // [jc][row]
-    v4f rd[4];          // the 4 x 4 input patch, one row per vector
+    v4f rd[4];            // the 4 x 4 input patch, one row per vector
     auto fetch = [&](int g) __attribute__((always_inline)) {
       const int tau = g * 4 + t4, tyy = tau / C::TTX, txx = tau - tyy * C::TTX;
 #pragma unroll
@@ -933,8 +937,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
         rd[i] = v4f{r[0], m.x, m.y, r[3]};
       }
     };
-    constexpr int G0 = 0, GN = C::GROUPS / C::NSUB;
-    fetch(sub * GN + G0);
+    constexpr int GN = C::GROUPS / C::NSUB;
+    fetch(sub * GN);
 #pragma unroll 1
     for (int gi = 0; gi < GN; ++gi) {
       float z[NCO][16];
@@ -968,7 +972,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
 #pragma unroll
         for (int jc = 0; jc < NCO; ++jc) acc[xi][jc] = WSL_MFMA16(z[jc][xi], v[xi], acc[xi][jc]);
     }
+  };
+
+  __syncthreads();   // BN table visible
+  if constexpr (C::NBUF == 1) {
+    // a step is ~5000 cycles of matrix work per wave; the co-resident workgroup covers this one's load latency
+    for (int item = it0; item < it1; ++item) {
+      issue();
+      commit(tiles, tiles + C::DY_FLOATS);
+      __syncthreads();
+      compute(tiles, tiles + C::DY_FLOATS);
+      __syncthreads();
+    }
+  } else {
+    if (it0 < it1) {
+      issue();
+      commit(tiles, tiles + C::DY_FLOATS);
+    }
     __syncthreads();
+    int cur = 0;
+    for (int item = it0; item < it1; ++item, cur ^= 1) {
+      const bool more = item + 1 < it1;
+      if (more) issue();                                         // in flight during the compute phase
+      compute(tiles + cur * C::BUF_FLOATS, tiles + cur * C::BUF_FLOATS + C::DY_FLOATS);
+      if (more) commit(tiles + (cur ^ 1) * C::BUF_FLOATS, tiles + (cur ^ 1) * C::BUF_FLOATS + C::DY_FLOATS);
+      __syncthreads();   // the other buffer was last read before the previous barrier
+    }
   }
 
   // ---- epilogue: dg = G^T M G per lane, merge the tile subsets (fixed order), store the 9 taps
@@ -1040,10 +1069,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgWinoP p) {
   }
 }
 
-template <int TH, int TW, int NCO, int NCI>
+template <int TH, int TW, int NCO, int NCI, int NW>
 static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
-  using C = WgWinoCfg<TH, TW, NCO, NCI>;
-  auto kern = wgrad_wino_kernel<TH, TW, NCO, NCI>;
+  using C = WgWinoCfg<TH, TW, NCO, NCI, NW>;
+  auto kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
@@ -1052,9 +1081,17 @@ static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
   dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
   const double px = (double)p.N * p.H * p.W;
   void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
-  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  WSL_LAUNCH(kern, grid, dim3(C::THREADS), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("wgrad_wino_kernel");
+}
+
+// waves per workgroup of the 32 x 32 variant: 4 (default: two workgroups per CU) or 8 = one double-buffered workgroup per CU
+// with the next tile's loads in flight during the compute phase -- measured equal (+-5 % per layer), so it stays opt-in
+// (env WSL_WGRAD_WINO_WAVES=8)
+int wgrad_wino_waves() {
+  static const int w = getenv("WSL_WGRAD_WINO_WAVES") ? atoi(getenv("WSL_WGRAD_WINO_WAVES")) : 4;
+  return w == 8 ? 8 : 4;
 }
 
 // takes the launches wgrad_mfma2s_kernel would get with the same plan: 3x3, 32 x 32 channel blocks (two dY tiles per wave,
@@ -1084,9 +1121,13 @@ int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t
   p.dy = dy, p.dy_bs = dy_bs, p.part_dw = part_dw, p.part_db = part_db;
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
-  if (cb == 32) return th == 4 ? launch_wgrad_wino<4, 32, 2, 2>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2>(p, ci_blocks, stream);
-  if (tw == 64) return launch_wgrad_wino<4, 64, 1, 1>(p, ci_blocks, stream);
-  return th == 4 ? launch_wgrad_wino<4, 32, 1, 1>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 1, 1>(p, ci_blocks, stream);
+  if (cb == 32) {
+    if (wgrad_wino_waves() == 8)
+      return th == 4 ? launch_wgrad_wino<4, 32, 2, 2, 8>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2, 8>(p, ci_blocks, stream);
+    return th == 4 ? launch_wgrad_wino<4, 32, 2, 2, 4>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2, 4>(p, ci_blocks, stream);
+  }
+  if (tw == 64) return launch_wgrad_wino<4, 64, 1, 1, 4>(p, ci_blocks, stream);
+  return th == 4 ? launch_wgrad_wino<4, 32, 1, 1, 4>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 1, 1, 4>(p, ci_blocks, stream);
 }
 
 }  // namespace wsl
