@@ -95,6 +95,12 @@ int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t
  * form of the kernel (input transform through LDS) instead of the register-resident one. */
 int wsl_conv2d_wino_ok(int N, int H, int W, int Ca, int Cb, int Co, int ks);
 int wsl_debug_conv_wino(int on);
+/* Kernel variants kept for A/B timing (both measured, see profiles/r1z_winograd.md): conv_form 1 = the first form of the
+ * Winograd conv kernel (input transform through LDS), 2 = default (transform in the MFMA operand registers); wgrad_waves 8 =
+ * the Winograd weight gradient as one 8-wave double-buffered workgroup per CU, 4 = default.  Any other value re-reads the
+ * environment (WSL_WINO_FORM, WSL_WGRAD_WINO_WAVES).  The weight gradient of conv2d_wgrad() itself takes its Winograd form
+ * automatically for 3x3 layers with 16- or 32-aligned channel counts (env WSL_WGRAD_WINO=0 switches it off). */
+int wsl_debug_wino_variant(int conv_form, int wgrad_waves);
 /* Debug / experiments: which packed-path kernel wsl_conv2d_fwd(wmode 2|3) launches: 2 = lock-step workgroups with a
  * register prefetch (default, fastest measured), 3 = wave-specialised persistent workgroups (wsl_conv3.hip). */
 int wsl_debug_conv_variant(int v);

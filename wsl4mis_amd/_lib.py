@@ -61,6 +61,7 @@ _PROTOS = {
     "wsl_debug_conv_plan": (i32, [i32, i32, i32]),
     "wsl_conv2d_wino_ok": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "wsl_debug_conv_wino": (i32, [i32]),
+    "wsl_debug_wino_variant": (i32, [i32, i32]),
     "wsl_debug_net_concurrent": (i32, [i32]),
     "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
     "wsl_debug_lds_dma_probe": (i32, [c_fp, c_fp, c_fp]),

@@ -699,7 +699,8 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   if (v2 && g.cb == 32 && wgrad_wino_ok(p.in.a, &p.in.b, H, W, Co, ks, g.th, g.tw, g.cb, g.ib)) {
     // the 32 x 32 Winograd weight gradient holds 128 accumulator registers: 2 resident workgroups per CU -> 512 persistent ones
     // (256 when it runs as one 8-wave double-buffered workgroup per CU)
-    static const int wgs = getenv("WSL_WGRAD_WINO_WGS") ? atoi(getenv("WSL_WGRAD_WINO_WGS")) : (wgrad_wino_waves() == 8 ? 256 : 512);
+    static const int wgs_env = getenv("WSL_WGRAD_WINO_WGS") ? atoi(getenv("WSL_WGRAD_WINO_WGS")) : 0;
+    const int wgs = wgs_env > 0 ? wgs_env : (wgrad_wino_waves() == 8 ? 256 : 512);
     int want = wgs / (g.co_blocks * g.ci_blocks);
     if (want < 1) want = 1;
     if (want < g.nsplit) g.nsplit = want;   // never more partials than the workspace was sized for

@@ -704,6 +704,13 @@ bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, 
   return true;
 }
 
+// kernel variants (defaults from the environment; wsl_debug_wino_variant() overrides them for tests / A-B timing)
+static int g_wino_form = -1, g_wgrad_waves = -1;
+static int wino_form() {
+  if (g_wino_form < 0) g_wino_form = (getenv("WSL_WINO_FORM") && atoi(getenv("WSL_WINO_FORM")) == 1) ? 1 : 2;
+  return g_wino_form;
+}
+
 template <int TH, int TW, int NT>
 static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
   using C = Wino2Cfg<TH, TW, NT>;
@@ -755,7 +762,7 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
     return WSL_EINVAL;
   }
   p.tiles_x = W / tw, p.tiles_y = H / th;
-  static const int form = getenv("WSL_WINO_FORM") ? atoi(getenv("WSL_WINO_FORM")) : 2;   // 1: V through LDS, 2: V in registers
+  const int form = wino_form();   // 1: V through LDS, 2: V in registers
   if (tw == 64) return launch_wino2<8, 64, 1>(p, is_dgrad, stream);
   if (form == 2 && co_t == 32) {
     if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);
@@ -1090,8 +1097,8 @@ static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
 // with the next tile's loads in flight during the compute phase -- measured equal (+-5 % per layer), so it stays opt-in
 // (env WSL_WGRAD_WINO_WAVES=8)
 int wgrad_wino_waves() {
-  static const int w = getenv("WSL_WGRAD_WINO_WAVES") ? atoi(getenv("WSL_WGRAD_WINO_WAVES")) : 4;
-  return w == 8 ? 8 : 4;
+  if (g_wgrad_waves < 0) g_wgrad_waves = (getenv("WSL_WGRAD_WINO_WAVES") && atoi(getenv("WSL_WGRAD_WINO_WAVES")) == 8) ? 8 : 4;
+  return g_wgrad_waves;
 }
 
 // takes the launches wgrad_mfma2s_kernel would get with the same plan: 3x3, 32 x 32 channel blocks (two dY tiles per wave,
@@ -1131,3 +1138,9 @@ int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t
 }
 
 }  // namespace wsl
+
+extern "C" int wsl_debug_wino_variant(int conv_form, int wgrad_waves) {
+  wsl::g_wino_form = conv_form == 1 ? 1 : conv_form == 2 ? 2 : -1;
+  wsl::g_wgrad_waves = wgrad_waves == 8 ? 8 : wgrad_waves == 4 ? 4 : -1;
+  return WSL_OK;
+}
