@@ -512,7 +512,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
         }
       }
       if (kg == 0) fetch(1);   // the second channel group's patches are read while the first group's MFMAs issue
-      float bv[2][NT];
+      // B operands are requested BD transform positions ahead of their MFMAs (a position's two MFMAs take 64 cycles, an
+      // LDS read comes back after more than that)
+      constexpr int BD = NT == 2 ? 4 : 2, BR = BD + 1;   // (the 128-tile variant has no registers to spare)
+      float bv[BR][NT];
       auto loadb = [&](int xi, int buf) __attribute__((always_inline)) {
         const float* bp = w_t + xi * (4 * 16 * 2 * NT) + b_off + kg * NT;
         if constexpr (NT == 2) {
@@ -522,14 +525,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
           bv[buf][0] = bp[0];
         }
       };
-      loadb(0, 0);
+#pragma unroll
+      for (int xi = 0; xi < BD; ++xi) loadb(xi, xi % BR);
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) {
-        if (xi + 1 < 16) loadb(xi + 1, (xi + 1) & 1);
+        if (xi + BD < 16) loadb(xi + BD, (xi + BD) % BR);
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi & 1][j], acc[xi][m * NT + j]);
+          for (int j = 0; j < NT; ++j) acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi % BR][j], acc[xi][m * NT + j]);
         WSL_SCHED_BARRIER();
       }
     }
