@@ -950,7 +950,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
     };
     constexpr int GN = C::GROUPS / C::NSUB;
     fetch(sub * GN);
-#pragma unroll 1
+#pragma unroll   // (fully: a rolled loop pays 24 register moves per group for the prefetched operands)
     for (int gi = 0; gi < GN; ++gi) {
       float z[NCO][16];
 #pragma unroll
