@@ -370,6 +370,92 @@ struct Wino2Cfg {
   static_assert(8 * CO_T <= IN_FLOATS && (TTX % 16 == 0 || MTW == 1), "reduction scratch / row groups");
 };
 
+// epilogue of both conv_wino2 kernels: output transform (register-only), bias, float4 stores, BatchNorm partials
+template <typename C, int TH, int TW, int NT>
+__device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2], float* scratch, int n, int co0, int y0, int x0,
+                                               int tile_id, int nb) {
+  constexpr int CO_T = C::CO_T, MTW = C::MTW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = p.W, HW = p.H * p.W;
+  float* in_t = scratch;
+  float o[2][16];
+  float bsum[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int tb = (wave * MTW + m) * 16 + 4 * (lane >> 4);          // first of this lane's 4 consecutive tiles
+    const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
+    float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int a = m * NT + j;
+      const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
+      float bs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float m0 = acc[c][a][r], m1 = acc[4 + c][a][r], m2 = acc[8 + c][a][r], m3 = acc[12 + c][a][r];
+          s0[c] = (m0 + m1) + m2;
+          s1[c] = (m1 - m2) - m3;
+        }
+        const float y00 = ((s0[0] + s0[1]) + s0[2]) + bias, y01 = ((s0[1] - s0[2]) - s0[3]) + bias;
+        const float y10 = ((s1[0] + s1[1]) + s1[2]) + bias, y11 = ((s1[1] - s1[2]) - s1[3]) + bias;
+        o[a][2 * r] = y00, o[a][2 * r + 1] = y01, o[a][8 + 2 * r] = y10, o[a][8 + 2 * r + 1] = y11;
+        bs += (y00 + y01) + (y10 + y11);
+      }
+      float* yj = yb + (int64_t)j * 16 * HW;
+      *reinterpret_cast<float4*>(yj) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
+      *reinterpret_cast<float4*>(yj + 4) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
+      *reinterpret_cast<float4*>(yj + W) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
+      *reinterpret_cast<float4*>(yj + W + 4) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
+      bsum[j] += bs;
+    }
+  }
+  if (p.stat_part) {
+    float* red1 = in_t;
+    float* red2 = in_t + 4 * CO_T;
+    constexpr float cnt = (float)(TH * TW);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = j * 16 + (lane & 15);
+      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float d = o[m * NT + j][e] - mean_b;
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = j * 16 + lane, co = co0 + col;
+        float* dst = p.stat_part + ((int64_t)co * ((int64_t)nb * p.slots) + (int64_t)tile_id * p.slots) * 2;   // [Co][slots][2]
+        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+      }
+      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
+    }
+  }
+}
+
 template <int TH, int TW, int NT>
 __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
   using C = Wino2Cfg<TH, TW, NT>;
@@ -540,83 +626,151 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: output transform (register-only), bias, float4 stores, BatchNorm partials
-  float o[2][16];
-  float bsum[NT];
+  wino2_epilogue<C, TH, TW, NT>(p, acc, in_t, n, co0, y0, x0, tile_id, nb);
+}
+
+// conv_wino2_kernel for launches whose sources carry no loader transform (every data-gradient launch): the raw tile and the
+// filter block need no VGPR round trip -- global_load_lds_dwordx4 streams both into LDS (lane-contiguous layouts: a thread's
+// tile slot is 16 * tid bytes into its plane group, the filter block is linear), double-buffered, so a chunk costs the
+// input transform + MFMAs and ONE barrier: no staging VALU, no LDS writes, no prefetch registers.
+template <int TH, int TW, int NT>
+struct Wino2RCfg : Wino2Cfg<TH, TW, NT> {
+  using B = Wino2Cfg<TH, TW, NT>;
+  static constexpr int PLANE = B::ROWS * B::ROWP;            // unpadded: slot of thread t = 4 * t floats into the plane group
+  static constexpr int IN_FLOATS = B::KC * PLANE;
+  static constexpr size_t SMEM = sizeof(float) * (2 * IN_FLOATS + 2 * B::W_FLOATS);
+  static_assert(PLANE == 4 * B::POS && 8 * B::CO_T <= IN_FLOATS, "lane-contiguous tile layout");
+};
+
+template <int TH, int TW, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
+  using C = Wino2RCfg<TH, TW, NT>;
+  constexpr int KC = C::KC, CO_T = C::CO_T, MTW = C::MTW;
+  WSL_DYN_SMEM(smem);
+  float* in_b = reinterpret_cast<float*>(smem);      // two raw halo tiles [KC][PLANE]
+  float* w_b = in_b + 2 * C::IN_FLOATS;              // two filter blocks (operand order of conv_wino2_kernel)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD-aware tile order, as conv_mfma2_kernel
+  const int tile_id = bid;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = blockIdx.y * CO_T;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
+  const int HW = H * W;
+
+  const int grp = tid / C::POS, pos = tid - grp * C::POS;
+  const int pty = pos / C::ROWP4, ptx4 = pos - pty * C::ROWP4;
+  const int gy = y0 + pty - 1, gx = x0 + ptx4 * 4 - C::PADL;
+  const bool owner = grp < C::G;
+  const bool pvalid = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
+  const uint32_t toff = pvalid ? (uint32_t)(grp * HW + gy * W + gx) : 0u;
+  const int64_t gstride = (int64_t)C::G * HW;
+  const float* xa_n = p.a.x + n * p.a.bs;
+  const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
+  const float* w_n = p.u + (int64_t)blockIdx.y * C::W_FLOATS + 4 * tid;
+  const int64_t w_cstride = (int64_t)(Co / CO_T) * C::W_FLOATS;
+
+  // slots of positions outside the image stay zero in both buffers for the whole kernel: the DMA never touches them
+  if (owner && !pvalid) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
+    for (int bsel = 0; bsel < 2; ++bsel)
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i)
+        *reinterpret_cast<float4*>(in_b + bsel * C::IN_FLOATS + i * (C::G * C::PLANE) + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto issue = [&](int c0, int bsel) __attribute__((always_inline)) {
+    const bool ina = c0 < p.a.C;                                   // uniform
+    const int chb = ina ? c0 : c0 - p.a.C;
+    const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
+    float* dst = in_b + bsel * C::IN_FLOATS + wave * 256;          // wave-uniform: lane l lands at dst + 4 * l floats
+    if (pvalid) {
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) WSL_LDS_DMA16(xb + i * gstride + toff, dst + i * (C::G * C::PLANE));
+    }
+    const float* wb = w_n + (c0 / KC) * w_cstride;
+    float* wdst = w_b + bsel * C::W_FLOATS + wave * 256;
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) WSL_LDS_DMA16(wb + i * (4 * kThreads), wdst + i * (4 * kThreads));
+  };
+
+  issue(0, 0);
+  v4f acc[16][2];   // [xi][m * NT + j]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i][0] = v4f{0.f, 0.f, 0.f, 0.f}, acc[i][1] = v4f{0.f, 0.f, 0.f, 0.f};
+  int poff[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
-    const int tb = (wave * MTW + m) * 16 + 4 * (lane >> 4);          // first of this lane's 4 consecutive tiles
-    const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
-    float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int a = m * NT + j;
-      const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
-      float bs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float m0 = acc[c][a][r], m1 = acc[4 + c][a][r], m2 = acc[8 + c][a][r], m3 = acc[12 + c][a][r];
-          s0[c] = (m0 + m1) + m2;
-          s1[c] = (m1 - m2) - m3;
-        }
-        const float y00 = ((s0[0] + s0[1]) + s0[2]) + bias, y01 = ((s0[1] - s0[2]) - s0[3]) + bias;
-        const float y10 = ((s1[0] + s1[1]) + s1[2]) + bias, y11 = ((s1[1] - s1[2]) - s1[3]) + bias;
-        o[a][2 * r] = y00, o[a][2 * r + 1] = y01, o[a][8 + 2 * r] = y10, o[a][8 + 2 * r + 1] = y11;
-        bs += (y00 + y01) + (y10 + y11);
-      }
-      float* yj = yb + (int64_t)j * 16 * HW;
-      *reinterpret_cast<float4*>(yj) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
-      *reinterpret_cast<float4*>(yj + 4) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
-      *reinterpret_cast<float4*>(yj + W) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
-      *reinterpret_cast<float4*>(yj + W + 4) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
-      bsum[j] += bs;
-    }
+    const int t = (wave * MTW + m) * 16 + (lane & 15), tyy = t / C::TTX, txx = t - tyy * C::TTX;
+    poff[m] = (lane >> 4) * C::PLANE + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
   }
-  if (p.stat_part) {
-    float* red1 = in_t;
-    float* red2 = in_t + 4 * CO_T;
-    constexpr float cnt = (float)(TH * TW);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s = bsum[j];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = j * 16 + (lane & 15);
-      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
-      float q = 0.f;
+  const int b_off = lane * (2 * NT);
+  WSL_WAIT_ALL();
+  __syncthreads();   // first chunk landed, zero slots visible
+
+  int bsel = 0;
+  for (int c0 = 0; c0 < Ci; c0 += KC, bsel ^= 1) {
+    if (c0 + KC < Ci) issue(c0 + KC, bsel ^ 1);   // the next chunk streams into the other buffers during this one's compute
+    const float* in_t = in_b + bsel * C::IN_FLOATS;
+    const float* w_t = w_b + bsel * C::W_FLOATS;
+    v4f rd[MTW][4];
+    auto fetch = [&](int kg) __attribute__((always_inline)) {
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float d = o[m * NT + j][e] - mean_b;
-          q = fmaf(d, d, q);
+        for (int i = 0; i < 4; ++i) {
+          const float* r = in_t + kg * (4 * C::PLANE) + poff[m] + i * C::ROWP;
+          const float2 mm = *reinterpret_cast<const float2*>(r + 1);
+          rd[m][i] = v4f{r[0], mm.x, mm.y, r[3]};
         }
-      q += __shfl_xor(q, 16);
-      q += __shfl_xor(q, 32);
-      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
-    }
-    __syncthreads();
-    if (wave == 0 && lane < 16) {
+    };
+    fetch(0);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = j * 16 + lane, co = co0 + col;
-        float* dst = p.stat_part + ((int64_t)co * ((int64_t)nb * p.slots) + (int64_t)tile_id * p.slots) * 2;   // [Co][slots][2]
-        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
-        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+    for (int kg = 0; kg < 2; ++kg) {
+      float v[MTW][16];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const v4f rt[4] = {rd[m][0] - rd[m][2], rd[m][1] + rd[m][2], rd[m][2] - rd[m][1], rd[m][1] - rd[m][3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[m][4 * i + 0] = rt[i][0] - rt[i][2];
+          v[m][4 * i + 1] = rt[i][1] + rt[i][2];
+          v[m][4 * i + 2] = rt[i][2] - rt[i][1];
+          v[m][4 * i + 3] = rt[i][1] - rt[i][3];
+        }
       }
-      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
+      if (kg == 0) fetch(1);
+      constexpr int BD = NT == 2 ? 4 : 2, BR = BD + 1;
+      float bv[BR][NT];
+      auto loadb = [&](int xi, int buf) __attribute__((always_inline)) {
+        const float* bp = w_t + xi * (4 * 16 * 2 * NT) + b_off + kg * NT;
+        if constexpr (NT == 2) {
+          const float2 b2 = *reinterpret_cast<const float2*>(bp);
+          bv[buf][0] = b2.x, bv[buf][1] = b2.y;
+        } else {
+          bv[buf][0] = bp[0];
+        }
+      };
+#pragma unroll
+      for (int xi = 0; xi < BD; ++xi) loadb(xi, xi % BR);
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) {
+        if (xi + BD < 16) loadb(xi + BD, (xi + BD) % BR);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi % BR][j], acc[xi][m * NT + j]);
+        WSL_SCHED_BARRIER();
+      }
     }
+    WSL_WAIT_ALL();    // the next chunk's DMA has landed
+    __syncthreads();   // ... and every wave is done with this chunk's buffers
   }
+  wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb);
 }
 
 // ------------------------------------------------------------------------------------------------ filter transform
@@ -716,7 +870,27 @@ static int wino_form() {
 }
 
 template <int TH, int TW, int NT>
+static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
+  using C = Wino2RCfg<TH, TW, NT>;
+  auto kern = conv_wino2r_kernel<TH, TW, NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(is_dgrad ? 7 : 6, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_wino2r_kernel");
+}
+
+template <int TH, int TW, int NT>
 static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
+  static const bool dma_on = !(getenv("WSL_WINO_DMA") && atoi(getenv("WSL_WINO_DMA")) == 0);
+  const bool raw = !p.a.scale && !p.a.emask && !p.a.cmask && (p.b.C == 0 || (!p.b.scale && !p.b.emask && !p.b.cmask));
+  if (dma_on && raw && wino_form() == 2) return launch_wino2r<TH, TW, NT>(p, is_dgrad, stream);   // plain sources: LDS DMA
   using C = Wino2Cfg<TH, TW, NT>;
   auto kern = conv_wino2_kernel<TH, TW, NT>;
   static bool attr_done = false;
