@@ -20,6 +20,8 @@
 // and two workgroups fit the 160 KB LDS of a CU.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "wsl_rt.h"
 
 namespace wsl {
@@ -567,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
   const int b_off = lane * (2 * NT);   // ((k = lane >> 4) * 16 + (col = lane & 15)) * (2 kg * NT j)
   __syncthreads();   // tables visible
 
+  // (peeling the first chunk to skip the accumulator clear, as the raw-source kernel does, costs 23 VGPRs here: spills)
   for (int c0 = 0; c0 < Ci; c0 += KC) {
     commit(c0);
     if (c0 + KC < Ci) issue(c0 + KC);   // flies across the whole compute phase
@@ -699,9 +702,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   };
 
   issue(0, 0);
-  v4f acc[16][2];   // [xi][m * NT + j]
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i][0] = v4f{0.f, 0.f, 0.f, 0.f}, acc[i][1] = v4f{0.f, 0.f, 0.f, 0.f};
+  v4f acc[16][2];   // [xi][m * NT + j]; first written by the first chunk's MFMAs
   int poff[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
@@ -712,8 +713,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   WSL_WAIT_ALL();
   __syncthreads();   // first chunk landed, zero slots visible
 
-  int bsel = 0;
-  for (int c0 = 0; c0 < Ci; c0 += KC, bsel ^= 1) {
+  // one chunk; FIRST: the accumulators start from the MFMA's zero C operand (no 128-register clear)
+  auto chunk = [&](int c0, int bsel, auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     if (c0 + KC < Ci) issue(c0 + KC, bsel ^ 1);   // the next chunk streams into the other buffers during this one's compute
     const float* in_t = in_b + bsel * C::IN_FLOATS;
     const float* w_t = w_b + bsel * C::W_FLOATS;
@@ -763,13 +765,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi % BR][j], acc[xi][m * NT + j]);
+          for (int j = 0; j < NT; ++j) {
+            const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+            const v4f cin = (FIRST && kg == 0) ? zero4 : acc[xi][m * NT + j];
+            acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi % BR][j], cin);
+          }
         WSL_SCHED_BARRIER();
       }
     }
     WSL_WAIT_ALL();    // the next chunk's DMA has landed
     __syncthreads();   // ... and every wave is done with this chunk's buffers
-  }
+  };
+  chunk(0, 0, std::true_type{});
+  for (int c0 = KC, bsel = 1; c0 < Ci; c0 += KC, bsel ^= 1) chunk(c0, bsel, std::false_type{});
   wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb);
 }
 
