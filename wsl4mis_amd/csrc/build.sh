@@ -15,7 +15,11 @@ for s in "${srcs[@]}"; do
   o="$here/build/$s.o"
   objs+=("$o")
   if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "$here/$s.hip" -o "$o" &
+    extra=""
+    # the Winograd kernels are bound by their vector-instruction count: the SLP vectoriser packs the output transforms into
+    # v_pk_add_f32 and then pays more v_mov_b32 to un-interleave the results than it saved (-8 % vector instructions without)
+    [ "$s" = "wsl_conv5" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra -c "$here/$s.hip" -o "$o" &
     pids+=($!)
   fi
 done
