@@ -367,7 +367,7 @@ struct Wino2Cfg {
   static constexpr int IN_FLOATS = KC * PLANE, W_FLOATS = 16 * KC * CO_T;
   static constexpr int WF4 = W_FLOATS / 4, NWL = WF4 / 256;
   static constexpr int MAXC = 256;
-  static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + 2 * W_FLOATS + 3 * MAXC);
+  static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + W_FLOATS + 3 * MAXC);
   static_assert(TILES % 64 == 0 && NA == 2 && POS <= 256 && KC % G == 0 && WF4 % 256 == 0 && TTX % 4 == 0, "tile shape");
   static_assert(8 * CO_T <= IN_FLOATS && (TTX % 16 == 0 || MTW == 1), "reduction scratch / row groups");
 };
@@ -464,9 +464,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
   constexpr int KC = C::KC, CO_T = C::CO_T, MTW = C::MTW;
   WSL_DYN_SMEM(smem);
   float* in_t = reinterpret_cast<float*>(smem);                 // raw (transformed-on-load) halo tile [KC][PLANE]
-  float* w_b = in_t + C::IN_FLOATS;                             // two U chunks (LDS DMA), operand order: [16 xi][4 k][16 col][2 kg][NT j]
-  float2* tab = reinterpret_cast<float2*>(w_b + 2 * C::W_FLOATS);   // [Ci] {scale, shift}
-  float* cm_l = w_b + 2 * C::W_FLOATS + 2 * C::MAXC;            // [Ci] channel multiplier of this sample
+  float* w_t = in_t + C::IN_FLOATS;                             // U chunk, operand order: [16 xi][4 k][16 col][2 kg][NT j]
+  float2* tab = reinterpret_cast<float2*>(w_t + C::W_FLOATS);   // [Ci] {scale, shift}
+  float* cm_l = w_t + C::W_FLOATS + 2 * C::MAXC;                // [Ci] channel multiplier of this sample
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x;
   const int nb = gridDim.x;
@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
 
   float4 pre[C::NLD];
   uint32_t prm[C::NLD];
+  v4f prw[C::NWL];
 
   auto issue = [&](int c0) __attribute__((always_inline)) {
     const bool ina = c0 < p.a.C;                                   // uniform
@@ -512,11 +513,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
 #pragma unroll
       for (int i = 0; i < C::NLD; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * gstride + toff);
     }
-    // the filter block goes straight to LDS (it is stored in operand order: a linear copy), into the buffer of chunk c0
     const float* wb = w_n + (c0 / KC) * w_cstride;
-    float* wdst = w_b + ((c0 / KC) & 1) * C::W_FLOATS + wave * 256;
 #pragma unroll
-    for (int i = 0; i < C::NWL; ++i) WSL_LDS_DMA16(wb + i * (4 * kThreads), wdst + i * (4 * kThreads));
+    for (int i = 0; i < C::NWL; ++i) prw[i] = *reinterpret_cast<const v4f*>(wb + i * (4 * kThreads));
   };
 
   auto commit = [&](int c0) __attribute__((always_inline)) {
@@ -539,6 +538,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
         *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
       }
     }
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) *reinterpret_cast<v4f*>(w_t + 4 * tid + i * (4 * kThreads)) = prw[i];
   };
 
   issue(0);
@@ -555,14 +556,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
       *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  // PEEL: the first chunk's MFMAs start from the zero C operand instead of a 128-register clear (the 128-tile variant has
-  // no registers to spare for the peeled copy of the chunk body)
-  constexpr bool PEEL = NT == 2;
   v4f acc[16][2];   // [xi][m * NT + j]
-  if constexpr (!PEEL) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i][0] = v4f{0.f, 0.f, 0.f, 0.f}, acc[i][1] = v4f{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int i = 0; i < 16; ++i) acc[i][0] = v4f{0.f, 0.f, 0.f, 0.f}, acc[i][1] = v4f{0.f, 0.f, 0.f, 0.f};
   // this lane's A-operand slots: tile (wave * MTW + m) * 16 + (lane & 15), channel (lane >> 4) of a group of four
   int poff[MTW];
 #pragma unroll
@@ -573,13 +569,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
   const int b_off = lane * (2 * NT);   // ((k = lane >> 4) * 16 + (col = lane & 15)) * (2 kg * NT j)
   __syncthreads();   // tables visible
 
-  auto chunk = [&](int c0, auto first_tag) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
+  // (peeling the first chunk to skip the accumulator clear, as the raw-source kernel does, costs 23 VGPRs here: spills)
+  for (int c0 = 0; c0 < Ci; c0 += KC) {
     commit(c0);
-    WSL_WAIT_ALL();                     // this chunk's filter block has landed (its tile loads were consumed by commit)
     if (c0 + KC < Ci) issue(c0 + KC);   // flies across the whole compute phase
     __syncthreads();
-    const float* w_t = w_b + ((c0 / KC) & 1) * C::W_FLOATS;
     v4f rd[MTW][4];
     auto fetch = [&](int kg) __attribute__((always_inline)) {
 #pragma unroll
@@ -628,21 +622,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
-            const v4f cin = (FIRST && kg == 0) ? zero4 : acc[xi][m * NT + j];
-            acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi % BR][j], cin);
-          }
+          for (int j = 0; j < NT; ++j) acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi % BR][j], acc[xi][m * NT + j]);
         WSL_SCHED_BARRIER();
       }
     }
     __syncthreads();
-  };
-  if constexpr (PEEL) {
-    chunk(0, std::true_type{});
-    for (int c0 = KC; c0 < Ci; c0 += KC) chunk(c0, std::false_type{});
-  } else {
-    for (int c0 = 0; c0 < Ci; c0 += KC) chunk(c0, std::false_type{});
   }
 
   wino2_epilogue<C, TH, TW, NT>(p, acc, in_t, n, co0, y0, x0, tile_id, nb);
