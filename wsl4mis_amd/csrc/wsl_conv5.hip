@@ -26,67 +26,6 @@
 
 namespace wsl {
 
-// ---- packed forms of the Winograd input transforms.  VOP3P source selectors let one v_pk_add_f32 compute a sum AND a
-// difference of the halves of a register pair, which the compiler does not find (it emits scalar adds or pays v_mov_b32 to
-// re-pair operands), so the three patterns are spelled out; the host emulator takes the plain C path.
-__device__ __forceinline__ wsl_v2f pk_sub_swap(wsl_v2f q, wsl_v2f p) {   // (q.x - p.y, q.y - p.x)
-#ifndef WSL_HOST_EMUL
-  wsl_v2f d;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(q), "v"(p));
-  return d;
-#else
-  return wsl_v2f{q[0] - p[1], q[1] - p[0]};
-#endif
-}
-__device__ __forceinline__ wsl_v2f pk_sum_diff_hi(wsl_v2f p) {          // (p.y + p.x, p.y - p.x)
-#ifndef WSL_HOST_EMUL
-  wsl_v2f d;
-  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(p));
-  return d;
-#else
-  return wsl_v2f{p[1] + p[0], p[1] - p[0]};
-#endif
-}
-__device__ __forceinline__ wsl_v2f pk_sum_diff_lo(wsl_v2f p) {          // (p.x + p.y, p.x - p.y)
-#ifndef WSL_HOST_EMUL
-  wsl_v2f d;
-  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(p));
-  return d;
-#else
-  return wsl_v2f{p[0] + p[1], p[0] - p[1]};
-#endif
-}
-// V' = (B^T d B) diag(1, 1, 1, -1) of one 4x4 patch given as its column pairs P_i = (d[i][1], d[i][2]) (one 8-byte LDS
-// read) and Q_i = (d[i][0], d[i][3]): 8 + 8 packed instructions.  The sign of column 3 is folded into the filter image
-// (wino_filter) resp. the weight gradient's epilogue.
-// same result with scalar instructions (for the variant that has no aligned register pairs to spare)
-__device__ __forceinline__ void wino_bt_d_b_scalar(const wsl_v2f (&P)[4], const wsl_v2f (&Q)[4], float (&v)[16]) {
-  float rt[4][4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float d0 = c == 0 ? Q[0][0] : c == 3 ? Q[0][1] : P[0][c - 1], d1 = c == 0 ? Q[1][0] : c == 3 ? Q[1][1] : P[1][c - 1];
-    const float d2 = c == 0 ? Q[2][0] : c == 3 ? Q[2][1] : P[2][c - 1], d3 = c == 0 ? Q[3][0] : c == 3 ? Q[3][1] : P[3][c - 1];
-    rt[0][c] = d0 - d2, rt[1][c] = d1 + d2, rt[2][c] = d2 - d1, rt[3][c] = d1 - d3;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    v[4 * i + 0] = rt[i][0] - rt[i][2];
-    v[4 * i + 1] = rt[i][1] + rt[i][2];
-    v[4 * i + 2] = rt[i][2] - rt[i][1];
-    v[4 * i + 3] = rt[i][3] - rt[i][1];   // negated, as wino_bt_d_b
-  }
-}
-__device__ __forceinline__ void wino_bt_d_b(const wsl_v2f (&P)[4], const wsl_v2f (&Q)[4], float (&v)[16]) {
-  const wsl_v2f rP[4] = {P[0] - P[2], P[1] + P[2], P[2] - P[1], P[1] - P[3]};
-  const wsl_v2f rQ[4] = {Q[0] - Q[2], Q[1] + Q[2], Q[2] - Q[1], Q[1] - Q[3]};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const wsl_v2f a = pk_sub_swap(rQ[i], rP[i]);    // (c0 - c2, c3 - c1) = (v0, -v3)
-    const wsl_v2f b = pk_sum_diff_hi(rP[i]);        // (c2 + c1, c2 - c1) = (v1, v2)
-    v[4 * i + 0] = a[0], v[4 * i + 1] = b[0], v[4 * i + 2] = b[1], v[4 * i + 3] = a[1];
-  }
-}
-
 struct WSrc {            // one source, device view (as Src2 of wsl_conv2.hip)
   const float* x;
   const uint8_t* emask;
@@ -241,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {   // the two tiles of the pair ride in the two halves of a packed-f32 register pair
       const wsl_v2f x0 = {rt[i][0], rt[i][2]}, x1 = {rt[i][1], rt[i][3]}, x2 = {rt[i][2], rt[i][4]}, x3 = {rt[i][3], rt[i][5]};
-      const wsl_v2f o0 = x0 - x2, o1 = x1 + x2, o2 = x2 - x1, o3 = x3 - x1;   // (column 3 negated: matches the filter image)
+      const wsl_v2f o0 = x0 - x2, o1 = x1 + x2, o2 = x2 - x1, o3 = x1 - x3;
       float* vb = v_t + (4 * i) * (KC * C::TILES) + voff;
       *reinterpret_cast<float2*>(vb) = make_float2(o0[0], o0[1]);
       *reinterpret_cast<float2*>(vb + KC * C::TILES) = make_float2(o1[0], o1[1]);
@@ -635,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
     commit(c0);
     if (c0 + KC < Ci) issue(c0 + KC);   // flies across the whole compute phase
     __syncthreads();
-    wsl_v2f rp[MTW][4], rq[MTW][4];   // the 4 x 4 patch as column pairs (1, 2) and (0, 3) per row
+    v4f rd[MTW][4];
     auto fetch = [&](int kg) __attribute__((always_inline)) {
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
@@ -643,8 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
         for (int i = 0; i < 4; ++i) {
           const float* r = in_t + kg * (4 * C::PLANE) + poff[m] + i * C::ROWP;
           const float2 mm = *reinterpret_cast<const float2*>(r + 1);
-          rp[m][i] = wsl_v2f{mm.x, mm.y};
-          rq[m][i] = wsl_v2f{r[0], r[3]};
+          rd[m][i] = v4f{r[0], mm.x, mm.y, r[3]};
         }
     };
     fetch(0);
@@ -653,8 +591,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
       float v[MTW][16];
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
-        if constexpr (MTW == 1) wino_bt_d_b(rp[m], rq[m], v[m]);
-        else wino_bt_d_b_scalar(rp[m], rq[m], v[m]);   // (the 128-tile variant sits at 256 VGPRs: packed pairs would spill)
+        const v4f rt[4] = {rd[m][0] - rd[m][2], rd[m][1] + rd[m][2], rd[m][2] - rd[m][1], rd[m][1] - rd[m][3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[m][4 * i + 0] = rt[i][0] - rt[i][2];
+          v[m][4 * i + 1] = rt[i][1] + rt[i][2];
+          v[m][4 * i + 2] = rt[i][2] - rt[i][1];
+          v[m][4 * i + 3] = rt[i][1] - rt[i][3];
+        }
       }
       if (kg == 0) fetch(1);   // the second channel group's patches are read while the first group's MFMAs issue
       // B operands are requested BD transform positions ahead of their MFMAs (a position's two MFMAs take 64 cycles, an
@@ -775,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
     if (c0 + KC < Ci) issue(c0 + KC, bsel ^ 1);   // the next chunk streams into the other buffers during this one's compute
     const float* in_t = in_b + bsel * C::IN_FLOATS;
     const float* w_t = w_b + bsel * C::W_FLOATS;
-    wsl_v2f rp[MTW][4], rq[MTW][4];   // the 4 x 4 patch as column pairs (1, 2) and (0, 3) per row
+    v4f rd[MTW][4];
     auto fetch = [&](int kg) __attribute__((always_inline)) {
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
@@ -783,8 +727,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
         for (int i = 0; i < 4; ++i) {
           const float* r = in_t + kg * (4 * C::PLANE) + poff[m] + i * C::ROWP;
           const float2 mm = *reinterpret_cast<const float2*>(r + 1);
-          rp[m][i] = wsl_v2f{mm.x, mm.y};
-          rq[m][i] = wsl_v2f{r[0], r[3]};
+          rd[m][i] = v4f{r[0], mm.x, mm.y, r[3]};
         }
     };
     fetch(0);
@@ -792,7 +735,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
     for (int kg = 0; kg < 2; ++kg) {
       float v[MTW][16];
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) wino_bt_d_b(rp[m], rq[m], v[m]);
+      for (int m = 0; m < MTW; ++m) {
+        const v4f rt[4] = {rd[m][0] - rd[m][2], rd[m][1] + rd[m][2], rd[m][2] - rd[m][1], rd[m][1] - rd[m][3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[m][4 * i + 0] = rt[i][0] - rt[i][2];
+          v[m][4 * i + 1] = rt[i][1] + rt[i][2];
+          v[m][4 * i + 2] = rt[i][2] - rt[i][1];
+          v[m][4 * i + 3] = rt[i][1] - rt[i][3];
+        }
+      }
       if (kg == 0) fetch(1);
       constexpr int BD = NT == 2 ? 4 : 2, BR = BD + 1;
       float bv[BR][NT];
@@ -858,7 +810,7 @@ __device__ __forceinline__ void wino_filter(const float* w, float* u, int Co, in
     dst[(4 * r + 0) * xs] = t[r][0];
     dst[(4 * r + 1) * xs] = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]);
     dst[(4 * r + 2) * xs] = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]);
-    dst[(4 * r + 3) * xs] = -t[r][2];   // the kernels' input transform carries column 3 with the opposite sign
+    dst[(4 * r + 3) * xs] = t[r][2];
   }
 }
 
@@ -1161,8 +1113,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
   // before the MFMAs of group g issue.  Z is formed WITHOUT the two negations of A (rows/columns with index 3 carry the
   // opposite sign: Z'[p][q] = s_p s_q Z[p][q], s_3 = -1); the epilogue puts the signs back into M.
   auto compute = [&](const float* dy_t, const float* a_t) __attribute__((always_inline)) {
-    float2 rdy[NCO][2];        // [jc][row]
-    wsl_v2f rp[4], rq[4];      // the 4 x 4 input patch as column pairs (1, 2) and (0, 3) per row
+    float2 rdy[NCO][2];   // [jc][row]
+    v4f rd[4];            // the 4 x 4 input patch, one row per vector
     auto fetch = [&](int g) __attribute__((always_inline)) {
       const int tau = g * 4 + t4, tyy = tau / C::TTX, txx = tau - tyy * C::TTX;
 #pragma unroll
@@ -1175,8 +1127,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
       for (int i = 0; i < 4; ++i) {
         const float* r = ap + i * C::ROWP;
         const float2 m = *reinterpret_cast<const float2*>(r + 1);
-        rp[i] = wsl_v2f{m.x, m.y};
-        rq[i] = wsl_v2f{r[0], r[3]};
+        rd[i] = v4f{r[0], m.x, m.y, r[3]};
       }
     };
     constexpr int GN = C::GROUPS / C::NSUB;
@@ -1190,16 +1141,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
         const wsl_v2f q[4] = {r0, r0 + r1, r0 - r1, r1};   // q[3] = +dY[1] (sign folded)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const wsl_v2f sd = pk_sum_diff_lo(q[i]);          // (q.x + q.y, q.x - q.y)
           z[jc][4 * i + 0] = q[i][0];
-          z[jc][4 * i + 1] = sd[0];
-          z[jc][4 * i + 2] = sd[1];
+          z[jc][4 * i + 1] = q[i][0] + q[i][1];
+          z[jc][4 * i + 2] = q[i][0] - q[i][1];
           z[jc][4 * i + 3] = q[i][1];                       // sign folded
         }
         if (dbw) accb[jc] += z[jc][5];
       }
       float v[16];
-      wino_bt_d_b(rp, rq, v);   // column 3 carries the opposite sign (undone in the epilogue together with Z's)
+      {
+        const v4f rt[4] = {rd[0] - rd[2], rd[1] + rd[2], rd[2] - rd[1], rd[1] - rd[3]};   // packed over the 4 columns
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[4 * i + 0] = rt[i][0] - rt[i][2];
+          v[4 * i + 1] = rt[i][1] + rt[i][2];
+          v[4 * i + 2] = rt[i][2] - rt[i][1];
+          v[4 * i + 3] = rt[i][1] - rt[i][3];
+        }
+      }
       if (gi + 1 < GN) fetch(sub * GN + gi + 1);
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi)
@@ -1243,8 +1202,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
       float t[3][4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        // undo the folded signs: acc = s_p s_q t_q M with s_3 = -1 (Z) and t_3 = -1 (V) -> only row 3 is negated
-        const float m0 = acc[q][jc][r], m1 = acc[4 + q][jc][r], m2 = acc[8 + q][jc][r], m3 = -acc[12 + q][jc][r];
+        // (undo the folded signs: M[p][q] = s_p s_q M'[p][q], s_3 = -1)
+        const float sq = q == 3 ? -1.f : 1.f;
+        const float m0 = sq * acc[q][jc][r], m1 = sq * acc[4 + q][jc][r], m2 = sq * acc[8 + q][jc][r], m3 = -sq * acc[12 + q][jc][r];
         t[0][q] = m0 + 0.5f * (m1 + m2);
         t[1][q] = 0.5f * (m1 - m2);
         t[2][q] = 0.5f * (m1 + m2) + m3;
