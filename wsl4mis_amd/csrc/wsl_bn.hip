@@ -1,6 +1,8 @@
 // BatchNorm statistics / backward, 2x2 max-pool, bilinear x2 and the gradient fan-in of an encoder feature map
 // (ref: networks/unet.py:20-25 BatchNorm2d+LeakyReLU+Dropout, :38 MaxPool2d(2), :56-57 Upsample, :63-68 cat).
 // All of these are HBM-bound scans; reductions are two-stage with a fixed merge order (no atomics).
+#include <stdlib.h>
+
 #include "wsl_rt.h"
 
 namespace wsl {
@@ -186,6 +188,68 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(BnBwdP p, float* 
     float* dst = part + (((int64_t)n * p.chunks + blockIdx.x) * p.C + c) * 2;
     dst[0] = s1;
     dst[1] = s2;
+  }
+}
+
+// float4 forms of the two passes (HW % 4 == 0, 16-byte aligned tensors: every layer of the network): four elements per
+// load instruction instead of one.  Same per-element arithmetic as bn_dz().
+__device__ __forceinline__ void bn_dz4(const BnBwdP& p, int n, int c, int i, float sc, float sh, float mean, float invstd,
+                                       float (&d)[4], float (&xh)[4]) {
+  const int64_t idx = ((int64_t)n * p.C + c) * p.HW + i;
+  const float4 yv = *reinterpret_cast<const float4*>(p.y + idx);
+  const float4 gv = *reinterpret_cast<const float4*>(p.g + n * p.g_bs + (int64_t)c * p.HW + i);
+  const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+  float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+  if (p.emask) {
+    const uint32_t m = *reinterpret_cast<const uint32_t*>(p.emask + idx);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g4[k] = ((m >> (8 * k)) & 0xffu) ? g4[k] * p.es : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float z = fmaf(y4[k], sc, sh);
+    xh[k] = (y4[k] - mean) * invstd;
+    d[k] = z > 0.f ? g4[k] : WSL_LEAKY_SLOPE * g4[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_reduce4_kernel(BnBwdP p, float* part) {
+  __shared__ float red[8];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float mean = p.mean[c], invstd = p.invstd[c];
+  const float sc = p.gamma[c] * invstd, sh = fmaf(-mean, sc, p.beta[c]);
+  float s1 = 0.f, s2 = 0.f;
+  const int base = blockIdx.x * kChunk;
+  for (int i = base + 4 * threadIdx.x; i < base + kChunk && i < p.HW; i += 4 * kThreads) {
+    float d[4], xh[4];
+    bn_dz4(p, n, c, i, sc, sh, mean, invstd, d, xh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s1 += d[k];
+      s2 = fmaf(d[k], xh[k], s2);
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red + 4);
+  if (threadIdx.x == 0) {
+    float* dst = part + (((int64_t)n * p.chunks + blockIdx.x) * p.C + c) * 2;
+    dst[0] = s1;
+    dst[1] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const float* coef, float* dy) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float mean = p.mean[c], invstd = p.invstd[c];
+  const float sc = p.gamma[c] * invstd, sh = fmaf(-mean, sc, p.beta[c]);
+  const float c1 = coef[2 * c], c2 = coef[2 * c + 1];
+  const int base = blockIdx.x * kChunk;
+  for (int i = base + 4 * threadIdx.x; i < base + kChunk && i < p.HW; i += 4 * kThreads) {
+    float d[4], xh[4];
+    bn_dz4(p, n, c, i, sc, sh, mean, invstd, d, xh);
+    *reinterpret_cast<float4*>(dy + ((int64_t)n * p.C + c) * p.HW + i) =
+        make_float4(sc * (d[0] - c1 - xh[0] * c2), sc * (d[1] - c1 - xh[1] * c2), sc * (d[2] - c1 - xh[2] * c2),
+                    sc * (d[3] - c1 - xh[3] * c2));
   }
 }
 
@@ -457,10 +521,16 @@ extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const
   float* part = static_cast<float*>(ws);
   float* coef = part + (size_t)N * p.chunks * C * 2;
   dim3 grid(p.chunks, C, N);
-  WSL_LAUNCH(bnact_bwd_reduce_kernel, grid, dim3(kThreads), 0, stream, p, part);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  static const bool vec_on = !(getenv("WSL_BN_VEC") && atoi(getenv("WSL_BN_VEC")) == 0);
+  const bool vec = vec_on && (H * W) % 4 == 0 && (g_bs % 4) == 0 && al16(g) && al16(y) && al16(dy) &&
+                   (!emask || (reinterpret_cast<uintptr_t>(emask) & 3) == 0);
+  if (vec) WSL_LAUNCH(bnact_bwd_reduce4_kernel, grid, dim3(kThreads), 0, stream, p, part);
+  else WSL_LAUNCH(bnact_bwd_reduce_kernel, grid, dim3(kThreads), 0, stream, p, part);
   WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, N * p.chunks, C,
              (double)N * H * W, dgamma, dbeta, coef);
-  WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
+  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
+  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
   return check_launch("bnact_bwd");
 }
 
