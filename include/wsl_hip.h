@@ -229,8 +229,8 @@ int wsl_ustm_consistency_fwd_bwd(const float* a, const float* b, const float* pm
                                  float gscale, int N, int C, int HW, void* ws, size_t ws_bytes, void* stream);
 /* entropy_loss(p, C) = mean over pixels of -sum_c p log(p + 1e-6), divided by log(C) (ref: utils/losses.py:30-36);
  * dp = gscale * dloss/dp.  p is [N,C,HW] (already a softmax). */
-int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float gscale, int N, int C, int HW, void* ws,
-                        size_t ws_bytes, void* stream);
+int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float gscale, int N, int C, int HW, int norm_classes,
+                        void* ws, size_t ws_bytes, void* stream);
 int wsl_axpy(float* dst, const float* src, float k, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ optimiser
@@ -260,7 +260,8 @@ int wsl_augment_batch(const WslAugSample* samples, int n, float* out_img, uint8_
 
 /* Validation metric pieces (medpy.metric.binary.hd95 as called by code/val_2D.py:7-15): the surface of a binary [D,H,W]
  * volume (object minus its erosion by the 6-neighbourhood, background outside the array) and, for every point of one
- * voxel list ([n][3] int64 z,y,x -- torch.nonzero layout), the exact squared distance to the nearest point of another. */
+ * voxel list ([n][3] int64 z,y,x -- torch.nonzero layout), the exact squared distance to the nearest point of another.
+ * D == 0 denotes a 2-D [H,W] array: medpy then erodes with the 4-neighbourhood (no z test). */
 int wsl_surface_u8(const uint8_t* vol, uint8_t* border, int D, int H, int W, void* stream);
 int wsl_nearest_dist2(const int64_t* a_zyx, int na, const int64_t* b_zyx, int nb, int64_t* out, void* stream);
 

@@ -78,8 +78,8 @@ def conv_block(sd, pre, x, p, emask, training):
     y = F.conv2d(x, sd[pre + ".0.weight"], sd[pre + ".0.bias"], padding=1)
     a = _bn_act(sd, pre + ".1", y, training)
     if training and p > 0.0:
-        scale = torch.tensor(1.0 / (1.0 - p), dtype=torch.float32)
-        a = a * (emask.to(torch.float32) * scale)
+        scale = torch.tensor(1.0 / (1.0 - p), dtype=torch.float32).to(a.dtype)     # (fp64 "truth" runs: tests only)
+        a = a * (emask.to(a.dtype) * scale)
     y = F.conv2d(a, sd[pre + ".4.weight"], sd[pre + ".4.bias"], padding=1)
     return _bn_act(sd, pre + ".5", y, training)
 
@@ -164,13 +164,13 @@ def gatedcrf(y, img, radius, sigma_xy=6.0, sigma_rgb=0.1, weight=1.0):
     feature vector 0 and y=0, so it adds to sum(K) but not to the product."""
     N, C, H, W = y.shape
     r = radius
-    fx = (torch.arange(W, dtype=torch.float32) / sigma_xy).view(1, 1, 1, W).expand(N, 1, H, W)
-    fy = (torch.arange(H, dtype=torch.float32) / sigma_xy).view(1, 1, H, 1).expand(N, 1, H, W)
+    fx = (torch.arange(W, dtype=y.dtype) / sigma_xy).view(1, 1, 1, W).expand(N, 1, H, W)
+    fy = (torch.arange(H, dtype=y.dtype) / sigma_xy).view(1, 1, H, 1).expand(N, 1, H, W)
     fi = img / sigma_rgb
     feats = torch.cat([fx, fy, fi], dim=1)                 # order xy then rgb (gate_crf_loss.py:142-156)
     fp = F.pad(feats, (r, r, r, r))
     yp = F.pad(y, (r, r, r, r))
-    ksum = torch.zeros((), dtype=torch.float32)
+    ksum = torch.zeros((), dtype=y.dtype)
     msg = torch.zeros_like(y)
     for dy in range(-r, r + 1):
         for dx in range(-r, r + 1):

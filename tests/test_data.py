@@ -67,6 +67,20 @@ def test_random_generator_draw_order_and_pixels(mode):
     assert tuple(one["image"].shape) == (1, 32, 32) and one["label"].dtype == torch.uint8
 
 
+def test_more_samples_than_one_descriptor_table(mode):
+    """the headline batch (64 slices) and beyond: the launch is chunked so the by-value descriptor table stays < 4 KB"""
+    from wsl4mis_amd.dataloaders import dataset
+    rng = np.random.default_rng(29)
+    n = 70
+    samples = make_samples(rng, n, sizes=[(int(rng.integers(20, 40)), int(rng.integers(20, 40))) for _ in range(n)])
+    params = [[{"op": 0}, {"op": 1, "k": i % 4, "axis": i % 2}, {"op": 2, "angle": (i * 7) % 41 - 20, "lab_cval": 4}][i % 3]
+              for i in range(n)]
+    img, lab = dataset.augment_batch([s["image"] for s in samples], [s["label"] for s in samples], params, (32, 32))
+    for i, (s, p) in enumerate(zip(samples, params)):
+        ri, rl = data_ref.apply(s["image"], s["label"], p, (32, 32))
+        assert np.array_equal(img[i].cpu().numpy(), ri) and np.array_equal(lab[i].cpu().numpy(), rl), (i, p)
+
+
 def test_bad_input_raises(mode):
     from wsl4mis_amd.dataloaders import dataset
     with pytest.raises(ValueError):
@@ -101,6 +115,14 @@ def test_validation_metrics_match_the_medpy_algorithm(mode):
         checked += 1
     assert checked >= 3
     assert val_2D.metric_percase(np.zeros((3, 8, 8), bool), np.ones((3, 8, 8), bool)) == (0, 0)
+    # 2-D masks: medpy erodes with the 4-neighbourhood there (a [1,H,W] volume is all surface instead)
+    gt2, pred2 = blobs(rng, (1, 48, 40), 3)[0], blobs(rng, (1, 48, 40), 3)[0]
+    assert gt2.any() and pred2.any()
+    d_ref, h_ref = metrics_ref.calculate_metric_percase(pred2, gt2)
+    d, h = val_2D.metric_percase(pred2, gt2)
+    assert d == d_ref and abs(h - h_ref) <= 1e-12 * max(1.0, h_ref), (h, h_ref)
+    h3 = metrics_ref.calculate_metric_percase(pred2[None], gt2[None])[1]
+    assert abs(val_2D.metric_percase(pred2[None], gt2[None])[1] - h3) <= 1e-12 * max(1.0, h3)
     with pytest.raises(RuntimeError, match="second supplied array"):
         val_2D.metric_percase(np.ones((2, 8, 8), bool), np.zeros((2, 8, 8), bool))
 
@@ -182,6 +204,52 @@ def test_example_trainer_runs_on_the_fixture_files(tmp_path):
                       "--batch_size", "3", "--patch_size", "64", "64", "--val_every", "50",
                       "--resume", os.path.join(str(tmp_path), "iter_40.pth")])
     assert hist2[0][1] < hist[0][1]                                    # starts from the trained weights, not from scratch
+
+
+@pytest.mark.gpu
+def test_validation_label_maps_on_the_acdc_volume(tmp_path):
+    """SURVEY 8f rank 1 on real data: a briefly trained unet_cct (150 steps at 256 x 256 on the committed ACDC scribble
+    slices) segments the committed ACDC volume through val_2D's per-slice loop (zoom -> eval forward -> argmax -> zoom back);
+    the label maps must equal the oracle's eval forward of the same checkpoint (code/val_2D.py:90-124) -- near-tie pixels
+    are counted and reported, the allowance is in pixels."""
+    import importlib.util
+    from scipy.ndimage import zoom
+    from conftest import labelmap_mismatch
+    from oracle import torch_ref as R
+    from wsl4mis_amd import _lib, runtime, val_2D
+    from wsl4mis_amd.dataloaders import dataset
+    from wsl4mis_amd.networks.net_factory import net_factory
+    _lib._reset_for_tests()
+    runtime._ws_cache.clear()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_acdc", os.path.join(root, "examples", "train_acdc_scribble.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["--root_path", ACDC, "--fold", "fold3", "--labeled_type", "unlabeled", "--max_iterations", "150", "--batch_size", "2",
+              "--val_every", "1000", "--snapshot_path", str(tmp_path), "--save_every", "150"])
+    sd = torch.load(os.path.join(str(tmp_path), "iter_150.pth"), map_location="cpu")
+    model = net_factory("unet_cct", 1, 4)
+    model.load_state_dict(sd)
+    v = dataset.BaseDataSets(base_dir=ACDC, split="val", fold="fold3")[0]
+    vol, lab = v["image"], v["label"]
+    P = (256, 256)
+    pred = val_2D._predict_volume(vol, model, P, first_output=True)
+    assert len(np.unique(pred)) >= 2                                   # trained enough to segment something
+    ref = np.zeros_like(pred)
+    sdc = {k: t.clone() for k, t in sd.items()}
+    for i in range(vol.shape[0]):
+        h, w = vol[i].shape
+        inp = torch.from_numpy(zoom(vol[i], (P[0] / h, P[1] / w), order=0).astype(np.float32))[None, None]
+        with torch.no_grad():
+            z = R.net_forward(sdc, inp, "unet_cct", None, [torch.ones(1, 16 << l) for l in range(5)], False)[0]
+        ref[i] = zoom(torch.argmax(z, 1)[0].numpy().astype(np.uint8), (h / P[0], w / P[1]), order=0)
+    labelmap_mismatch("val_2D label maps, ACDC patient041_frame11 (6 x 224 x 154)", pred, ref, allow_px=4)
+    got = val_2D.test_single_volume_cct(torch.from_numpy(vol)[None], torch.from_numpy(lab)[None], model, classes=4, patch_size=P)
+    from oracle import metrics_ref
+    for c, (d, hd) in enumerate(got, start=1):
+        d_ref, h_ref = metrics_ref.calculate_metric_percase(ref == c, lab == c)
+        if np.array_equal(pred == c, ref == c):
+            assert d == d_ref and abs(hd - h_ref) <= 1e-12 * max(1.0, h_ref)
 
 
 def test_two_stream_batch_sampler_matches_the_reference_semantics():

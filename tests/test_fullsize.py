@@ -1,5 +1,5 @@
-"""BASELINE.json's full problem size (unet_cct, 64 slices of 256x256 per GPU) cannot be checked against a CPU oracle in
-test time, so the full-size runs are pinned through size-independent properties of the path:
+"""BASELINE.json's full problem size (unet_cct, 64 slices of 256x256 per GPU): size-independent properties of the path
+(the direct comparisons with the oracle at this size -- fp32 and fp64 -- live in tests/test_error_budget.py):
   * per-sample independence of the eval forward (a batch equals its halves, bit for bit),
   * linearity of the backward in the logit gradients,
   * linearity of the GatedCRF message in y, the loss head's closed forms (uniform logits -> ln 4, valid-pixel count),
@@ -113,64 +113,3 @@ def test_whole_step_is_bit_reproducible(setup):
     l2, p2 = run({})
     assert l1 == l2 and torch.equal(p1, p2)
     assert all(math.isfinite(v) for v in l1.values())
-
-
-def test_full_batch_step_matches_the_oracle():
-    """One ours_proposed step at the benchmark size (64 x 256x256, unet_cct -- the launches that pick the 32/64-channel
-    blocks) against the oracle's torch-CPU restatement run on this box's host cores with the same masks: logits and
-    losses to 1e-4; gradients in the L2 sense (4.2 M pixels x hundreds of channels always hold pre-activations within
-    fp32 noise of a LeakyReLU / max-pool kink, so element-wise gradient parity is undefined at this size for ANY two fp32
-    implementations -- see DESIGN 3)."""
-    from oracle import torch_ref as R
-    from wsl4mis_amd import _lib, runtime
-    from wsl4mis_amd.networks.net_factory import net_factory
-    from wsl4mis_amd.synthetic import batch
-    _lib._reset_for_tests()
-    runtime._ws_cache.clear()
-    dev = torch.device("cuda", 0)
-    torch.manual_seed(2022)
-    model = net_factory("unet_cct", 1, 4)
-    x, lab = batch(N, S, S, 2022, dev)
-    gen = torch.Generator().manual_seed(3)
-    em = [(torch.rand((N, 16 << l, S >> l, S >> l), generator=gen) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
-    cm = [(torch.rand((N, 16 << l), generator=gen) >= 0.5).float() * 2.0 for l in range(5)]
-    model.train()
-    model.set_dropout_masks([m.to(dev) for m in em], [c.to(dev) for c in cm])
-    z1, z2 = model._run_forward(x, keep_for_backward=True)
-    # the fused head as the engine calls it: losses and both dlogits in one pass
-    t1, t2 = torch.empty_like(z1), torch.empty_like(z2)
-    nl = runtime.L().wsl_loss_ws_bytes(N, 4, S * S)
-    lws = runtime.workspace("loss", nl)
-    out = torch.zeros(8, device=dev)
-    runtime.call("wsl_head_fwd_bwd", runtime.ptr(z1), runtime.ptr(z2), runtime.ptr(lab), 4, 0.37, 0.5, 1.0, runtime.ptr(out), None,
-                 runtime.ptr(t1), runtime.ptr(t2), N, 4, S * S, runtime.ptr(lws), nl, runtime.stream())
-    model._run_backward(x, [t1, t2], phase=0)
-    got = model.flat_grads().cpu().numpy()
-    o = out.cpu().numpy()
-    # ---- oracle on the host cores
-    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    pk = [k for k in sd if R.is_param(k)]
-    for k in pk:
-        sd[k].requires_grad_(True)
-    outs = R.net_forward(sd, x.cpu(), "unet_cct", em, cm, True)
-    rl, rce, rpse, _ = R.ours_proposed_loss(outs[0], outs[1], lab.cpu(), 0.37)
-    assert float((z1.cpu() - outs[0].detach()).abs().max()) <= 1e-4 * float(outs[0].detach().abs().max())
-    assert float((z2.cpu() - outs[1].detach()).abs().max()) <= 1e-4 * float(outs[1].detach().abs().max())
-    assert abs(o[0] - rl.item()) <= 1e-4 * abs(rl.item()) and abs(o[1] - rce.item()) <= 1e-4 * abs(rce.item())
-    rl.backward()
-    ref = np.concatenate([sd[k].grad.numpy().ravel() for k in pk])
-    assert ref.size == got.size
-    l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
-    off, worst = 0, []
-    for k in pk:                                   # no single tensor may hide behind the global norm
-        n = sd[k].numel()
-        r, g = ref[off:off + n], got[off:off + n]
-        off += n
-        if np.linalg.norm(r) > 1e-6 and not (k.endswith(".bias") and (".0." in k or ".4." in k)):   # (conv biases under BN: fp32 noise)
-            worst.append((float(np.linalg.norm(g - r) / np.linalg.norm(r)), k))
-    worst.sort(reverse=True)
-    print("worst per-tensor gradient deviations:", [(f"{v:.1e}", k) for v, k in worst[:4]])
-    assert worst[0][0] < 3e-2, worst[:4]
-    print(f"full-size step vs oracle: loss {o[0]:.6f} / {rl.item():.6f}, gradient L2 deviation {l2:.2e}")
-    assert l2 < 5e-3, l2
-    model.set_dropout_masks(None, None)

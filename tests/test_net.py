@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import golden, grad_tol, rel_err
+from conftest import close, golden, grad_tol, labelmap_mismatch, mixed_err, rel_err
 from netutil import check_grads, det_arenas, grad_l2, net_desc, ptr_array, strict_grads
 
 TOL = 1e-4
@@ -27,9 +27,9 @@ def run_net(be, tag, net, full=True):
     la = be.zeros((N, 4, H, W)) if cm else None
     be.call("wsl_net_forward", C.byref(d), be.ptr(dp), be.ptr(db), be.ptr(dn), be.ptr(x), pem, pcm, 1, be.ptr(lm),
             be.ptr(la) if cm else None, be.ptr(ws), nws, be.stream)
-    assert rel_err(be.np(lm), g["logits_main"]) < TOL
+    assert close(be.np(lm), g["logits_main"], TOL), (rel_err(be.np(lm), g["logits_main"]), mixed_err(be.np(lm), g["logits_main"]))
     if cm:
-        assert rel_err(be.np(la), g["logits_aux"]) < TOL
+        assert close(be.np(la), g["logits_aux"], TOL), (rel_err(be.np(la), g["logits_aux"]), mixed_err(be.np(la), g["logits_aux"]))
     # loss head
     out, pseudo = be.zeros((4,)), be.zeros((N, H, W), np.int64)
     dz1, dz2 = be.zeros((N, 4, H, W)), be.zeros((N, 4, H, W))
@@ -42,7 +42,7 @@ def run_net(be, tag, net, full=True):
     assert rel_err(o[0], g["loss_parts"][0]) < TOL
     if cm:
         assert rel_err(o[1:3], g["loss_parts"][1:3]) < TOL
-        assert np.mean(be.np(pseudo) != g["pseudo"]) <= 1e-3
+        labelmap_mismatch(f"test_net {tag} pseudo-label map ({be.name})", be.np(pseudo), g["pseudo"], allow_px=2)
     grads = be.zeros(params.shape)
     be.call("wsl_net_backward", C.byref(d), be.ptr(dp), be.ptr(x), pem, pcm, be.ptr(dz1), be.ptr(dz2) if cm else None,
             be.ptr(grads), be.ptr(ws), nws, 0, be.stream)

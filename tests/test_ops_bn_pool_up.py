@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import golden, rel_err
+from conftest import close, golden, rel_err
 
 TOL = 1e-4
 
@@ -35,9 +35,9 @@ def test_bnact_bwd(be, shape, drop):
     ws = be.ws(nws)
     be.call("wsl_bnact_bwd", be.ptr(d[0]), C * H * W, *[be.ptr(a) for a in d[1:]], be.ptr(dm) if drop else None, es,
             be.ptr(dy), be.ptr(dgam), be.ptr(dbet), N, C, H, W, be.ptr(ws), nws, be.stream)
-    assert rel_err(be.np(dy), yt.grad.numpy()) < TOL
-    assert rel_err(be.np(dgam), gt.grad.numpy()) < TOL
-    assert rel_err(be.np(dbet), bt.grad.numpy()) < TOL
+    assert close(be.np(dy), yt.grad.numpy(), TOL)
+    assert close(be.np(dgam), gt.grad.numpy(), TOL)
+    assert close(be.np(dbet), bt.grad.numpy(), TOL)
 
 
 def test_pool_and_routing_golden(be):

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import close, rel_err
 
 TOL = 1e-4
 
@@ -110,7 +110,7 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
     part, cnt = be.zeros((nblk, Co, 2)), be.zeros((nblk,))
     be.call("wsl_conv2d_fwd", sa, sb, be.ptr(d["w"]), be.ptr(d["bias"]), be.ptr(y), Co * H * W, N, H, W, Co, ks, 0,
             be.ptr(part), be.ptr(cnt), be.stream)
-    assert rel_err(be.np(y), y_ref.detach().numpy()) < TOL
+    assert close(be.np(y), y_ref.detach().numpy(), TOL)
     # ---- packed fast path (aligned float4 staging + register prefetch), same outputs incl. the statistics
     fast = bool(be.lib.wsl_conv2d_fast_ok(sa, sb, be.ptr(y), Co * H * W, W))
     assert fast == (W % 4 == 0 and (Cb == 0 or Ca % 4 == 0))
@@ -120,14 +120,14 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
         be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(wp), Co, Ci, ks, 0, be.stream)
         be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), be.ptr(d["bias"]), be.ptr(y2), Co * H * W, N, H, W, Co, ks, 2,
                 be.ptr(part2), be.ptr(cnt2), be.stream)
-        assert rel_err(be.np(y2), y_ref.detach().numpy()) < TOL
+        assert close(be.np(y2), y_ref.detach().numpy(), TOL)
         assert float(be.np(cnt2).sum()) == N * H * W     # per-wave partials: the counts tile the tensor exactly
         # without statistics (how the network calls a layer that no BatchNorm follows): 16 -> 4 classifiers with full
         # 8x64 tiles take the 4x4x1-MFMA kernel of wsl_conv4.hip
         y3 = be.zeros((N, Co, H, W))
         be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), be.ptr(d["bias"]), be.ptr(y3), Co * H * W, N, H, W, Co, ks, 2,
                 None, None, be.stream)
-        assert rel_err(be.np(y3), y_ref.detach().numpy()) < TOL
+        assert close(be.np(y3), y_ref.detach().numpy(), TOL)
     # ---- Winograd F(2x2, 3x3) path for the layers it fits: same outputs and statistics
     def wino_shape(Ca_, Cb_, Co_):
         return (ks == 3 and (Ca_ + Cb_) % 8 == 0 and Ca_ + Cb_ <= 256 and (Cb_ == 0 or Ca_ % 8 == 0) and Co_ % 16 == 0
@@ -140,7 +140,7 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
         be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(u), Co, Ci, ks, 2, be.stream)
         be.call("wsl_conv2d_fwd", sa, sb, be.ptr(u), be.ptr(d["bias"]), be.ptr(y4), Co * H * W, N, H, W, Co, ks, 4,
                 be.ptr(part4), be.ptr(cnt4), be.stream)
-        assert rel_err(be.np(y4), y_ref.detach().numpy()) < TOL
+        assert close(be.np(y4), y_ref.detach().numpy(), TOL)
         assert rel_err(be.np(y4), be.np(y2)) < 1e-5                     # vs the direct MFMA kernel: fp32 round-off only
         assert float(be.np(cnt4).sum()) == N * H * W
         mean4, invstd4, sc4, sh4 = (be.zeros((Co,)) for _ in range(4))
@@ -152,7 +152,7 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
         assert rel_err(be.np(invstd4), (1 / torch.sqrt(yr4.var((0, 2, 3), unbiased=False) + 1e-5)).numpy()) < 1e-5
         y5 = be.zeros((N, Co, H, W))                                     # without statistics / bias
         be.call("wsl_conv2d_fwd", sa, sb, be.ptr(u), None, be.ptr(y5), Co * H * W, N, H, W, Co, ks, 4, None, None, be.stream)
-        assert rel_err(be.np(y5), (y_ref.detach() - torch.from_numpy(bias)[None, :, None, None]).numpy()) < TOL
+        assert close(be.np(y5), (y_ref.detach() - torch.from_numpy(bias)[None, :, None, None]).numpy(), TOL)
     elif fast and ks == 3:
         with pytest.raises(Exception, match="wino_ok"):
             be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), None, be.ptr(y2), Co * H * W, N, H, W, Co, ks, 4, None, None, be.stream)
@@ -182,20 +182,20 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
     sr = be.src(d["r"], Co)
     be.call("wsl_conv2d_fwd", sr, be.src(), be.ptr(d["w"]), None, be.ptr(dx), Ci * H * W, N, H, W, Ci, ks, 1, None, None,
             be.stream)
-    assert rel_err(be.np(dx), vin.grad.numpy()) < TOL
+    assert close(be.np(dx), vin.grad.numpy(), TOL)
     if bool(be.lib.wsl_conv2d_fast_ok(sr, be.src(), be.ptr(dx), Ci * H * W, W)):
         wpd, dx2 = be.zeros((ks * ks, Co, Ci)), be.zeros((N, Ci, H, W))
         be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(wpd), Ci, Co, ks, 1, be.stream)
         be.call("wsl_conv2d_fwd", sr, be.src(), be.ptr(wpd), None, be.ptr(dx2), Ci * H * W, N, H, W, Ci, ks, 3, None, None,
                 be.stream)
-        assert rel_err(be.np(dx2), vin.grad.numpy()) < TOL
+        assert close(be.np(dx2), vin.grad.numpy(), TOL)
         if bool(be.lib.wsl_conv2d_wino_ok(N, H, W, Co, 0, Ci, ks)):
             assert variant == 2 and wino_shape(Co, 0, Ci)
             ud, dx4 = be.zeros((16, Co, Ci)), be.zeros((N, Ci, H, W))
             be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(ud), Ci, Co, ks, 3, be.stream)
             be.call("wsl_conv2d_fwd", sr, be.src(), be.ptr(ud), None, be.ptr(dx4), Ci * H * W, N, H, W, Ci, ks, 5, None, None,
                     be.stream)
-            assert rel_err(be.np(dx4), vin.grad.numpy()) < TOL
+            assert close(be.np(dx4), vin.grad.numpy(), TOL)
         else:
             assert not (variant == 2 and wino_shape(Co, 0, Ci))
     # ---- weight / bias gradient
@@ -203,8 +203,8 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
     ws, dw, db = be.ws(nws), be.zeros((Co, Ci, ks, ks)), be.zeros((Co,))
     be.call("wsl_conv2d_wgrad", sa, sb, be.ptr(d["r"]), Co * H * W, be.ptr(dw), be.ptr(db), N, H, W, Co, ks, be.ptr(ws),
             nws, be.stream)
-    assert rel_err(be.np(dw), wt.grad.numpy()) < TOL
-    assert rel_err(be.np(db), bt.grad.numpy()) < TOL
+    assert close(be.np(dw), wt.grad.numpy(), TOL)
+    assert close(be.np(db), bt.grad.numpy(), TOL)
 
 
 def test_conv_channel_slice_views(be):
@@ -221,7 +221,7 @@ def test_conv_channel_slice_views(be):
     be.call("wsl_conv2d_fwd", s, be.src(), be.ptr(dw_), None, be.ptr(out) + 2 * H * W * 4, 9 * H * W, N, H, W, 6, 3, 0,
             None, None, be.stream)
     o = be.np(out)
-    assert rel_err(o[:, 2:8], y_ref) < TOL
+    assert close(o[:, 2:8], y_ref, TOL)
     assert np.all(o[:, :2] == 0) and np.all(o[:, 8:] == 0)
 
 
@@ -268,7 +268,7 @@ def test_every_lean_conv_instantiation(be, plan, ks):
         be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(wp), Co, Ca + Cb, ks, 0, be.stream)
         be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), be.ptr(d["bias"]), be.ptr(y), Co * H * W, N, H, W, Co, ks, 2,
                 be.ptr(part), be.ptr(cnt), be.stream)
-        assert rel_err(be.np(y), y_ref.detach().numpy()) < TOL
+        assert close(be.np(y), y_ref.detach().numpy(), TOL)
         p = be.np(part)
         assert rel_err(p[:, :, 0].sum(1), y_ref.detach().sum((0, 2, 3)).numpy()) < 1e-5
         # data gradient: dL/d(vin) = conv(r, w rotated), output channels = Ca + Cb = 24 -> blocks of 8 would not divide:
@@ -282,6 +282,6 @@ def test_every_lean_conv_instantiation(be, plan, ks):
         be.call("wsl_conv2d_pack_weights", be.ptr(dw2), be.ptr(wd), 64, 64, ks, 1, be.stream)
         be.call("wsl_conv2d_fwd", be.src(d["r"], 64), be.src(), be.ptr(wd), None, be.ptr(dx), 64 * H * W, N, H, W, 64, ks, 3,
                 None, None, be.stream)
-        assert rel_err(be.np(dx), ref2.detach().numpy()) < TOL
+        assert close(be.np(dx), ref2.detach().numpy(), TOL)
     finally:
         be.call("wsl_debug_conv_plan", 0, 0, 0)

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden, rel_err
+from conftest import close, golden, labelmap_mismatch, rel_err
 
 TOL = 1e-4
 
@@ -28,9 +28,8 @@ def test_fused_head_golden(be, tag):
     assert rel_err(o[2], g[f"{tag}_loss_pse"]) < 1e-5 and o[3] == np.sum(lab != 4)
     # label map: bit-exact given identical softmax inputs is pinned by test_mix_argmax_bit_exact; here the softmax is
     # the kernel's own (expf rounding differs from torch's CPU vector exp), so report the mismatch rate instead
-    mism = np.mean(be.np(pseudo) != g[f"{tag}_pseudo"])
-    assert mism <= 1e-3, mism
-    assert rel_err(be.np(dz1), g[f"{tag}_dz1"]) < TOL and rel_err(be.np(dz2), g[f"{tag}_dz2"]) < TOL
+    labelmap_mismatch(f"test_ops_loss head {tag} pseudo-label map ({be.name})", be.np(pseudo), g[f"{tag}_pseudo"], allow_px=2)
+    assert close(be.np(dz1), g[f"{tag}_dz1"], TOL) and close(be.np(dz2), g[f"{tag}_dz2"], TOL)
 
 
 def test_mix_argmax_bit_exact(be):
@@ -52,7 +51,7 @@ def test_softmax_ce_golden(be):
     ws, n = lws(be, N, C, H * W)
     be.call("wsl_ce_fwd_bwd", be.ptr(dz_), be.ptr(dl), 0, 4, be.ptr(loss), be.ptr(dz), 1.0, N, C, H * W, be.ptr(ws), n,
             be.stream)
-    assert rel_err(be.np(loss)[0], g["ce_loss"]) < 1e-5 and rel_err(be.np(dz), g["ce_dz"]) < TOL
+    assert rel_err(be.np(loss)[0], g["ce_loss"]) < 1e-5 and close(be.np(dz), g["ce_dz"], TOL)
     l64 = be.arr(lab.astype(np.int64))            # int64 labels (.long() in the trainers)
     be.call("wsl_ce_fwd_bwd", be.ptr(dz_), be.ptr(l64), 1, 4, be.ptr(loss), None, 1.0, N, C, H * W, be.ptr(ws), n, be.stream)
     assert rel_err(be.np(loss)[0], g["ce_loss"]) < 1e-5
@@ -84,7 +83,7 @@ def test_pdice_golden(be, pre, ignore):
             be.stream)
     be.call("wsl_pdice_bwd", be.ptr(ds_), be.ptr(dt), 1, ignore, be.ptr(sums), None, be.ptr(ds), N, C, H * W, be.stream)
     assert rel_err(be.np(loss)[0], g[f"{pre}_loss"]) < 1e-5
-    assert rel_err(be.np(ds), g[f"{pre}_ds"]) < TOL
+    assert close(be.np(ds), g[f"{pre}_ds"], TOL)
 
 
 @pytest.mark.parametrize("tag", ["r5", "r2", "ns5", "ns2", "r1", "alt"])
@@ -99,8 +98,8 @@ def test_gatedcrf_golden(be, tag):
     be.call("wsl_gatedcrf_fwd", be.ptr(dy_), be.ptr(di), be.ptr(msg), be.ptr(loss), N, C, H, W, r, sxy, srgb, w,
             be.ptr(ws), n, be.stream)
     be.call("wsl_gatedcrf_bwd", be.ptr(msg), None, 1.0, be.ptr(dy), N, C, H, W, be.stream)
-    assert rel_err(be.np(loss)[0], g[f"{tag}_loss"]) < TOL
-    assert rel_err(be.np(dy), g[f"{tag}_dy"]) < TOL
+    assert close(be.np(loss)[0], g[f"{tag}_loss"], TOL)
+    assert close(be.np(dy), g[f"{tag}_dy"], TOL)
 
 
 def test_gatedcrf_unsupported_radius(be):
@@ -129,7 +128,7 @@ def test_tv_ms_mse_golden(be):
     ws, n = lws(be, N, C, H * W)
     be.call("wsl_mumford_shah_fwd_bwd", be.ptr(di), be.ptr(dp_), be.ptr(loss), be.ptr(dp), 1.0, N, C, H, W, be.ptr(ws), n,
             be.stream)
-    assert rel_err(be.np(loss)[0], g["ms_loss"]) < 1e-5 and rel_err(be.np(dp), g["ms_dp"]) < TOL
+    assert rel_err(be.np(loss)[0], g["ms_loss"]) < 1e-5 and close(be.np(dp), g["ms_dp"], TOL)
     g = golden("g3_head")
     a, b = g["mse_a"], g["mse_b"]
     N, C, H, W = a.shape
@@ -138,7 +137,7 @@ def test_tv_ms_mse_golden(be):
     ws, n = lws(be, N, C, H * W)
     be.call("wsl_softmax_mse_fwd_bwd", be.ptr(da_), be.ptr(db_), be.ptr(loss), be.ptr(da), 1.0, N, C, H * W, be.ptr(ws), n,
             be.stream)
-    assert rel_err(be.np(loss)[0], g["mse_loss"]) < 1e-5 and rel_err(be.np(da), g["mse_da"]) < TOL
+    assert rel_err(be.np(loss)[0], g["mse_loss"]) < 1e-5 and close(be.np(da), g["mse_da"], TOL)
 
 
 def test_sgd_ema_golden(be):

@@ -252,8 +252,69 @@ def test_entropy_loss_kernel(mode):
     (2.0 * got).backward()
     assert abs(got.item() - ref.item()) < 1e-6
     assert rel_err(p.grad.cpu().numpy(), 2.0 * p_ref.grad.numpy()) < 1e-5
+    # C is only the log(C) normaliser (losses.py:30-33): the reference's default C=2 works on a 4-class softmax too
+    p2 = p_ref.detach().clone().to(dev()).requires_grad_()
+    got2 = losses.entropy_loss(p2)
+    got2.backward()
+    assert abs(got2.item() - ref.item() * math.log(4) / math.log(2)) < 1e-6
+    assert rel_err(p2.grad.cpu().numpy(), p_ref.grad.numpy() * math.log(4) / math.log(2)) < 1e-5
     with pytest.raises(ValueError):
-        losses.entropy_loss(p, C=2)
+        losses.entropy_loss(p, C=1)
+
+
+def test_autograd_accumulation_and_interleaved_forwards(mode):
+    """p.grad must be autograd's own memory, not a view of the arena the next backward overwrites: two backward passes
+    accumulate g_a + g_b, zero_grad(set_to_none=False) works, and a no_grad / eval forward between a training forward and
+    its backward must not redraw the dropout masks the backward replays."""
+    from wsl4mis_amd.networks.net_factory import net_factory
+    from wsl4mis_amd.utils import losses
+    torch.manual_seed(3)
+    model = net_factory("unet", 1, 4)
+    model.train()
+    S = 16
+    xa, xb = torch.rand(2, 1, S, S).to(dev()), torch.rand(2, 1, S, S).to(dev())
+    lab = torch.randint(0, 5, (2, S, S), dtype=torch.uint8).to(dev())
+    ce = losses.PartialCrossEntropyLoss(ignore_index=4)
+    gen = torch.Generator().manual_seed(8)
+    em = [(torch.rand((2, 16 << l, S >> l, S >> l), generator=gen) >= 0.3).to(torch.uint8).to(dev()) for l in range(5)]
+    model.set_dropout_masks(em, None)
+
+    def grads_of(x, zero):
+        if zero == "none":
+            model.zero_grad(set_to_none=True)
+        elif zero == "inplace":
+            model.zero_grad(set_to_none=False)
+        ce(model(x), lab.long()).backward()
+        return torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+
+    ga, gb = grads_of(xa, "none"), grads_of(xb, "none")
+    gab = grads_of(xa, "keep")                                 # p.grad holds g_b: accumulate g_a on top
+    scale = float((ga + gb).abs().max())
+    assert float((gab - (ga + gb)).abs().max()) <= 1e-6 * scale
+    assert float((grads_of(xb, "inplace") - gb).abs().max()) <= 1e-6 * scale      # not 2 * g_b
+    model = net_factory("unet_cct", 1, 4)
+    model.train()
+    # interleaved forwards: drawn masks this time
+    model.set_dropout_masks(None, None)
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(11)
+    z1, z2 = model(xa)
+    saved = [t.clone() for t in model._saved[3]] + [t.clone() for t in model._saved[4]]
+    with torch.no_grad():
+        model(xb)                                              # train-mode forward without grad: must use other buffers
+    model.eval()
+    with torch.no_grad():
+        model(xb)                                              # eval forward of unet_cct still draws the aux dropout2d masks
+    model.train()
+    assert all(torch.equal(a, b) for a, b in zip(saved, list(model._saved[3]) + list(model._saved[4])))
+    (ce(z1, lab.long()) + 0.5 * ce(z2, lab.long())).backward()
+    g1 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.set_dropout_masks(saved[:5], saved[5:])              # the same step without the interleaved forwards
+    model.zero_grad(set_to_none=True)
+    z1, z2 = model(xa)
+    (ce(z1, lab.long()) + 0.5 * ce(z2, lab.long())).backward()
+    g2 = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert float((g1 - g2).abs().max()) <= 1e-6 * float(g2.abs().max())
 
 
 def test_engine_loss_curve_start(mode):
@@ -397,14 +458,14 @@ def test_validation_volume_label_maps(mode):
     sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in det_state(
         {k: tuple(v.shape) for k, v in m.state_dict().items()}, 5).items()}
     pred = val_2D._predict_volume(vol, m, P, first_output=True)
-    mism = 0
+    ref = np.zeros_like(pred)
     for i in range(D):
         inp = torch.from_numpy(zoom(vol[i], (P[0] / H, P[1] / W), order=0))[None, None]
         with torch.no_grad():
             z = R.net_forward(sd, inp, "unet_cct", None, [torch.ones(1, 16 << l) for l in range(5)], False)[0]
-        ref = zoom(torch.argmax(z, 1)[0].numpy().astype(np.uint8), (H / P[0], W / P[1]), order=0)
-        mism += int((ref != pred[i]).sum())
-    assert mism <= 0.01 * pred.size, mism
+        ref[i] = zoom(torch.argmax(z, 1)[0].numpy().astype(np.uint8), (H / P[0], W / P[1]), order=0)
+    from conftest import labelmap_mismatch
+    labelmap_mismatch(f"val_2D label maps, synthetic 2 x 20 x 24 volume ({mode})", pred, ref, allow_px=2)
     assert val_2D.dice_percase(np.array([1, 1, 0]), np.array([1, 0, 0])) == pytest.approx(2 / 3)
     with pytest.raises(NotImplementedError):
         val_2D.test_single_volume(torch.from_numpy(vol[0]), torch.from_numpy(lab[0]), m, 4)

@@ -98,7 +98,7 @@ _PROTOS = {
     "wsl_rot90": (i32, [c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "wsl_softmax_accum": (i32, [c_fp, c_fp, f32, i32, i32, i32, i32, c_fp]),
     "wsl_ustm_consistency_fwd_bwd": (i32, [c_fp, c_fp, c_fp, f32, c_fp, c_fp, f32, i32, i32, i32, c_fp, sz, c_fp]),
-    "wsl_entropy_fwd_bwd": (i32, [c_fp, c_fp, c_fp, f32, i32, i32, i32, c_fp, sz, c_fp]),
+    "wsl_entropy_fwd_bwd": (i32, [c_fp, c_fp, c_fp, f32, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_axpy": (i32, [c_fp, c_fp, f32, i64, c_fp]),
     "wsl_sgd_step": (i32, [c_fp, c_fp, c_fp, i64, f32, f32, f32, i32, f32, c_fp, f32, c_fp]),
     "wsl_surface_u8": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),

@@ -12,7 +12,7 @@
 
 namespace wsl {
 
-constexpr int kAugMax = 64;   // samples per launch (descriptor table travels as a kernel argument)
+constexpr int kAugMax = 32;   // samples per launch: the descriptor table travels as a kernel argument (32 * 96 + 8 B < 4 KB)
 struct AugTable {
   int n;
   WslAugSample s[kAugMax];
@@ -63,14 +63,18 @@ __global__ __launch_bounds__(256) void augment_kernel(AugTable t, float* out_img
 // ---- validation metric: the two device pieces of medpy.metric.binary.hd95
 // surface of a binary volume = the object minus its erosion by the 6-neighbourhood with a background border
 // (scipy.ndimage.binary_erosion(structure=generate_binary_structure(3, 1), border_value=0))
+// D == 0: a 2-D [H,W] array, for which medpy's structure is the 4-neighbourhood (generate_binary_structure(2, 1)) -- not the
+// same as a [1,H,W] volume, every voxel of which touches the background border along z.
 __global__ __launch_bounds__(256) void surface_kernel(const uint8_t* vol, uint8_t* border, int D, int H, int W) {
+  const bool flat = D == 0;
+  if (flat) D = 1;
   const int64_t n = (int64_t)D * H * W;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
     const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((int64_t)W * H));
     uint8_t b = 0;
     if (vol[i]) {
-      const bool inner = z > 0 && z < D - 1 && y > 0 && y < H - 1 && x > 0 && x < W - 1 && vol[i - 1] && vol[i + 1] &&
-                         vol[i - W] && vol[i + W] && vol[i - (int64_t)W * H] && vol[i + (int64_t)W * H];
+      const bool inner = y > 0 && y < H - 1 && x > 0 && x < W - 1 && vol[i - 1] && vol[i + 1] && vol[i - W] && vol[i + W] &&
+                         (flat || (z > 0 && z < D - 1 && vol[i - (int64_t)W * H] && vol[i + (int64_t)W * H]));
       b = inner ? 0 : 1;
     }
     border[i] = b;
@@ -103,8 +107,8 @@ __global__ __launch_bounds__(256) void nearest_d2_kernel(const int64_t* a, int n
 using namespace wsl;
 
 extern "C" int wsl_surface_u8(const uint8_t* vol, uint8_t* border, int D, int H, int W, void* stream) {
-  WSL_REQUIRE(vol && border && D > 0 && H > 0 && W > 0, "surface_u8: bad arguments");
-  const int64_t n = (int64_t)D * H * W;
+  WSL_REQUIRE(vol && border && D >= 0 && H > 0 && W > 0, "surface_u8: bad arguments");
+  const int64_t n = (int64_t)(D ? D : 1) * H * W;
   int64_t blocks = (n + kThreads - 1) / kThreads;
   if (blocks > 4096) blocks = 4096;
   WSL_LAUNCH(surface_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, vol, border, D, H, W);

@@ -996,13 +996,13 @@ extern "C" int wsl_ustm_consistency_fwd_bwd(const float* a, const float* b, cons
   return check_launch("ustm_consistency_fwd_bwd");
 }
 
-extern "C" int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float gscale, int N, int C, int HW, void* ws,
-                                   size_t ws_bytes, void* stream) {
-  WSL_REQUIRE(p && loss && dp && N > 0 && C > 1 && C <= kMaxC && HW > 0, "entropy: bad args");
+extern "C" int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float gscale, int N, int C, int HW,
+                                   int norm_classes, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(p && loss && dp && N > 0 && C > 0 && C <= kMaxC && HW > 0 && norm_classes > 1, "entropy: bad args");
   const int HW_ = HW;
   WSL_WS_OK("entropy_fwd_bwd");
   const int64_t P = (int64_t)N * HW;
-  const double norm = 1.0 / ((double)P * log((double)C));
+  const double norm = 1.0 / ((double)P * log((double)norm_classes));   // losses.py:32-33: C is only the log(C) normaliser
   const int nb = grid_for(P);
   float* part = static_cast<float*>(ws);
   WSL_LAUNCH(entropy_kernel, dim3(nb), dim3(kThreads), 0, stream, p, C, HW, P, (float)(gscale * norm), dp, part);

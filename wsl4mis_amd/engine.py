@@ -174,7 +174,7 @@ class TrainEngine:
             rt.call("wsl_pdice_bwd", rt.ptr(t["s"]), rt.ptr(label_u8), 0, -1, rt.ptr(sums), rt.ptr(gout), rt.ptr(t["ds"]),
                     N, C_, HW, rt.stream())
         else:
-            rt.call("wsl_entropy_fwd_bwd", rt.ptr(t["s"]), rt.ptr(lo[4:]), rt.ptr(t["ds"]), w, N, C_, HW, rt.ptr(lws), nl, rt.stream())
+            rt.call("wsl_entropy_fwd_bwd", rt.ptr(t["s"]), rt.ptr(lo[4:]), rt.ptr(t["ds"]), w, N, C_, HW, C_, rt.ptr(lws), nl, rt.stream())
         rt.call("wsl_softmax_bwd", rt.ptr(t["s"]), rt.ptr(t["ds"]), rt.ptr(t["dzx"]), N, C_, HW, rt.stream())
         rt.call("wsl_axpy", rt.ptr(t["dz1"]), rt.ptr(t["dzx"]), 1.0, N * C_ * HW, rt.stream())
 

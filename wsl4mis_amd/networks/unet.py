@@ -34,8 +34,11 @@ class _NetFn(torch.autograd.Function):
         if ctx.token != mod._fwd_token:
             raise _lib.WslError("backward() after a newer training forward of the same module: the activations kept "
                                 "in the module's workspace were overwritten (use a second model instance)")
-        grads = mod._run_backward(ctx.x, gouts)
-        return (None, None) + grads
+        mod._run_backward(ctx.x, gouts)
+        # autograd keeps what is returned here as p.grad and later ACCUMULATES into it in place: hand out views of a private
+        # copy, never of the arena the next wsl_net_backward overwrites (the fused TrainEngine reads the arena directly)
+        flat = mod._grad_arena.clone()
+        return (None, None) + tuple(flat[off:off + n].view(shape) for _, off, n, shape in mod._plist)
 
 
 class _HipUNet(nn.Module):
@@ -69,6 +72,7 @@ class _HipUNet(nn.Module):
         self._fwd_token = 0
         self._forced_masks = None
         self._last_masks = None
+        self._mask_bufs = {}
 
     # ------------------------------------------------------------------ structure
     def _desc(self, N, H, W):
@@ -134,7 +138,9 @@ class _HipUNet(nn.Module):
         """Inject the Bernoulli masks of the next forward(s) (parity tests replay the reference's); None = draw."""
         self._forced_masks = emasks if callable(emasks) else (None if emasks is None and cmasks is None else (emasks, cmasks))
 
-    def _draw_masks(self, N, H, W, training):
+    def _draw_masks(self, N, H, W, training, slot="infer"):
+        """slot: 'train' for a forward whose masks a pending backward will read again, 'infer' for every other forward --
+        two buffer sets, so a no_grad / eval forward between forward and backward cannot redraw the saved masks."""
         dev = self._param_arena.device
         if callable(self._forced_masks):                 # (tests) masks that depend on the batch shape of the forward
             em, cm = self._forced_masks(N, H, W)
@@ -146,19 +152,21 @@ class _HipUNet(nn.Module):
         want_c = self._n_dec == 2 and cm is None     # F.dropout2d(x, 0.5) is active in eval mode too (unet.py:254-256,344)
         if want_e or want_c:
             key = (N, H, W)
-            if getattr(self, "_mask_key", None) != key:     # persistent mask buffers, refilled in place every forward
-                self._mask_e = [torch.empty((N, _FT[l], H >> l, W >> l), dtype=torch.uint8, device=dev) for l in range(5)]
-                self._mask_c = [torch.empty((N, _FT[l]), dtype=torch.float32, device=dev) for l in range(5)]
-                self._mask_key = key
+            bufs = self._mask_bufs.get(slot)
+            if bufs is None or bufs[0] != key:              # persistent mask buffers, refilled in place every forward
+                bufs = (key,
+                        [torch.empty((N, _FT[l], H >> l, W >> l), dtype=torch.uint8, device=dev) for l in range(5)],
+                        [torch.empty((N, _FT[l]), dtype=torch.float32, device=dev) for l in range(5)])
+                self._mask_bufs[slot] = bufs
             outs, probs, scales, isf = [], [], [], []
             if want_e:
-                em = self._mask_e
+                em = bufs[1]
                 outs += em
                 probs += [1.0 - p for p in _DROP]
                 scales += [1.0] * 5
                 isf += [0] * 5
             if want_c:
-                cm = self._mask_c
+                cm = bufs[2]
                 outs += cm
                 probs += [0.5] * 5
                 scales += [2.0] * 5
@@ -184,7 +192,7 @@ class _HipUNet(nn.Module):
         training = self.training
         grad_mode = training and keep_for_backward      # (grad mode is off inside autograd.Function.forward)
         ws = rt.workspace(("net", id(self), "train" if grad_mode else "infer"), nws)
-        em, cm = self._draw_masks(N, H, W, training)
+        em, cm = self._draw_masks(N, H, W, training, "train" if grad_mode else "infer")
         lm = torch.empty((N, self.class_num, H, W), dtype=torch.float32, device=x.device)
         la = torch.empty_like(lm) if self._n_dec == 2 else None
         rt.call("wsl_net_forward", C.byref(d), rt.ptr(self._param_arena), rt.ptr(self._buf_arena), rt.ptr(self._nbt),

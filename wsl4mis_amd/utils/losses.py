@@ -281,11 +281,12 @@ class _Entropy(torch.autograd.Function):
     def forward(ctx, p, C):
         p = rt.f32c(p, "p")
         N, Cn, HW = p.shape[0], p.shape[1], p[0, 0].numel()
-        if int(C) != Cn:
-            raise ValueError(f"entropy_loss: C={C} but p has {Cn} channels")
+        if int(C) < 2:
+            raise ValueError(f"entropy_loss: C={C} (the log(C) normaliser needs C >= 2)")
         ws, n = _lws(N, Cn, HW)
         loss, dp = _scalar(p.device), torch.empty_like(p)
-        rt.call("wsl_entropy_fwd_bwd", rt.ptr(p), rt.ptr(loss), rt.ptr(dp), 1.0, N, Cn, HW, rt.ptr(ws), n, rt.stream())
+        # like the reference, C is only the normaliser (default 2 whatever the channel count; losses.py:30-33)
+        rt.call("wsl_entropy_fwd_bwd", rt.ptr(p), rt.ptr(loss), rt.ptr(dp), 1.0, N, Cn, HW, int(C), rt.ptr(ws), n, rt.stream())
         ctx.save_for_backward(dp)
         return loss.reshape(())
 

@@ -24,10 +24,13 @@ def dice_percase(pred, gt):
 
 def _surface_points(vol_bool):
     v = torch.as_tensor(np.ascontiguousarray(vol_bool, dtype=np.uint8)).to(rt.device())
+    if v.dim() not in (2, 3):
+        raise NotImplementedError(f"hd95 of a {v.dim()}-D array is not built (2-D masks and [D,H,W] volumes are)")
+    depth = 0 if v.dim() == 2 else v.shape[0]          # D = 0: a 2-D array -> 4-neighbourhood erosion, like medpy
     if v.dim() == 2:
         v = v[None]
     border = torch.empty_like(v)
-    rt.call("wsl_surface_u8", rt.ptr(v), rt.ptr(border), v.shape[0], v.shape[1], v.shape[2], rt.stream())
+    rt.call("wsl_surface_u8", rt.ptr(v), rt.ptr(border), depth, v.shape[1], v.shape[2], rt.stream())
     return torch.nonzero(border).contiguous()          # [n, 3] int64 (z, y, x)
 
 
