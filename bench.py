@@ -52,49 +52,70 @@ def parse():
     ap.add_argument("--serial-decoders", action="store_true",
                     help="run the two decoders of unet_cct on ONE stream in the timed region too (per-launch timings do "
                          "not overlap; the command behind profiles/*serial* rocprofv3 summaries)")
+    ap.add_argument("--force-dp", action="store_true", help="N=1 only: take the data-parallel route (split backward, bucketed RCCL "
+                    "all-reduce in a 1-rank group on the comm stream) to measure its overhead on one GPU")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
+    ap.add_argument("--cpu-one-batch", action="store_true", help="CPU leg: only --cpu-batch, not batch 16 as well")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU leg and print its JSON")
     return ap.parse_args()
 
 
 def cpu_baseline(args):
-    """The oracle (torch-CPU restatement of the reference step) on a bounded sample of the same workload."""
+    """The oracle (torch-CPU restatement of the reference step) on bounded samples of the same workload: batch 4 and batch
+    16, ~10-15 s of CPU work each.  Built for BASELINE.json's configs 0-4: unet pce (config 0),
+    unet_cct pce / pce_gatedcrf / ours_proposed, unet mean_teacher."""
     from oracle import torch_ref as R
+    from wsl4mis_amd.synthetic import scribble_labels
     n_thr = args.cpu_threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(n_thr)
-    B, S = args.cpu_batch, args.size
-    g = torch.Generator().manual_seed(1)
-    sd = {}
-    for k, shp in R.state_layout(args.net, 1, 4):
-        if k.endswith("num_batches_tracked"):
-            sd[k] = torch.zeros((), dtype=torch.int64)
-        elif k.endswith("running_var") or (k.split(".")[-2] in ("1", "5") and k.endswith("weight")):
-            sd[k] = torch.ones(shp)
-        elif len(shp) == 4:
-            sd[k] = torch.randn(shp, generator=g) * (1.0 / (shp[1] * shp[2] * shp[3]) ** 0.5)
-        else:
-            sd[k] = torch.zeros(shp)
-    tr = R.RefTrainer(sd, args.net)
-    from wsl4mis_amd.synthetic import scribble_labels
-    x = torch.rand((B, 1, S, S), generator=g)
-    lab = torch.from_numpy(scribble_labels(B, S, S, 5))
-    em = [(torch.rand((B, 16 << l, S >> l, S >> l), generator=g) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
-    cm = [(torch.rand((B, 16 << l), generator=g) >= 0.5).float() * 2 for l in range(5)]
+    S = args.size
+    if args.loss not in ("pce", "pce_gatedcrf", "ours_proposed", "mean_teacher") or (args.loss == "ours_proposed" and args.net != "unet_cct"):
+        raise SystemExit(f"cpu baseline is not built for {args.net} {args.loss}")
     crf = args.crf_radius if args.loss == "pce_gatedcrf" else None
-    if args.loss in ("pce", "mean_teacher"):
-        raise SystemExit("cpu baseline is built for ours_proposed and pce_gatedcrf")
-    tr.step(x, lab, 0.4, em, cm, crf)                      # warm-up (thread pool, oneDNN primitives)
-    iters, t0 = 0, time.perf_counter()
-    while iters < max(2, args.cpu_iters) or (time.perf_counter() - t0 < 15.0 and iters < 12):   # ~15-30 s of CPU work
-        tr.step(x, lab, 0.4, em, cm, crf)
-        iters += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(B * iters / dt, 3), "unit": "slices/s", "cores": n_thr, "kind": "port",
-            "sample": f"oracle/torch_ref.py RefTrainer (stock torch CPU ops), {args.net} {args.loss}"
-                      + (f" r={args.crf_radius}" if crf else "") + f", batch {B} at {S}x{S}, 1 warm-up + {iters} timed "
-                      f"steps, {n_thr} threads of {os.cpu_count()} host cores"}
+
+    def leg(B, budget_s):
+        g = torch.Generator().manual_seed(1)
+        sd = {}
+        for k, shp in R.state_layout(args.net, 1, 4):
+            if k.endswith("num_batches_tracked"):
+                sd[k] = torch.zeros((), dtype=torch.int64)
+            elif k.endswith("running_var") or (k.split(".")[-2] in ("1", "5") and k.endswith("weight")):
+                sd[k] = torch.ones(shp)
+            elif len(shp) == 4:
+                sd[k] = torch.randn(shp, generator=g) * (1.0 / (shp[1] * shp[2] * shp[3]) ** 0.5)
+            else:
+                sd[k] = torch.zeros(shp)
+        x = torch.rand((B, 1, S, S), generator=g)
+        lab = torch.from_numpy(scribble_labels(B, S, S, 5))
+        em = [(torch.rand((B, 16 << l, S >> l, S >> l), generator=g) >= R.DROP[l]).to(torch.uint8) for l in range(5)]
+        cm = [(torch.rand((B, 16 << l), generator=g) >= 0.5).float() * 2 for l in range(5)]
+        if args.loss == "mean_teacher":
+            tr = R.RefMeanTeacher(sd)
+            noise = torch.clamp(torch.randn((B, 1, S, S), generator=g) * 0.1, -0.2, 0.2)
+            one = lambda: tr.step(x, lab, em, em, noise)                                      # noqa: E731
+        else:
+            tr = R.RefTrainer(sd, args.net)
+            one = lambda: tr.step(x, lab, 0.4, em, cm, crf, kind="pce" if args.loss == "pce" else None)   # noqa: E731
+        one()                                                  # warm-up (thread pool, oneDNN primitives)
+        iters, t0 = 0, time.perf_counter()
+        while iters < max(2, args.cpu_iters) or (time.perf_counter() - t0 < budget_s and iters < 12):
+            one()
+            iters += 1
+        dt = time.perf_counter() - t0
+        return {"batch": B, "value": round(B * iters / dt, 3), "timed_steps": iters, "seconds": round(dt, 2)}
+
+    legs = [leg(args.cpu_batch, 12.0)] + ([leg(16, 10.0)] if args.cpu_batch != 16 and not args.cpu_one_batch else [])
+    best = max(legs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "slices/s", "cores": n_thr, "kind": "port",
+            "sample": f"oracle/torch_ref.py (stock torch CPU ops = what the reference's CPU path executes), {args.net} {args.loss}"
+                      + (f" r={args.crf_radius}" if crf else "") + f", batch {best['batch']} at {S}x{S}, 1 warm-up + "
+                      f"{best['timed_steps']} timed steps ({best['seconds']} s), {n_thr} threads of {os.cpu_count()} host cores; the best "
+                      "of the batch sizes in `batches`"
+                      + ("; GatedCRF in the oracle is a tap loop over shifted views, which is KINDER to the CPU than the reference's "
+                         "two F.unfold materialisations (127 MB per slice each)" if crf else ""),
+            "batches": legs}
 
 
 def cpu_baseline_subprocess(args):
@@ -102,7 +123,7 @@ def cpu_baseline_subprocess(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--loss", args.loss, "--net", args.net,
            "--size", str(args.size), "--crf-radius", str(args.crf_radius), "--cpu-batch", str(args.cpu_batch),
-           "--cpu-iters", str(args.cpu_iters), "--cpu-threads", str(args.cpu_threads)]
+           "--cpu-iters", str(args.cpu_iters), "--cpu-threads", str(args.cpu_threads)] + (["--cpu-one-batch"] if args.cpu_one_batch else [])
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in reversed(r.stdout.strip().splitlines()):
@@ -116,7 +137,9 @@ def cpu_baseline_subprocess(args):
 def main():
     args = parse()
     if args.loss in ("mean_teacher", "ustm", "pce_tv", "pce_ms", "pce_entropy", "ce_dice"):
-        args.net, args.no_cpu_baseline = "unet", True      # config 4 (and USTM): single-decoder student + EMA teacher
+        args.net = "unet"                                  # config 4 (and USTM): single-decoder student + EMA teacher
+        if args.loss != "mean_teacher":
+            args.no_cpu_baseline = True
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
         return
@@ -128,15 +151,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path in the product)")
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from wsl4mis_amd import _lib
     from wsl4mis_amd.engine import TrainEngine
     from wsl4mis_amd.synthetic import batch
     dev = torch.device("cuda", local)
     torch.manual_seed(2022)                                   # same initial weights on every rank
-    eng = TrainEngine(args.net, 1, 4, base_lr=0.01, max_iterations=60000, loss=args.loss, crf_radius=args.crf_radius)
+    eng = TrainEngine(args.net, 1, 4, base_lr=0.01, max_iterations=60000, loss=args.loss, crf_radius=args.crf_radius,
+                      force_dp=args.force_dp)
     torch.manual_seed(2022 + 1000 * rank)                     # different dropout masks / data per rank
     x, lab = batch(args.batch, args.size, args.size, 2022 + rank, dev)
     random.seed(2022)                                         # identical beta stream on all ranks
@@ -153,6 +179,8 @@ def main():
     prof_timed = not args.no_prof and (not overlapped or args.prof_timed)
     if prof_timed:
         L.wsl_prof_enable(1)
+    if eng.dp:
+        eng.comm_diag(True)                                   # two events per step around the wait for the comm stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -160,6 +188,7 @@ def main():
     for _ in range(args.steps):
         eng.step(x, lab, random.random() + 1e-10)
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                         # this rank's own time, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -169,10 +198,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     losses = eng.losses()
+    dp_diag = None
+    if eng.dp:
+        # self-diagnosing N > 1 line: what each rank saw, how long the main stream sat waiting for the
+        # all-reduce stream, and whether the replicas are still bit-identical after the timed region
+        wait_ms = eng.comm_diag(False)
+        p = eng.model.flat_params()
+        digest = torch.stack([p.view(torch.int32).to(torch.int64).sum(), (p.view(torch.int32).to(torch.int64) * torch.arange(
+            1, p.numel() + 1, device=dev, dtype=torch.int64) % 1000003).sum()])
+        mine = torch.tensor([dt_own * 1e3 / args.steps, wait_ms / max(1, args.steps), float(digest[0].item()), float(digest[1].item()),
+                             float(losses["loss"])], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        rows_ = [[float(v) for v in t.tolist()] for t in allr]
+        dp_diag = {"backend": dist.get_backend(), "world_size_seen_by_the_process_group": dist.get_world_size(),
+                   "per_rank_ms_per_step": [round(r[0], 3) for r in rows_],
+                   "ms_per_step_min": round(min(r[0] for r in rows_), 3), "ms_per_step_max": round(max(r[0] for r in rows_), 3),
+                   "per_rank_ms_per_step_main_stream_blocked_on_allreduce": [round(r[1], 4) for r in rows_],
+                   "replicas_bit_identical_after_timed_region": all(r[2] == rows_[0][2] and r[3] == rows_[0][3] for r in rows_),
+                   "per_rank_last_loss": [round(r[4], 5) for r in rows_],
+                   "allreduce": "flat fp32 gradient arena in 2 buckets (decoders, then encoder) on a side stream; bytes per step "
+                                f"{4 * eng.model.n_param}", "semantics": "DDP-equivalent (per-rank BN statistics and loss normalisation, gradients averaged)"}
 
     def report():
-        rows = (_lib.WslProfRow * 8)()
-        L.wsl_prof_report(rows, 8)
+        rows = (_lib.WslProfRow * _lib.WSL_PROF_FAMILIES)()
+        L.wsl_prof_report(rows, _lib.WSL_PROF_FAMILIES)
         L.wsl_prof_enable(0)
         fams = {}
         for r in rows:
@@ -180,62 +233,96 @@ def main():
                 fams[r.name.decode()] = {"calls": int(r.calls), "ms": round(r.ms, 3),
                                          "avg_us": round(1e3 * r.ms / r.calls, 2),
                                          "tflops": round(r.flops / (r.ms * 1e-3) / 1e12, 2) if r.flops else None,
+                                         "issued_tflops": round(r.issued_flops / (r.ms * 1e-3) / 1e12, 2) if r.flops else None,
                                          "algo_GBps": round(r.bytes / (r.ms * 1e-3) / 1e9, 1)}
         return rows, fams
 
-    def roofline_of(rows, nsteps):
-        conv = [r for r in rows if r.calls and r.flops > 0]
-        if not conv:
+    def pmc_traffic(name, grp, calls):
+        """HBM bytes per launch of the dominant kernel family from the newest committed rocprofv3 PMC record
+        (FETCH_SIZE / WRITE_SIZE in separate runs of this same command -- tools/pmc_traffic.py); the record's file name,
+        SHA-256 and modification date travel in the line, so a stale record is visible."""
+        import glob
+        import hashlib
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=os.path.basename)          # r1z < r2a < ...: the newest round's record
+        if not cands:
             return None
-        # one entry per kernel family: the direct MFMA convolution (1x1 layers, first conv, 4-channel classifiers), the
-        # Winograd F(2x2,3x3) convolution (every other 3x3 layer, forward + data-gradient launches) and the weight gradient
-        # (Winograd form for the 3x3 layers; the 1x1 / first / classifier layers ride in the same event family).  The
-        # dominant one = most time per step.
-        # Flops are the ALGORITHMIC ones (direct convolution: 2 * 9 * Ci * Co per pixel) for all of them -- the Winograd
-        # kernel issues 2.25x fewer matrix instructions for the same result, so its fraction can pass what a direct kernel
-        # could reach.
-        kern = {"conv_mfma2l_kernel (fwd + data-gradient launches)": [r for r in rows[:2] if r.calls],
-                "conv_wino2_kernel (fwd + data-gradient launches)": [r for r in rows[6:8] if r.calls],
-                "wgrad_wino_kernel": [r for r in rows[2:3] if r.calls]}
-        per_kernel = {k: {"ms_per_step": round(sum(r.ms for r in v) / nsteps, 3), "launches": int(sum(r.calls for r in v)),
-                          "avg_launch_us": round(1e3 * sum(r.ms for r in v) / sum(r.calls for r in v), 2),
-                          "achieved": round(sum(r.flops for r in v) / (sum(r.ms for r in v) * 1e-3) / 1e12, 2),
-                          "frac": round(sum(r.flops for r in v) / (sum(r.ms for r in v) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-                      for k, v in kern.items() if v}
-        name, grp = max(((k, v) for k, v in kern.items() if v), key=lambda kv: sum(r.ms for r in kv[1]))
-        ms, fl, calls = sum(r.ms for r in grp), sum(r.flops for r in grp), sum(r.calls for r in grp)
-        ach = fl / (ms * 1e-3) / 1e12
-        traffic = None     # HBM bytes per launch of that kernel family from the committed rocprofv3 PMC passes
-        try:               # (FETCH_SIZE / WRITE_SIZE, separate runs of this same command -- tools/pmc_traffic.py)
-            tfile = next(f for f in ("r1z_pmc_traffic.json", "r1t_pmc_traffic.json", "r1h_pmc_traffic.json")
-                         if os.path.exists(os.path.join(ROOT, "profiles", f)))
-            with open(os.path.join(ROOT, "profiles", tfile)) as fh:
-                tj = json.load(fh)["kernels"]
+        tfile = cands[-1]
+        try:
+            raw = open(tfile, "rb").read()
+            tdoc = json.loads(raw)
+            tj = tdoc["kernels"]
             keys = ("conv_wino2_kernel", "conv_wino_kernel") if name.startswith("conv_wino") else \
                    ("conv_mfma2l_kernel", "conv_mfma2_kernel") if name.startswith("conv") else \
-                   ("wgrad_wino_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel")
+                   ("wgrad_wino_kernel",)
             nl = sum(tj[k]["launches_sampled"] for k in keys if k in tj)
-            traffic = {"hbm_bytes_per_launch": sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["launches_sampled"]
-                                                   for k in keys if k in tj) / nl,
-                       "algorithmic_bytes_per_launch": sum(r.bytes for r in grp) / calls,
-                       "source": f"profiles/{tfile} (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
-        except (OSError, KeyError, ValueError, ZeroDivisionError, StopIteration):
-            pass
-        return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            return {"hbm_bytes_per_launch": sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["launches_sampled"] for k in keys if k in tj) / nl,
+                    "algorithmic_bytes_per_launch": sum(r.bytes for r in grp) / calls,
+                    "source": f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md; a committed "
+                              "record of an earlier run of this command, not collected in this run)",
+                    "source_sha256": hashlib.sha256(raw).hexdigest(),
+                    "source_collected_utc": tdoc.get("collected_utc")}
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            return None
+
+    def roofline_of(rows, nsteps, ms_per_step):
+        byname = {r.name.decode(): r for r in rows if r.calls}
+        conv = [r for r in byname.values() if r.flops > 0]
+        if not conv:
+            return None
+        # one entry per MFMA kernel family.  Flops are the ALGORITHMIC ones (direct convolution: 2 * 9 * Ci * Co per pixel,
+        # SURVEY 8d) -- `frac`; the Winograd F(2x2,3x3) kernels issue 2.25x fewer matrix instructions for the same result, so
+        # `issued_frac` (matrix-core flops actually issued / peak) is reported next to it: THAT is the matrix-pipe utilisation.
+        kern = {"conv_mfma2l_kernel (direct: 1x1, first conv, classifiers; fwd + data-gradient launches)":
+                    [byname[k] for k in ("conv_mfma2l_kernel(fwd)", "conv_mfma2l_kernel(dgrad)") if k in byname],
+                "conv_wino2_kernel (Winograd; fwd + data-gradient launches)":
+                    [byname[k] for k in ("conv_wino2_kernel(fwd)", "conv_wino2_kernel(dgrad)") if k in byname],
+                "wgrad_wino_kernel (Winograd weight gradient)": [byname[k] for k in ("wgrad_wino_kernel",) if k in byname],
+                "wgrad_direct_kernels (1x1, first conv, classifiers)": [byname[k] for k in ("wgrad_direct_kernels",) if k in byname]}
+
+        def fam(v):
+            ms, fl, iss, calls = sum(r.ms for r in v), sum(r.flops for r in v), sum(r.issued_flops for r in v), sum(r.calls for r in v)
+            return {"ms_per_step": round(ms / nsteps, 3), "launches": int(calls), "avg_launch_us": round(1e3 * ms / calls, 2),
+                    "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "issued": round(iss / (ms * 1e-3) / 1e12, 2), "issued_frac": round(iss / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "algo_GBps": round(sum(r.bytes for r in v) / (ms * 1e-3) / 1e9, 1)}
+        per_kernel = {k: fam(v) for k, v in kern.items() if v}
+        name, grp = max(((k, v) for k, v in kern.items() if v), key=lambda kv: sum(r.ms for r in kv[1]))
+        d = per_kernel[name]
+        calls = sum(r.calls for r in grp)
+        traffic = pmc_traffic(name, grp, calls)
+        iss_step = sum(r.issued_flops for r in conv) / nsteps
+        # HBM-bound kernel families: SURVEY 8d's algorithmic bytes / measured time / 8 TB/s
+        hbm = {}
+        for k in ("bnact_bwd(reduce+finalize+apply)", "bilinear_up2(fwd+bwd)", "pool2_fwd+feat_grad_combine", "gatedcrf_fwd_kernel",
+                  "loss_head(reduce+finalize+bwd+mix)", "sgd_kernel", "bn_finalize_kernel", "wgrad_reduce_kernel", "masks+filter_images"):
+            if k in byname:
+                r = byname[k]
+                gbs = r.bytes / (r.ms * 1e-3) / 1e9
+                hbm[k] = {"ms_per_step": round(r.ms / nsteps, 3), "launches_per_step": round(r.calls / nsteps, 1),
+                          "algorithmic_bytes_per_step": round(r.bytes / nsteps), "achieved_GBps": round(gbs, 1),
+                          "frac": round(gbs / PEAK_HBM_GBS, 4)}
+        return {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": d["frac"],
+                "issued": d["issued"], "issued_frac": d["issued_frac"],
+                "whole_step_issued_frac": round(iss_step / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,     # HBM bytes per launch (PMC)
                 "traffic_detail": traffic,
-                "launches": int(calls), "avg_launch_us": round(1e3 * ms / calls, 2), "flops_per_launch": fl / calls,
-                "flops_counted": "algorithmic (direct convolution)", "kernels": per_kernel,
+                "launches": int(calls), "avg_launch_us": d["avg_launch_us"], "flops_per_launch": sum(r.flops for r in grp) / calls,
+                "flops_counted": "frac/achieved: algorithmic (direct convolution); issued/issued_frac: matrix-core flops issued "
+                                 "(= algorithmic / 2.25 for the Winograd kernels); whole_step_issued_frac: all MFMA kernels' issued "
+                                 "flops per step / the timed region's ms_per_step / peak",
+                "kernels": per_kernel,
                 "all_mfma_kernels_tflops": round(sum(r.flops for r in conv) / (sum(r.ms for r in conv) * 1e-3) / 1e12, 2),
-                "all_mfma_kernels_ms_per_step": round(sum(r.ms for r in conv) / nsteps, 3)}
+                "all_mfma_kernels_ms_per_step": round(sum(r.ms for r in conv) / nsteps, 3),
+                "hbm_roofline": {"peak_GBps": PEAK_HBM_GBS, "kernels": hbm,
+                                 "all_hbm_kernels_ms_per_step": round(sum(v["ms_per_step"] for v in hbm.values()), 3)}}
 
     roof, fams = None, {}
     if not args.no_prof:
         timed = None
         if prof_timed:
             rows, fams = report()
-            roof = roofline_of(rows, args.steps)
+            roof = roofline_of(rows, args.steps, 1e3 * dt / args.steps)
         if overlapped:
             # second segment, decoders serialised: launches of the dominant kernel no longer overlap each other
             if roof:
@@ -254,7 +341,7 @@ def main():
             rows2, fams = report()
             L.wsl_debug_net_concurrent(1)
             eng.concurrent = True
-            roof = roofline_of(rows2, seg)
+            roof = roofline_of(rows2, seg, 1e3 * dt / args.steps)
             if roof:
                 roof["measured"] = (f"{seg} extra steps of the same workload right after the timed region, two decoder streams "
                                     f"serialised ({round(seg_ms, 3)} ms/step incl. event overhead); in the timed region "
@@ -277,10 +364,12 @@ def main():
                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "crf_radius": args.crf_radius},
                "whole_step_conv_mfma_frac": round(value / world * gflop * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
                "roofline": roof, "kernels": fams, "last_losses": {k: round(v, 5) for k, v in losses.items()}}
+        if dp_diag:
+            out["dp"] = dp_diag
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
 
 

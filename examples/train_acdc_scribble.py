@@ -37,9 +37,14 @@ def main(argv=None):
     ap.add_argument("--patch_size", type=int, nargs=2, default=[256, 256])
     ap.add_argument("--seed", type=int, default=2022)
     ap.add_argument("--val_every", type=int, default=200)
-    ap.add_argument("--labeled_type", default="labeled")
+    ap.add_argument("--labeled_type", default="all", help="'all' = every training patient of the fold (upstream WSL4MIS's weakly-"
+                    "supervised runs), 'labeled' / 'unlabeled' = the subsets of dataset_semi.py")
     ap.add_argument("--snapshot_path", default=None, help="write the reference's checkpoints here (state_dict .pth files)")
     ap.add_argument("--save_every", type=int, default=3000)
+    ap.add_argument("--no_hd95", action="store_true", help="validation: Dice only (the model-selection metric), skip HD95")
+    ap.add_argument("--log_every", type=int, default=20)
+    ap.add_argument("--quiet", action="store_true", help="no per-iteration lines (validation lines stay)")
+    ap.add_argument("--curve_json", default=None, help="write the loss / validation curve here (rank 0)")
     ap.add_argument("--resume", default=None, help="a state_dict .pth (the reference's or ours: same keys) to start from")
     args = ap.parse_args(argv)
 
@@ -50,11 +55,11 @@ def main(argv=None):
         dist.init_process_group("nccl")
     random.seed(args.seed), np.random.seed(args.seed + rank), torch.manual_seed(args.seed)
     train = BaseDataSets(base_dir=args.root_path, split="train", fold=args.fold, sup_type=args.sup_type,
-                         labeled_type=args.labeled_type)
-    val = BaseDataSets(base_dir=args.root_path, split="val", fold=args.fold)
+                         labeled_type=args.labeled_type, cache=True)
+    val = BaseDataSets(base_dir=args.root_path, split="val", fold=args.fold, cache=True)
     if len(train) == 0:
         raise SystemExit("no training slices for this fold under " + args.root_path)
-    aug = BatchRandomGenerator(args.patch_size)
+    aug = BatchRandomGenerator(args.patch_size, device_cache=True)
     eng = TrainEngine(args.model, 1, args.num_classes, base_lr=args.base_lr, max_iterations=args.max_iterations,
                       loss=args.loss)
     if args.resume:
@@ -64,6 +69,9 @@ def main(argv=None):
     torch.manual_seed(args.seed + 1000 * rank)          # dropout masks differ per rank; beta is shared (python RNG)
     order = np.random.RandomState(args.seed + rank)
     it, best, history = 0, 0.0, []
+    log = [] if (args.curve_json and rank == 0) else None
+    import time
+    t_start = time.time()
     while it < args.max_iterations:
         perm = order.permutation(len(train))
         for b in range(0, len(perm), args.batch_size):
@@ -73,23 +81,50 @@ def main(argv=None):
             image, label = aug([train[int(i)] for i in idx])
             eng.step(image, label, random.random() + 1e-10)
             it += 1
-            if rank == 0 and (it % 20 == 0 or it == 1):
+            if rank == 0 and (it % args.log_every == 0 or it == 1):
                 o = eng.losses()
                 history.append((it, o["loss"]))
-                print("iteration %d : " % it + ", ".join(f"{k} {v:.4f}" for k, v in o.items()), flush=True)
-            if rank == 0 and len(val) and it % args.val_every == 0:
-                m = np.array([[d for d, _ in val_2D.test_single_volume_cct(v["image"], v["label"], eng.model, args.num_classes,
-                                                                          args.patch_size)] for v in (val[i] for i in range(len(val)))])
-                if float(m.mean()) > best and args.snapshot_path:      # ..._ours_proposed.py:174-182
-                    for name in ("iter_{}_dice_{}.pth".format(it, round(float(m.mean()), 4)), "{}_best_model.pth".format(args.model)):
-                        torch.save(eng.model.state_dict(), os.path.join(args.snapshot_path, name))
-                best = max(best, float(m.mean()))
-                print("iteration %d : mean_dice %.4f (best %.4f)" % (it, m.mean(), best), flush=True)
+                if log is not None:
+                    log.append(dict(o, iteration=it, lr=eng.lr))
+                if not args.quiet:
+                    print("iteration %d : " % it + ", ".join(f"{k} {v:.4f}" for k, v in o.items()), flush=True)
+            if len(val) and it % args.val_every == 0:
+                # every rank validates its share of the volumes (replicas are bit-identical), then one all-reduce of the sums:
+                # nobody sits blocked in the next step's gradient all-reduce while rank 0 works through the whole set
+                volume_fn = val_2D.test_single_volume_cct if args.model == "unet_cct" else val_2D.test_single_volume
+                acc = np.zeros(2 * (args.num_classes - 1) + 1)
+                for i in range(rank, len(val), world):
+                    v = val[i]
+                    m = np.array(volume_fn(v["image"], v["label"], eng.model, args.num_classes, args.patch_size,
+                                           with_hd95=not args.no_hd95), dtype=np.float64)
+                    acc += np.concatenate([m[:, 0], m[:, 1], [1.0]])
+                if world > 1:
+                    t = torch.from_numpy(acc).cuda()
+                    dist.all_reduce(t)
+                    acc = t.cpu().numpy()
+                nc = args.num_classes - 1
+                dice_c, hd_c = acc[:nc] / acc[-1], acc[nc:2 * nc] / acc[-1]
+                mean_dice, mean_hd95 = float(dice_c.mean()), float(hd_c.mean())
+                if rank == 0:
+                    if mean_dice > best and args.snapshot_path:      # ..._ours_proposed.py:174-182
+                        for name in ("iter_{}_dice_{}.pth".format(it, round(mean_dice, 4)), "{}_best_model.pth".format(args.model)):
+                            torch.save(eng.model.state_dict(), os.path.join(args.snapshot_path, name))
+                    print("iteration %d : mean_dice %.4f mean_hd95 %.3f (best %.4f)" % (it, mean_dice, mean_hd95, max(best, mean_dice)),
+                          flush=True)
+                    if log is not None:
+                        log.append({"iteration": it, "mean_dice": mean_dice, "mean_hd95": mean_hd95,
+                                    "dice_per_class": [float(x) for x in dice_c]})
+                best = max(best, mean_dice)
                 eng.model.train()
             if rank == 0 and args.snapshot_path and it % args.save_every == 0:     # ..._ours_proposed.py:194-198
                 torch.save(eng.model.state_dict(), os.path.join(args.snapshot_path, "iter_" + str(it) + ".pth"))
             if it >= args.max_iterations:
                 break
+    if log is not None:
+        import json
+        with open(args.curve_json, "w") as fh:
+            json.dump({"args": vars(args), "train_slices": len(train), "val_volumes": len(val), "best_mean_dice": best,
+                       "wall_seconds": round(time.time() - t_start, 1), "world": world, "curve": log}, fh)
     return history
 
 

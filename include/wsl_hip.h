@@ -37,11 +37,12 @@ const char* wsl_build_info(void);   /* "gfx950 hipcc ..." or "HOST-EMULATION (te
 /* Opt-in measurement: HIP events bracket every launch of the heavy kernel families on the launch stream while
  * enabled; wsl_prof_report() waits for those events (the library's only synchronising call) and fills one row per
  * family with the launch count, summed duration and the ALGORITHMIC flops / bytes those launches covered. */
-#define WSL_PROF_FAMILIES 8
+#define WSL_PROF_FAMILIES 16
 typedef struct WslProfRow {
   char name[48];
   int64_t calls;
   double ms, flops, bytes;
+  double issued_flops;   /* matrix-core flops actually issued: = flops for the direct kernels, flops / 2.25 for Winograd F(2x2,3x3) */
 } WslProfRow;
 int wsl_prof_enable(int on);                      /* also clears what was recorded so far */
 int wsl_prof_report(WslProfRow* rows, int max_rows);

@@ -293,11 +293,16 @@ class RefTrainer:
         self.bufs = [torch.zeros_like(self.sd[k]) for k in self.pkeys]
         self.lr = base_lr
 
-    def step(self, x, label_u8, beta, emasks, cmasks, crf=None):
+    def step(self, x, label_u8, beta, emasks, cmasks, crf=None, kind=None):
+        """kind: None = ours_proposed (unet_cct) / pCE (unet), + 0.1 GatedCRF when `crf` (a radius) is given;
+        'pce' = the dual-branch 0.5 (ce1 + ce2) alone on unet_cct (BASELINE.json config 1)."""
         for k in self.pkeys:
             self.sd[k].grad = None
         out = net_forward(self.sd, x, self.net, emasks, cmasks, True)
-        if self.net == "unet_cct" and crf is None:
+        if self.net == "unet_cct" and kind == "pce":
+            lce = 0.5 * (ce_ignore(out[0], label_u8) + ce_ignore(out[1], label_u8))
+            loss, lpse = lce, torch.zeros(())
+        elif self.net == "unet_cct" and crf is None:
             loss, lce, lpse, _ = ours_proposed_loss(out[0], out[1], label_u8, beta)
         elif self.net == "unet_cct":
             s1, s2 = torch.softmax(out[0], 1), torch.softmax(out[1], 1)
@@ -317,3 +322,29 @@ class RefTrainer:
         self.lr = poly_lr(self.base_lr, self.it, self.max_it)
         self.it += 1
         return float(loss.detach()), float(lce.detach()), float(lpse.detach())
+
+
+class RefMeanTeacher:
+    """BASELINE.json config 4 as SURVEY 8d defines it: student unet + EMA teacher (train mode, no_grad, noisy input);
+    loss = mean_teacher_loss; SGD on the student; EMA update with the iteration count before its increment."""
+
+    def __init__(self, sd, base_lr=0.01, max_it=60000):
+        self.student = RefTrainer(sd, "unet", base_lr, max_it)
+        self.teacher = {k: v.clone() for k, v in sd.items()}
+
+    def step(self, x, label_u8, emasks_s, emasks_t, noise):
+        st = self.student
+        for k in st.pkeys:
+            st.sd[k].grad = None
+        with torch.no_grad():
+            zt = net_forward(self.teacher, x + noise, "unet", emasks_t, None, True)
+        zs = net_forward(st.sd, x, "unet", emasks_s, None, True)
+        loss, lce, ltv, lcons = mean_teacher_loss(zs, zt, label_u8, st.it)
+        loss.backward()
+        with torch.no_grad():
+            ps = [st.sd[k] for k in st.pkeys]
+            sgd_step(ps, [p.grad for p in ps], st.bufs, st.lr, first=(st.it == 0))
+            ema_update([self.teacher[k] for k in st.pkeys], ps, 0.99, st.it)
+        st.lr = poly_lr(st.base_lr, st.it, st.max_it)
+        st.it += 1
+        return float(loss.detach()), float(lce.detach()), float(ltv.detach()), float(lcons.detach())

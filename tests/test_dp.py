@@ -43,6 +43,79 @@ def test_two_rank_gloo_matches_ddp_fixture(tmp_path):
     assert np.array_equal(r0["params_after"], r1["params_after"])   # replicas stay bit-identical after the step
 
 
+@pytest.mark.parametrize("kind", ["pce_gatedcrf", "mean_teacher"])
+def test_two_rank_gloo_other_compositions_match_the_oracle(tmp_path, kind):
+    """The headline composition (unet_cct pCE + GatedCRF) and BASELINE.json config 4 (mean teacher: teacher forward + gradient
+    all-reduce in one step) through the data-parallel route on two gloo ranks: the averaged gradient, the SGD step and the
+    EMA teacher equal the oracle's per-shard computation averaged (DDP-equivalent semantics), and the replicas
+    stay bit-identical."""
+    import torch
+    from detinit import det_state
+    from oracle import torch_ref as R
+    import dp_worker
+    get_backend("emul")
+    port = str(free_port())
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", port, str(tmp_path), kind],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    r0, r1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))
+    assert np.array_equal(r0["grads"], r1["grads"]) and np.array_equal(r0["params_after"], r1["params_after"])
+    # ---- oracle: each shard on its own (own BN statistics, own loss normalisation), gradients averaged
+    net = "unet_cct" if kind == "pce_gatedcrf" else "unet"
+    layout = {k: tuple(shp) for k, shp in R.state_layout(net, 1, 4)}
+
+    def det(seed):
+        return {k: torch.from_numpy(np.asarray(v)).clone() for k, v in det_state(layout, seed).items()}
+    pk = [k for k in layout if R.is_param(k)]
+    from netutil import KinkMargins
+    shard_grads, losses, it = [], [], 4500
+    for r in range(2):
+        d = dp_worker.shard_inputs(r, kind)
+        with KinkMargins() as km, torch.no_grad():         # the shard is clear of gradient discontinuities (see dp_worker.SHARD_SEEDS)
+            R.net_forward(det(9), d["x"], net, d["em"], d["cm"] if net == "unet_cct" else None, True)
+            if kind == "mean_teacher":
+                R.net_forward(det(22), d["x"] + d["noise"], net, d["em_t"], None, True)
+        assert km.leaky > 4e-6 and km.pool > 1e-6, (r, km.leaky, km.pool)
+        sd = det(9)
+        for k in pk:
+            sd[k].requires_grad_(True)
+        if kind == "pce_gatedcrf":
+            o1, o2 = R.net_forward(sd, d["x"], net, d["em"], d["cm"], True)
+            s1, s2 = torch.softmax(o1, 1), torch.softmax(o2, 1)
+            lce = 0.5 * (R.ce_ignore(o1, d["lab"]) + R.ce_ignore(o2, d["lab"]))
+            loss = lce + 0.1 * R.gatedcrf(d["beta"] * s1 + (1.0 - d["beta"]) * s2, d["x"], 2)[0]
+        else:
+            with torch.no_grad():
+                zt = R.net_forward(det(22), d["x"] + d["noise"], net, d["em_t"], None, True)
+            loss = R.mean_teacher_loss(R.net_forward(sd, d["x"], net, d["em"], None, True), zt, d["lab"], it)[0]
+        loss.backward()
+        losses.append(float(loss.detach()))
+        shard_grads.append(np.concatenate([sd[k].grad.numpy().ravel() for k in pk]).astype(np.float64))
+    for r, rr in enumerate((r0, r1)):
+        assert abs(float(rr["loss"]) - losses[r]) <= 1e-4 * abs(losses[r]), (r, float(rr["loss"]), losses[r])
+    ref = 0.5 * (shard_grads[0] + shard_grads[1])
+    off, bad = 0, []
+    for k in pk:
+        n = int(np.prod(layout[k])) if layout[k] else 1
+        err = float(np.max(np.abs(r0["grads"][off:off + n] - ref[off:off + n])))
+        if err > grad_tol(k, ref[off:off + n]):
+            bad.append((k, err, float(np.max(np.abs(ref[off:off + n])))))
+        off += n
+    assert not bad, bad[:6]
+    # SGD with the averaged gradient (it = 4500: momentum buffer starts at zero -> buf = g), then the EMA teacher
+    p0 = np.concatenate([det(9)[k].numpy().ravel() for k in pk]).astype(np.float64)
+    lr = 0.01
+    p1 = p0 - lr * (ref + 1e-4 * p0)
+    assert np.max(np.abs(r0["params_after"] - p1)) <= 1e-6 * np.max(np.abs(p1))
+    if kind == "mean_teacher":
+        assert np.array_equal(r0["teacher_after"], r1["teacher_after"])
+        t0 = np.concatenate([det(22)[k].numpy().ravel() for k in pk]).astype(np.float64)
+        a = min(1.0 - 1.0 / (it + 1), 0.99)
+        assert np.max(np.abs(r0["teacher_after"] - (a * t0 + (1 - a) * p1))) <= 1e-6 * np.max(np.abs(t0))
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_single_rank_rccl_group_takes_the_dp_route_and_changes_nothing():

@@ -22,9 +22,12 @@ class WslSrc(C.Structure):
                 ("shift", c_fp), ("emask", c_fp), ("emask_scale", C.c_float), ("_pad1", C.c_float), ("cmask", c_fp)]
 
 
+WSL_PROF_FAMILIES = 16
+
+
 class WslProfRow(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("calls", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
-                ("bytes", C.c_double)]
+                ("bytes", C.c_double), ("issued_flops", C.c_double)]
 
 
 class WslNetDesc(C.Structure):

@@ -90,15 +90,17 @@ int stream_join(void*, void*) { return WSL_OK; }
 // library that synchronises (on its own events).
 namespace wsl {
 #ifndef WSL_HOST_EMUL
-struct ProfRec { int fam; double flops, bytes; hipEvent_t a, b; };
+struct ProfRec { int fam; double flops, bytes, issued; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
-static const char* kFamNames[WSL_PROF_FAMILIES] = {"conv_mfma2l_kernel(fwd)", "conv_mfma2l_kernel(dgrad)", "wgrad_wino_kernel",
-                                                   "wgrad_reduce_kernel", "gatedcrf_fwd_kernel", "other", "conv_wino2_kernel(fwd)",
-                                                   "conv_wino2_kernel(dgrad)"};
-void* prof_begin(int fam, double flops, double bytes, void* stream) {
+static const char* kFamNames[WSL_PROF_FAMILIES] = {
+    "conv_mfma2l_kernel(fwd)", "conv_mfma2l_kernel(dgrad)", "wgrad_wino_kernel", "wgrad_reduce_kernel", "gatedcrf_fwd_kernel",
+    "other", "conv_wino2_kernel(fwd)", "conv_wino2_kernel(dgrad)", "wgrad_direct_kernels", "bnact_bwd(reduce+finalize+apply)",
+    "bn_finalize_kernel", "bilinear_up2(fwd+bwd)", "pool2_fwd+feat_grad_combine", "loss_head(reduce+finalize+bwd+mix)", "sgd_kernel",
+    "masks+filter_images"};
+void* prof_begin(int fam, double flops, double bytes, void* stream, double issued) {
   if (!g_prof_on) return nullptr;
-  ProfRec r{fam, flops, bytes, nullptr, nullptr};
+  ProfRec r{fam, flops, bytes, issued < 0.0 ? flops : issued, nullptr, nullptr};
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
   (void)hipEventRecord(r.a, (hipStream_t)stream);
   g_prof.push_back(r);
@@ -109,7 +111,7 @@ void prof_end(void* tok, void* stream) {
   (void)hipEventRecord(g_prof[(size_t)(uintptr_t)tok - 1].b, (hipStream_t)stream);
 }
 #else
-void* prof_begin(int, double, double, void*) { return nullptr; }
+void* prof_begin(int, double, double, void*, double) { return nullptr; }
 void prof_end(void*, void*) {}
 #endif
 }  // namespace wsl
@@ -145,6 +147,7 @@ extern "C" int wsl_prof_report(WslProfRow* rows, int max_rows) {
     rows[r.fam].ms += ms;
     rows[r.fam].flops += r.flops;
     rows[r.fam].bytes += r.bytes;
+    rows[r.fam].issued_flops += r.issued;
   }
 #endif
   return WSL_PROF_FAMILIES;

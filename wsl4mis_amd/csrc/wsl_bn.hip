@@ -486,6 +486,7 @@ extern "C" int wsl_bn_stats_finalize(const float* stat_part, const float* stat_c
                                      float* shift, void* stream) {
   WSL_REQUIRE(stat_part && stat_cnt && gamma && beta && mean && invstd && scale && shift, "bn_stats_finalize: null");
   WSL_REQUIRE(nblk > 0 && C > 0, "bn_stats_finalize: bad sizes");
+  ProfScope ps(PF_BN_FINALIZE, 0.0, 4.0 * (3.0 * nblk * C + 8.0 * C), stream);
   WSL_LAUNCH(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, stat_part, stat_cnt, nblk, C, gamma, beta, eps,
              momentum, running_mean, running_var, nbt, mean, invstd, scale, shift);
   return check_launch("bn_finalize_kernel");
@@ -508,6 +509,7 @@ extern "C" int wsl_src_materialize(const WslSrc* s, float* out, int64_t out_bs, 
 
 extern "C" int wsl_pool2_fwd(const WslSrc* s, float* out, int N, int H, int W, void* stream) {
   WSL_REQUIRE(s && s->x && out && N > 0 && H > 1 && W > 1 && s->C > 0, "pool2_fwd: bad args");
+  ProfScope ps(PF_POOL_FANIN, 0.0, 5.0 * (double)N * s->C * H * W, stream);        // read 4 B, write 1 B per input element
   WSL_LAUNCH(pool2_fwd_kernel, dim3(cdiv((H / 2) * (W / 2), kChunk), s->C, N), dim3(kThreads), 0, stream, *s, out, H, W);
   return check_launch("pool2_fwd_kernel");
 }
@@ -516,6 +518,8 @@ extern "C" int wsl_feat_grad_combine(const WslSrc* f, const float* ga, int64_t g
                                      const float* gb_cmask, const float* gp, float* g, int N, int H, int W, void* stream) {
   WSL_REQUIRE(f && g && N > 0 && H > 0 && W > 0 && f->C > 0, "feat_grad_combine: bad args");
   WSL_REQUIRE(!gp || f->x, "feat_grad_combine: pool routing needs the feature map");
+  // reads: skip gradient(s) 4 B (+4 B), the feature 4 B and the pooled gradient 1 B when routing; writes 4 B per element
+  ProfScope ps(PF_POOL_FANIN, 0.0, (double)N * f->C * H * W * (4.0 * (ga ? 1 : 0) + 4.0 * (gb ? 1 : 0) + (gp ? 5.0 : 0.0) + 4.0), stream);
   WSL_LAUNCH(feat_grad_combine_kernel, dim3(cdiv(((H + 1) / 2) * ((W + 1) / 2), kChunk), f->C, N), dim3(kThreads), 0,
              stream, *f, ga, ga_bs, gb, gb_bs, gb_cmask, gp, g, H, W);
   return check_launch("feat_grad_combine_kernel");
@@ -537,6 +541,8 @@ extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const
     return WSL_EWORKSPACE;
   }
   BnBwdP p{g, g_bs, y, mean, invstd, gamma, beta, emask, emask_scale, C, H * W, cdiv(H * W, kChunk)};
+  // reduce pass reads g, y (+ keep mask); apply pass reads them again and writes dy: 20 (+2) B per element
+  ProfScope ps(PF_BN_BWD, 0.0, (double)N * C * H * W * (20.0 + (emask ? 2.0 : 0.0)), stream);
   float* part = static_cast<float*>(ws);
   float* coef = part + (size_t)N * p.chunks * C * 2;
   dim3 grid(p.chunks, C, N);
@@ -556,6 +562,7 @@ extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const
 extern "C" int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream) {
   WSL_REQUIRE(u && out && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_fwd: bad args");
   WSL_REQUIRE(out_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_fwd: out batch stride too small");
+  ProfScope ps(PF_BILINEAR, 0.0, 20.0 * (double)N * C * h * w, stream);            // read 4 B per input, write 4 x 4 B
   if (up2_fast_ok(out, out_bs, w)) {
     const int lw = ilog2(2 * w);                                    // output row width = 2^lw <= 256
     int rows = 8192 / (2 * w);                                      // ~8K outputs per workgroup
@@ -573,6 +580,7 @@ extern "C" int wsl_bilinear_up2_bwd(const float* dout, int64_t dout_bs, float* d
                                     void* stream) {
   WSL_REQUIRE(dout && du && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_bwd: bad args");
   WSL_REQUIRE(dout_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_bwd: dout batch stride too small");
+  ProfScope ps(PF_BILINEAR, 0.0, 20.0 * (double)N * C * h * w, stream);
   if (up2_fast_ok(dout, dout_bs, w)) {
     const int ltj = ilog2(w < 64 ? w : 64);
     WSL_LAUNCH(bilinear_up2_bwd4_kernel, dim3((w >> ltj) * cdiv(h, kUpTI), C, N), dim3(kThreads), 0, stream, dout, dout_bs,

@@ -521,7 +521,7 @@ static int launch_wgrad(WgradP& p, const WgPlan& g, void* stream) {
   }
   dim3 grid(g.co_blocks * g.ci_blocks, g.nsplit);
   const double px = (double)p.N * p.in.H * p.in.W;
-  void* tok = prof_begin(2, 2.0 * px * p.Co * p.in.Ci * KS * KS, 4.0 * px * (p.Co + p.in.Ci), stream);
+  void* tok = prof_begin(PF_WGRAD_DIRECT, 2.0 * px * p.Co * p.in.Ci * KS * KS, 4.0 * px * (p.Co + p.in.Ci), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("wgrad_mfma_kernel");
@@ -728,7 +728,7 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
     return rc;
   }
   const int64_t total = (int64_t)KK * Co * Ci + (db ? Co : 0);
-  void* tok = prof_begin(3, 0.0, 4.0 * (double)total * (g.nsplit + 1), stream);
+  void* tok = prof_begin(PF_WGRAD_REDUCE, 0.0, 4.0 * (double)total * (g.nsplit + 1), stream);
   struct EndProf { void* t; void* s; ~EndProf() { prof_end(t, s); } } endprof{tok, stream};
   if (g.nsplit >= 64) {
     WSL_LAUNCH((wgrad_reduce_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(kThreads), 0, stream, p.part_dw,

@@ -780,7 +780,14 @@ __global__ __launch_bounds__(256) void pack_table_kernel(PackTable t, const floa
   }
 }
 
+static double pack_table_elems(const PackTable& t) {
+  double e = 0.0;
+  for (int i = 0; i < t.n; ++i) e += (double)t.e[i].Co * t.e[i].Ci * t.e[i].KK;
+  return e;
+}
+
 int conv2_pack_table(const PackTable& t, const float* params, float* packf, float* packd, int with_dgrad, void* stream) {
+  ProfScope ps(PF_PREP, 0.0, 4.0 * pack_table_elems(t) * (with_dgrad ? 3.0 : 2.0), stream);
   WSL_LAUNCH(pack_table_kernel, dim3(32, t.n, with_dgrad ? 2 : 1), dim3(kThreads), 0, stream, t, params, packf, packd);
   return check_launch("pack_table_kernel");
 }
@@ -1528,7 +1535,7 @@ static int launch_wgrad2s(Wgrad2P& p, int ci_blocks, void* stream) {
   }
   dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(PF_WGRAD_DIRECT, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("wgrad_mfma2s_kernel");
@@ -1545,7 +1552,7 @@ static int launch_wgrad2l(Wgrad2P& p, int ci_blocks, void* stream) {
   }
   dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(PF_WGRAD_DIRECT, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("wgrad_mfma2l_kernel");
@@ -1570,7 +1577,7 @@ static int launch_wgrad2(Wgrad2P& p, int ci_blocks, void* stream) {
   }
   dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(PF_WGRAD_DIRECT, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("wgrad_mfma2_kernel");

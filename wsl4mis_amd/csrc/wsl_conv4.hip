@@ -210,7 +210,7 @@ static int launch_wgrad_small(WgSmallP& p, void* stream) {
     attr_done = true;
   }
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(2, 2.0 * px * 16 * CBN * 9, 4.0 * px * (16 + CBN), stream);
+  void* tok = prof_begin(PF_WGRAD_DIRECT, 2.0 * px * 16 * CBN * 9, 4.0 * px * (16 + CBN), stream);
   WSL_LAUNCH(kern, dim3(p.nsplit), dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("wgrad_small_kernel");

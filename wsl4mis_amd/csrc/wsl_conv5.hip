@@ -834,6 +834,9 @@ __global__ __launch_bounds__(256) void wino_pack_table_kernel(PackTable t, const
 }
 
 int wino_pack_table(const PackTable& t, const float* params, float* uf, float* ud, int with_dgrad, void* stream) {
+  double e = 0.0;
+  for (int i = 0; i < t.n; ++i) e += t.e[i].KK == 9 ? (double)t.e[i].Co * t.e[i].Ci : 0.0;
+  ProfScope ps(PF_PREP, 0.0, 4.0 * e * (9.0 + 16.0 * (with_dgrad ? 2.0 : 1.0)), stream);
   WSL_LAUNCH(wino_pack_table_kernel, dim3(16, t.n, with_dgrad ? 2 : 1), dim3(kThreads), 0, stream, t, params, uf, ud);
   return check_launch("wino_pack_table_kernel");
 }
@@ -888,7 +891,8 @@ static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(is_dgrad ? 7 : 6, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
+                         2.0 * px * p.Co * p.Ci * 4);   // issued: 16 instead of 36 multiply-adds per 2x2 tile
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_wino2r_kernel");
@@ -908,7 +912,8 @@ static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(is_dgrad ? 7 : 6, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
+                         2.0 * px * p.Co * p.Ci * 4);   // issued: 16 instead of 36 multiply-adds per 2x2 tile
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_wino2_kernel");
@@ -926,7 +931,8 @@ static int launch_wino(WinoP& p, int is_dgrad, void* stream) {
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
   const double px = (double)p.N * p.H * p.W;
   // priced at the DIRECT algorithm's flops (9 multiply-adds per pixel and channel pair): the algorithmic work
-  void* tok = prof_begin(is_dgrad ? 7 : 6, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
+                         2.0 * px * p.Co * p.Ci * 4);   // issued: 16 instead of 36 multiply-adds per 2x2 tile
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_wino_kernel");
@@ -1273,7 +1279,7 @@ static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
   }
   dim3 grid(p.co_blocks * ci_blocks, p.nsplit);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(2, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(PF_WGRAD_WINO, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream, 2.0 * px * p.Co * p.Ci * 4);
   WSL_LAUNCH(kern, grid, dim3(C::THREADS), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("wgrad_wino_kernel");

@@ -878,6 +878,9 @@ extern "C" int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t*
   const int HW_ = HW;
   WSL_WS_OK("head_fwd_bwd");
   HeadP h{z1, z2, label, ignore, C, HW, N, (int64_t)N * HW, (float)beta, (float)(1.0 - beta)};
+  // forward reads the logits + 1 B label; backward reads them again and writes the logit gradients
+  const double nbr = z2 ? 2.0 : 1.0;
+  ProfScope ps(PF_LOSS_HEAD, 0.0, (double)N * HW * ((dz1 ? 2.0 : 1.0) * (4.0 * C * nbr + 1.0) + (dz1 ? 4.0 * C * nbr : 0.0) + (pseudo ? 8.0 : 0.0)), stream);
   const int nb = grid_for(h.P);
   float* part = static_cast<float*>(ws);
   float* scal = part + (size_t)kMaxBlocks * kMaxK;
@@ -904,7 +907,7 @@ extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, fl
   const int TSX = kCrfTW + 2 * radius, TSY = kCrfTH + 2 * radius;
   const size_t smem = sizeof(float) * ((size_t)(C + 1) * TSX * TSY + TSX + TSY);
   float* part = static_cast<float*>(ws);
-  void* tok = prof_begin(4, 0.0, 4.0 * (double)N * H * W * (2 * C + 1), stream);
+  void* tok = prof_begin(PF_GATEDCRF, 0.0, 4.0 * (double)N * H * W * (2 * C + 1), stream);   // 36 B/px at C = 4
   if (C == 4) WSL_LAUNCH((gatedcrf_fwd_kernel<4>), dim3(nb), dim3(kThreads), smem, stream, q, part);
   else if (C == 2) WSL_LAUNCH((gatedcrf_fwd_kernel<2>), dim3(nb), dim3(kThreads), smem, stream, q, part);
   else WSL_LAUNCH((gatedcrf_fwd_kernel<0>), dim3(nb), dim3(kThreads), smem, stream, q, part);
@@ -1013,6 +1016,7 @@ extern "C" int wsl_entropy_fwd_bwd(const float* p, float* loss, float* dp, float
 extern "C" int wsl_mixprob_fwd(const float* z1, const float* z2, double beta, float* y, int N, int C, int HW, void* stream) {
   WSL_REQUIRE(z1 && y && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "mixprob_fwd: bad args");
   const int64_t P = (int64_t)N * HW;
+  ProfScope ps(PF_LOSS_HEAD, 0.0, (double)P * 4.0 * C * (z2 ? 3.0 : 2.0), stream);
   if (C == 4) WSL_LAUNCH((mixprob_fwd_kernel<4>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), y, C, HW, P);
   else WSL_LAUNCH((mixprob_fwd_kernel<0>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), y, C, HW, P);
   return check_launch("mixprob_fwd_kernel");
@@ -1022,6 +1026,8 @@ extern "C" int wsl_mixprob_bwd(const float* z1, const float* z2, double beta, co
                                float* dz2, int accumulate, int N, int C, int HW, void* stream) {
   WSL_REQUIRE(z1 && dy && dz1 && (!z2 || dz2) && N > 0 && HW > 0 && C > 0 && C <= kMaxC, "mixprob_bwd: bad args");
   const int64_t P = (int64_t)N * HW;
+  const double nbr_ = z2 ? 2.0 : 1.0;     // reads the logits and dy, reads (accumulate) and writes the logit gradients
+  ProfScope ps(PF_LOSS_HEAD, 0.0, (double)P * 4.0 * C * (nbr_ + 1.0 + nbr_ * (accumulate ? 2.0 : 1.0)), stream);
   if (C == 4) WSL_LAUNCH((mixprob_bwd_kernel<4>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), dy, k, dz1, dz2, accumulate, C, HW, P);
   else WSL_LAUNCH((mixprob_bwd_kernel<0>), dim3(grid_for(P)), dim3(kThreads), 0, stream, z1, z2, (float)beta, (float)(1.0 - beta), dy, k, dz1, dz2, accumulate, C, HW, P);
   return check_launch("mixprob_bwd_kernel");

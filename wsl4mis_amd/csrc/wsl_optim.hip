@@ -117,6 +117,9 @@ extern "C" int wsl_draw_masks(int n_masks, void* const* outs, const int64_t* num
   int64_t blocks = (biggest / 4 + kThreads - 1) / kThreads;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
+  double mbytes = 0.0;
+  for (int i = 0; i < n_masks; ++i) mbytes += (double)numels[i] * (is_f32[i] ? 4.0 : 1.0);
+  ProfScope ps(PF_PREP, 0.0, mbytes, stream);
   WSL_LAUNCH(masks_kernel, dim3((unsigned)blocks, n_masks), dim3(kThreads), 0, stream, t, (uint32_t)seed,
              (uint32_t)(seed >> 32));
   return check_launch("masks_kernel");
@@ -127,6 +130,7 @@ extern "C" int wsl_sgd_step(float* p, const float* grad, float* buf, int64_t n, 
   WSL_REQUIRE(p && grad && buf && n > 0, "sgd_step: bad args");
   auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool vec = al(p) && al(grad) && al(buf) && (!ema || al(ema));
+  ProfScope ps(PF_SGD, 0.0, (double)n * (20.0 + (ema ? 8.0 : 0.0)), stream);      // read p, g, buf; write p, buf (+ ema r/w)
   int64_t blocks = (n / 4 + kThreads - 1) / kThreads;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;

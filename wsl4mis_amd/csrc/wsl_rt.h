@@ -44,10 +44,21 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 namespace wsl {
 
 void set_error(const char* fmt, ...);
-// opt-in HIP-event bracketing of one launch (wsl_api.hip); fam: 0 conv fwd, 1 conv dgrad, 2 wgrad, 3 wgrad reduce,
-// 4 gatedcrf, 5 other, 6 Winograd conv fwd, 7 Winograd conv dgrad
-void* prof_begin(int fam, double flops, double bytes, void* stream);
+// opt-in HIP-event bracketing of one launch (or one entry point's launches) on the stream they are enqueued on (wsl_api.hip).
+// flops / bytes are the ALGORITHMIC ones; issued < 0 means "= flops".
+enum ProfFam {
+  PF_CONV_FWD = 0, PF_CONV_DGRAD = 1, PF_WGRAD_WINO = 2, PF_WGRAD_REDUCE = 3, PF_GATEDCRF = 4, PF_OTHER = 5, PF_WINO_FWD = 6,
+  PF_WINO_DGRAD = 7, PF_WGRAD_DIRECT = 8, PF_BN_BWD = 9, PF_BN_FINALIZE = 10, PF_BILINEAR = 11, PF_POOL_FANIN = 12,
+  PF_LOSS_HEAD = 13, PF_SGD = 14, PF_PREP = 15
+};
+void* prof_begin(int fam, double flops, double bytes, void* stream, double issued = -1.0);
 void prof_end(void* tok, void* stream);
+struct ProfScope {
+  void *tok, *stream;
+  ProfScope(int fam, double flops, double bytes, void* s, double issued = -1.0) : tok(prof_begin(fam, flops, bytes, s, issued)), stream(s) {}
+  ~ProfScope() { prof_end(tok, stream); }
+  ProfScope(const ProfScope&) = delete;
+};
 int check_launch(const char* what);
 int device_cu_count();   // compute units of the current device (cached)
 // Library-owned side stream for work that is independent of the caller's stream for a while (the second decoder of

@@ -36,18 +36,25 @@ class BaseDataSets(Dataset):
     FOLDS = ("fold1", "fold2", "fold3", "fold4", "fold5")
 
     def __init__(self, base_dir=None, num=4, labeled_type="labeled", split="train", transform=None, fold="fold1",
-                 sup_type="label"):
+                 sup_type="label", cache=False):
         if fold not in self.FOLDS:
             raise ValueError(f"unknown fold {fold!r} (the reference returns 'ERROR KEY' here and fails later)")
         self._base_dir, self.split, self.sup_type, self.transform = base_dir, split, sup_type, transform
         self.num, self.labeled_type = num, labeled_type
+        # cache=True (not in the reference): decoded arrays are kept in host memory after the first read -- h5lite inflates in
+        # Python, and a 60000-iteration run touches each of the ~1500 slice files ~500 times
+        self._cache = {} if cache else None
         k = self.FOLDS.index(fold)
         test_ids = ["patient{:0>3}".format(i) for i in range(20 * k + 1, 20 * k + 21)]
         train_ids = [p for p in ("patient{:0>3}".format(i) for i in range(1, 101)) if p not in test_ids]
         labeled = [p for p in ("patient{:0>3}".format(10 * i) for i in range(1, 11)) if p in train_ids]
         if split == "train":
             files = os.listdir(os.path.join(base_dir, "ACDC_training_slices"))
-            chosen = labeled if labeled_type == "labeled" else [p for p in train_ids if p not in labeled]
+            # labeled_type: 'labeled' | anything else = the unlabeled remainder, like the reference; 'all' (extension) = every
+            # training patient of the fold -- what the weakly-supervised scripts of upstream WSL4MIS train on (every slice
+            # has a scribble), which the fold-aware class shipped in this reference cannot express
+            chosen = labeled if labeled_type == "labeled" else train_ids if labeled_type == "all" else \
+                [p for p in train_ids if p not in labeled]
         elif split == "val":
             files = os.listdir(os.path.join(base_dir, "ACDC_training_volumes"))
             chosen = test_ids
@@ -60,10 +67,15 @@ class BaseDataSets(Dataset):
 
     def __getitem__(self, idx):
         case = self.sample_list[idx]
-        sub = "ACDC_training_slices" if self.split == "train" else "ACDC_training_volumes"
-        with h5lite.File(os.path.join(self._base_dir, sub, case)) as f:
-            image = f["image"][:]
-            label = f[self.sup_type if self.split == "train" else "label"][:]
+        if self._cache is not None and case in self._cache:
+            image, label = self._cache[case]
+        else:
+            sub = "ACDC_training_slices" if self.split == "train" else "ACDC_training_volumes"
+            with h5lite.File(os.path.join(self._base_dir, sub, case)) as f:
+                image = f["image"][:]
+                label = f[self.sup_type if self.split == "train" else "label"][:]
+            if self._cache is not None:
+                self._cache[case] = (image, label)
         sample = {"image": image, "label": label}
         if self.split == "train" and self.transform is not None:
             sample = self.transform(sample)
@@ -71,15 +83,16 @@ class BaseDataSets(Dataset):
         return sample
 
 
-def draw_params(label_np):
-    """The reference's random decisions for ONE sample, same draw order and generators (dataset_semi.py:155-161)."""
+def draw_params(label_np, has_ignore=None):
+    """The reference's random decisions for ONE sample, same draw order and generators (dataset_semi.py:155-161).
+    has_ignore: precomputed `4 in np.unique(label)` (then label_np is not read)."""
     p = {"op": 0}
     if random.random() > 0.5:
         p["op"], p["k"] = 1, int(np.random.randint(0, 4))
         p["axis"] = int(np.random.randint(0, 2))
     elif random.random() > 0.5:
         p["op"], p["angle"] = 2, int(np.random.randint(-20, 20))
-        p["lab_cval"] = 4 if 4 in np.unique(label_np) else 0
+        p["lab_cval"] = 4 if (has_ignore if has_ignore is not None else 4 in np.unique(label_np)) else 0
     return p
 
 
@@ -117,8 +130,8 @@ def augment_batch(images, labels, params, output_size):
     out_img = torch.empty((n, 1, Ho, Wo), dtype=torch.float32, device=dev)
     out_lab = torch.empty((n, Ho, Wo), dtype=torch.uint8, device=dev)
     _lib.check(L.wsl_augment_batch(arr, n, rt.ptr(out_img), rt.ptr(out_lab), Ho, Wo, rt.stream()))
-    if dev.type == "cuda":
-        torch.cuda.current_stream().synchronize()   # the descriptor array and the staged inputs may go out of scope
+    # no host sync: the descriptors were copied into the launch's kernel arguments, and the staged inputs are released through
+    # torch's stream-ordered allocator on this same stream
     return out_img, out_lab
 
 
@@ -138,12 +151,30 @@ class RandomGenerator(object):
 class BatchRandomGenerator(object):
     """The batched form the engine wants: a list of samples in, one device batch out (one kernel launch)."""
 
-    def __init__(self, output_size):
+    def __init__(self, output_size, device_cache=False):
+        """device_cache: keep each distinct source array on the device after its first use (keyed by the identity of the
+        numpy arrays a caching BaseDataSets hands out), so a step stages nothing over PCIe."""
         self.output_size = output_size
+        self._dev = {} if device_cache else None
+
+    def _staged(self, s):
+        key = (id(s["image"]), id(s["label"]))
+        hit = self._dev.get(key)
+        if hit is None:
+            lab = np.asarray(s["label"])
+            hit = (torch.as_tensor(np.asarray(s["image"]), dtype=torch.float32).to(rt.device()).contiguous(),
+                   torch.as_tensor(lab, dtype=torch.uint8).to(rt.device()).contiguous(), bool(4 in np.unique(lab)),
+                   s["image"], s["label"])                    # (the arrays themselves: keeps the ids alive)
+            self._dev[key] = hit
+        return hit
 
     def __call__(self, samples):
-        params = [draw_params(np.asarray(s["label"])) for s in samples]     # the reference's per-sample draw order
-        return augment_batch([s["image"] for s in samples], [s["label"] for s in samples], params, self.output_size)
+        if self._dev is None:
+            params = [draw_params(np.asarray(s["label"])) for s in samples]     # the reference's per-sample draw order
+            return augment_batch([s["image"] for s in samples], [s["label"] for s in samples], params, self.output_size)
+        st = [self._staged(s) for s in samples]
+        params = [draw_params(None, has_ignore=t[2]) for t in st]
+        return augment_batch([t[0] for t in st], [t[1] for t in st], params, self.output_size)
 
 
 class TwoStreamBatchSampler(Sampler):

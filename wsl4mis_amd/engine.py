@@ -73,6 +73,7 @@ class TrainEngine:
             dist.broadcast(self.model._param_arena, src=0)
             dist.broadcast(self.model._buf_arena, src=0)
         self._bufs = {}
+        self._diag = None                                  # comm_diag(True): [(event, event)] around the waits for the comm stream
         self.teacher = None
         self._tstream, self._zt = None, None
         self.concurrent = os.environ.get("WSL_NET_CONCURRENT") != "0"   # side streams (teacher forward); see DESIGN 4
@@ -288,9 +289,28 @@ class TrainEngine:
             m._run_backward(x, g, phase=2)
             self._allreduce(flat_g[:m.n_enc_param])
             if self.comm is not None:
-                torch.cuda.current_stream().wait_stream(self.comm)
+                cur = torch.cuda.current_stream()
+                if self._diag is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                    cur.wait_stream(self.comm)
+                    e1.record(cur)
+                    self._diag.append((e0, e1))
+                else:
+                    cur.wait_stream(self.comm)
         else:
             m._run_backward(x, g, phase=0)
+
+    def comm_diag(self, on):
+        """on=True: start timing how long the main stream sits blocked on the all-reduce stream at the end of every backward;
+        on=False: stop, return the total in ms (host sync on the recorded events)."""
+        if on:
+            self._diag = []
+            return 0.0
+        pairs, self._diag = self._diag or [], None
+        if pairs:
+            pairs[-1][1].synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in pairs))
 
     def optimizer_step(self):
         m = self.model

@@ -60,30 +60,31 @@ def hd95_percase(pred, gt, voxelspacing=None):
     return hi_v - diff * (1 - t) if t >= 0.5 else lo_v + diff * t
 
 
-def metric_percase(pred, gt):
+def metric_percase(pred, gt, with_hd95=True):
     """ref: val_2D.py:7-15 calculate_metric_percase -> (dice, hd95), (0, 0) when nothing is predicted."""
     pred, gt = np.asarray(pred) > 0, np.asarray(gt) > 0
     if pred.sum() > 0:
-        return dice_percase(pred, gt), hd95_percase(pred, gt)
+        return dice_percase(pred, gt), (hd95_percase(pred, gt) if with_hd95 else 0.0)
     return 0, 0
 
 
-def _predict_volume(image, net, patch_size, first_output):
+def _predict_volume(image, net, patch_size, first_output, slices_per_forward=16):
+    """The reference feeds one slice per forward (val_2D.py:22-37, 94-111); the eval forward is per-sample (BatchNorm uses its
+    running statistics -- bit-equality of a batch and its parts is tested), so the zoomed slices go through in batches."""
     image = np.asarray(image, dtype=np.float32)
     prediction = np.zeros(image.shape, dtype=np.uint8)
     net.eval()
-    for ind in range(image.shape[0]):
-        slc = image[ind]
-        x, y = slc.shape
-        inp = zoom(slc, (patch_size[0] / x, patch_size[1] / y), order=0)
-        t = torch.from_numpy(np.ascontiguousarray(inp, dtype=np.float32))[None, None].to(rt.device())
+    x, y = image.shape[1:]
+    for i0 in range(0, image.shape[0], slices_per_forward):
+        inp = np.stack([zoom(slc, (patch_size[0] / x, patch_size[1] / y), order=0) for slc in image[i0:i0 + slices_per_forward]])
+        t = torch.from_numpy(np.ascontiguousarray(inp, dtype=np.float32))[:, None].to(rt.device())
         with torch.no_grad():
             out = net(t)
             if first_output and isinstance(out, (tuple, list)):
                 out = out[0]                      # val_2D.py:104: only the main branch is evaluated
-            lab = torch.argmax(out, dim=1)[0]     # argmax(softmax(z)) == argmax(z)
-        pred = zoom(lab.cpu().numpy().astype(np.uint8), (x / patch_size[0], y / patch_size[1]), order=0)
-        prediction[ind] = pred
+            lab = torch.argmax(out, dim=1).cpu().numpy().astype(np.uint8)     # argmax(softmax(z)) == argmax(z)
+        for k in range(lab.shape[0]):
+            prediction[i0 + k] = zoom(lab[k], (x / patch_size[0], y / patch_size[1]), order=0)
     return prediction
 
 
@@ -92,22 +93,22 @@ def _squeeze(v):
     return a[0] if a.ndim == 4 else a            # DataLoader batch dimension of the reference (val_2D.py:19-20)
 
 
-def test_single_volume(image, label, net, classes, patch_size=(256, 256)):
+def test_single_volume(image, label, net, classes, patch_size=(256, 256), with_hd95=True):
     image, label = _squeeze(image), _squeeze(label)
     if image.ndim != 3:
         raise NotImplementedError("2-D slices of a [D,H,W] volume are the built path (the reference's else-branch "
                                   "feeds a single image)")
     prediction = _predict_volume(image, net, patch_size, first_output=False)
-    return [metric_percase(prediction == i, label == i) for i in range(1, classes)]
+    return [metric_percase(prediction == i, label == i, with_hd95) for i in range(1, classes)]
 
 
-def test_single_volume_cct(image, label, net, classes, patch_size=(256, 256)):
+def test_single_volume_cct(image, label, net, classes, patch_size=(256, 256), with_hd95=True):
     image, label = _squeeze(image), _squeeze(label)
     if image.ndim != 3:
         raise NotImplementedError("2-D slices of a [D,H,W] volume are the built path (val_2D.py:116 unpacks four "
                                   "outputs in its else-branch, which no 2-D net returns)")
     prediction = _predict_volume(image, net, patch_size, first_output=True)
-    return [metric_percase(prediction == i, label == i) for i in range(1, classes)]
+    return [metric_percase(prediction == i, label == i, with_hd95) for i in range(1, classes)]
 
 
 test_single_volume.__test__ = False        # (names kept from the reference; not pytest cases)
