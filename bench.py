@@ -14,7 +14,7 @@ step on one batch of 64 slices per GPU, inputs resident in HBM.  Prints ONE JSON
 unet_cct runs its two decoders on two streams (+5 % step rate; mean teacher: the teacher's forward), so in the timed region launches of the dominant kernel
 overlap each other and a per-launch duration no longer measures the kernel.  The `roofline` object is therefore taken
 from a short second segment of the same workload in the same process with the decoders serialised
-(`wsl_debug_net_concurrent(0)`), where launches do not overlap; the timed region's own (overlapping) per-launch figures
+(`wsl_net_concurrent(0)`), where launches do not overlap; the timed region's own (overlapping) per-launch figures
 are reported next to it as `roofline.timed_region_overlapped`.  `--serial-decoders` serialises the timed region too.
 """
 import argparse
@@ -151,11 +151,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path in the product)")
     torch.cuda.set_device(local)
-    if world > 1 or args.force_dp:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.force_dp:
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local))
     from wsl4mis_amd import _lib
     from wsl4mis_amd.engine import TrainEngine
     from wsl4mis_amd.synthetic import batch
@@ -168,12 +174,11 @@ def main():
     random.seed(2022)                                         # identical beta stream on all ranks
     L = _lib.lib()
     if args.serial_decoders:
-        L.wsl_debug_net_concurrent(0)
+        L.wsl_net_concurrent(0)
         eng.concurrent = False
     for _ in range(args.warmup):
         eng.step(x, lab, random.random() + 1e-10)
-    overlapped = (args.net == "unet_cct" or args.loss == "mean_teacher") and not args.serial_decoders and \
-        os.environ.get("WSL_NET_CONCURRENT") != "0"
+    overlapped = (args.net == "unet_cct" or args.loss == "mean_teacher") and not args.serial_decoders
     # per-launch HIP events cost ~2 % of the step rate: when the roofline comes from its own serialised segment anyway
     # (overlapped run) the timed region stays uninstrumented unless --prof-timed asks for its overlapping figures too
     prof_timed = not args.no_prof and (not overlapped or args.prof_timed)
@@ -328,7 +333,7 @@ def main():
             if roof:
                 timed = {k: roof[k] for k in ("achieved", "frac", "launches", "avg_launch_us", "all_mfma_kernels_tflops")}
             seg = max(1, min(args.steps, 5))
-            L.wsl_debug_net_concurrent(0)
+            L.wsl_net_concurrent(0)
             eng.concurrent = False
             eng.step(x, lab, random.random() + 1e-10)
             L.wsl_prof_enable(1)
@@ -339,7 +344,7 @@ def main():
             torch.cuda.synchronize()
             seg_ms = 1e3 * (time.perf_counter() - ts) / seg
             rows2, fams = report()
-            L.wsl_debug_net_concurrent(1)
+            L.wsl_net_concurrent(1)
             eng.concurrent = True
             roof = roofline_of(rows2, seg, 1e3 * dt / args.steps)
             if roof:

@@ -91,35 +91,15 @@ int wsl_conv2d_fast_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t
  * wsl_conv2d_wino_ok() != 0: ks 3, (Ca + Cb) % 8 == 0 and <= 256, Ca % 8 == 0 when there are two sources, Co % 16 == 0,
  * (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0), plus the wsl_conv2d_fast_ok() alignment.  Results agree
  * with the direct kernels to fp32 round-off (~1e-6 relative); same BatchNorm partial layout and block count.
- * Env WSL_CONV_WINO / wsl_debug_conv_wino(): 0 off (wino_ok() returns 0), 1 only layers with Co % 32 == 0, 2 (default)
- * also layers with Co % 16 == 0; wsl_debug_conv_wino(-1) re-reads the environment.  Env WSL_WINO_FORM=1 selects the first
- * form of the kernel (input transform through LDS) instead of the register-resident one. */
+ * The product library reads no environment variable and exports no tuning switch; the test hooks that force a tile shape or
+ * switch the Winograd path off live in the private header wsl4mis_amd/csrc/wsl_debug.h. */
 int wsl_conv2d_wino_ok(int N, int H, int W, int Ca, int Cb, int Co, int ks);
-int wsl_debug_conv_wino(int on);
-/* Kernel variants kept for A/B timing (both measured, see profiles/r1z_winograd.md): conv_form 1 = the first form of the
- * Winograd conv kernel (input transform through LDS), 2 = default (transform in the MFMA operand registers); wgrad_waves 8 =
- * the Winograd weight gradient as one 8-wave double-buffered workgroup per CU, 4 = default.  Any other value re-reads the
- * environment (WSL_WINO_FORM, WSL_WGRAD_WINO_WAVES).  The weight gradient of conv2d_wgrad() itself takes its Winograd form
- * automatically for 3x3 layers with 16- or 32-aligned channel counts (env WSL_WGRAD_WINO=0 switches it off). */
-int wsl_debug_wino_variant(int conv_form, int wgrad_waves);
-/* Debug / experiments: which packed-path kernel wsl_conv2d_fwd(wmode 2|3) launches: 2 = lock-step workgroups with a
- * register prefetch (default, fastest measured), 3 = wave-specialised persistent workgroups (wsl_conv3.hip). */
-int wsl_debug_conv_variant(int v);
-/* Force the conv tile shape (rows, columns, output-channel block) wherever it divides the layer; th <= 0 restores the
- * built-in per-layer table.  Tests use it to run every kernel instantiation at small sizes; env WSL_CONV_PLAN=th,tw,co_t. */
-int wsl_debug_conv_plan(int th, int tw, int co_t);
-/* unet_cct runs its auxiliary decoder (forward and backward) on a library-owned side stream, forked from / joined to the
- * caller's stream with events, so the two independent decoders fill each other's launch gaps and workgroup tails
- * (+5 % step rate).  0 serialises everything on the caller's stream (per-launch timings then do not overlap: what
- * bench.py's roofline segment and profiles/ use); 1 restores the default.  Env WSL_NET_CONCURRENT=0 does the same. */
-int wsl_debug_net_concurrent(int on);
-/* Operand-layout probe of v_mfma_f32_4x4x1_16b_f32 (64 lanes: a[64], b[64] -> d[64][4]); tools/probe_mfma4.py. */
-int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, void* stream);
-/* Pure f32 MFMA stream (no memory traffic): shape 0 = 16x16x4, 1 = 32x32x2, 2 = 4x4x1; `blocks` workgroups of 4 waves,
- * 16 MFMAs per iteration and wave (tools/mfma_ceiling.py: the practical matrix ceiling at the sustained clock). */
-int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* out, void* stream);
-/* Destination-layout probe of global_load_lds_dwordx4: g[1024] -> out[2048] (the LDS image; tools/probe_lds_dma.py). */
-int wsl_debug_lds_dma_probe(const float* g, float* out, void* stream);
+/* Threading option.  unet_cct runs its auxiliary decoder (forward and backward) on a library-owned side stream, forked from /
+ * joined to the caller's stream with events, so the two independent decoders fill each other's launch gaps and workgroup
+ * tails (+5 % step rate).  One side stream + event pair exists per (device, caller stream).  on = 0 serialises everything on
+ * the caller's stream (per-launch timings then do not overlap: what bench.py's roofline segment and profiles/ use); 1 restores
+ * the default. */
+int wsl_net_concurrent(int on);
 
 /* dw[Co][Ci][ks][ks] = sum_{n,y,x} dy[n,co,y,x] * in[n,ci,y+ky-p,x+kx-p];  db[Co] = sum dy  (db may be NULL).
  * Split over pixels into partials in `ws`, then an order-fixed second stage. */

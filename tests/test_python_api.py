@@ -374,16 +374,16 @@ def test_engine_gatedcrf_curve_against_reference(mode):
 
 
 def test_two_stream_decoders_are_bit_identical_to_one_stream(mode):
-    """unet_cct runs its auxiliary decoder on a side stream (wsl_debug_net_concurrent): same bits either way"""
+    """unet_cct runs its auxiliary decoder on a side stream (wsl_net_concurrent): same bits either way"""
     if mode != "hip":
         pytest.skip("streams only exist on the device")
     from wsl4mis_amd import _lib
     outs = []
     for conc in (1, 0, 1):
-        _lib.lib().wsl_debug_net_concurrent(conc)
+        _lib.lib().wsl_net_concurrent(conc)
         got, _, eng = run_curve(3)
         outs.append((got, eng.model.flat_params().clone(), eng.model.flat_grads().clone()))
-    _lib.lib().wsl_debug_net_concurrent(1)
+    _lib.lib().wsl_net_concurrent(1)
     for got, prm, grd in outs[1:]:
         assert np.array_equal(got, outs[0][0]) and torch.equal(prm, outs[0][1]) and torch.equal(grd, outs[0][2])
 

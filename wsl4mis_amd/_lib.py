@@ -56,19 +56,12 @@ _PROTOS = {
     "wsl_build_info": (C.c_char_p, []),
     "wsl_prof_enable": (i32, [i32]),
     "wsl_prof_report": (i32, [C.POINTER(WslProfRow), i32]),
+    "wsl_net_concurrent": (i32, [i32]),
     "wsl_conv2d_fwd": (i32, [PS, PS, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
     "wsl_conv2d_stat_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "wsl_conv2d_pack_weights": (i32, [c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "wsl_conv2d_fast_ok": (i32, [PS, PS, c_fp, i64, i32]),
-    "wsl_debug_conv_variant": (i32, [i32]),
-    "wsl_debug_conv_plan": (i32, [i32, i32, i32]),
     "wsl_conv2d_wino_ok": (i32, [i32, i32, i32, i32, i32, i32, i32]),
-    "wsl_debug_conv_wino": (i32, [i32]),
-    "wsl_debug_wino_variant": (i32, [i32, i32]),
-    "wsl_debug_net_concurrent": (i32, [i32]),
-    "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
-    "wsl_debug_lds_dma_probe": (i32, [c_fp, c_fp, c_fp]),
-    "wsl_debug_mfma_stream": (i32, [i32, i32, i32, c_fp, c_fp]),
     "wsl_conv2d_wgrad": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "wsl_bn_stats_finalize": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, f32, f32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
@@ -120,6 +113,18 @@ _PROTOS = {
 }
 
 
+# private hooks (wsl4mis_amd/csrc/wsl_debug.h): bound when the loaded library has them; tests and tools only
+_DEBUG_PROTOS = {
+    "wsl_debug_conv_plan": (i32, [i32, i32, i32]),
+    "wsl_debug_conv_wino": (i32, [i32]),
+    "wsl_debug_wino_variant": (i32, [i32, i32]),          # EXPERIMENTS build only, like the three below
+    "wsl_debug_conv_variant": (i32, [i32]),
+    "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
+    "wsl_debug_lds_dma_probe": (i32, [c_fp, c_fp, c_fp]),
+    "wsl_debug_mfma_stream": (i32, [i32, i32, i32, c_fp, c_fp]),
+}
+
+
 class WslError(RuntimeError):
     pass
 
@@ -134,6 +139,10 @@ def bind(cdll, strict=True):
             missing.append(name)
             continue
         fn.restype, fn.argtypes = res, args
+    for name, (res, args) in _DEBUG_PROTOS.items():
+        if hasattr(cdll, name):
+            fn = getattr(cdll, name)
+            fn.restype, fn.argtypes = res, args
     if missing and strict:
         raise WslError(f"library lacks symbols declared in include/wsl_hip.h: {missing}")
     return missing

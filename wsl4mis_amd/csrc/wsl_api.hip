@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "wsl_rt.h"
@@ -44,32 +45,48 @@ int device_cu_count() {
 }
 
 #ifndef WSL_HOST_EMUL
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
-static int g_conc = -1;   // -1: not decided yet (environment), 0 off, 1 on
+// One side stream + fork/join event pair per (device, caller stream): two networks driven from different streams (or on
+// different devices) never share them; networks enqueued on the same caller stream are ordered by it anyway.  The table is the
+// library's only process-global mutable state besides the profiling records; it is guarded by a mutex.
+struct SideCtx { int dev; hipStream_t main, side; hipEvent_t fork, join; };
+static std::vector<SideCtx> g_sides;
+static std::mutex g_side_mu;
+static int g_conc = 1;   // wsl_net_concurrent(): 1 on (default), 0 off
 void set_concurrent(int on) { g_conc = on ? 1 : 0; }
-void* side_stream() {
-  if (g_conc < 0) g_conc = (getenv("WSL_NET_CONCURRENT") && atoi(getenv("WSL_NET_CONCURRENT")) == 0) ? 0 : 1;
+static SideCtx* side_ctx(void* main) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  for (auto& c : g_sides)
+    if (c.dev == dev && c.main == (hipStream_t)main) return &c;
+  SideCtx c{dev, (hipStream_t)main, nullptr, nullptr, nullptr};
+  if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess)
+    return nullptr;
+  g_sides.reserve(64);     // pointers into the table stay valid: it never grows past its reservation
+  if (g_sides.size() >= 64) return nullptr;
+  g_sides.push_back(c);
+  return &g_sides.back();
+}
+void* side_stream(void* main) {
   if (!g_conc) return nullptr;
-  if (!g_side) {
-    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
-      g_side = nullptr;
-      return nullptr;
-    }
-  }
-  return g_side;
+  SideCtx* c = side_ctx(main);
+  return c ? (void*)c->side : nullptr;
 }
 int stream_fork(void* main, void* side) {
-  if (hipEventRecord(g_ev_fork, (hipStream_t)main) != hipSuccess || hipStreamWaitEvent((hipStream_t)side, g_ev_fork, 0) != hipSuccess) {
+  SideCtx* c = side_ctx(main);
+  if (!c || (void*)c->side != side || hipEventRecord(c->fork, (hipStream_t)main) != hipSuccess ||
+      hipStreamWaitEvent((hipStream_t)side, c->fork, 0) != hipSuccess) {
     set_error("stream_fork: HIP error");
     return WSL_EHIP;
   }
   return WSL_OK;
 }
 int stream_join(void* main, void* side) {
-  if (hipEventRecord(g_ev_join, (hipStream_t)side) != hipSuccess || hipStreamWaitEvent((hipStream_t)main, g_ev_join, 0) != hipSuccess) {
+  SideCtx* c = side_ctx(main);
+  if (!c || (void*)c->side != side || hipEventRecord(c->join, (hipStream_t)side) != hipSuccess ||
+      hipStreamWaitEvent((hipStream_t)main, c->join, 0) != hipSuccess) {
     set_error("stream_join: HIP error");
     return WSL_EHIP;
   }
@@ -77,7 +94,7 @@ int stream_join(void* main, void* side) {
 }
 #else
 void set_concurrent(int) {}
-void* side_stream() { return nullptr; }
+void* side_stream(void*) { return nullptr; }
 int stream_fork(void*, void*) { return WSL_OK; }
 int stream_join(void*, void*) { return WSL_OK; }
 #endif
@@ -153,7 +170,7 @@ extern "C" int wsl_prof_report(WslProfRow* rows, int max_rows) {
   return WSL_PROF_FAMILIES;
 }
 
-extern "C" int wsl_debug_net_concurrent(int on) {
+extern "C" int wsl_net_concurrent(int on) {
   wsl::set_concurrent(on);
   return WSL_OK;
 }

@@ -547,7 +547,7 @@ extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const
   float* coef = part + (size_t)N * p.chunks * C * 2;
   dim3 grid(p.chunks, C, N);
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  static const bool vec_on = !(getenv("WSL_BN_VEC") && atoi(getenv("WSL_BN_VEC")) == 0);
+  static const bool vec_on = (WSL_TUNE("WSL_BN_VEC", 1) != 0);
   const bool vec = vec_on && (H * W) % 4 == 0 && (g_bs % 4) == 0 && al16(g) && al16(y) && al16(dy) &&
                    (!emask || (reinterpret_cast<uintptr_t>(emask) & 3) == 0);
   if (vec) WSL_LAUNCH(bnact_bwd_reduce4_kernel, grid, dim3(kThreads), 0, stream, p, part);

@@ -232,8 +232,7 @@ bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, 
 static int g_wino = -1;
 static bool wino_enabled() {
   if (g_wino < 0) {
-    const char* e = getenv("WSL_CONV_WINO");
-    g_wino = e ? atoi(e) : WSL_WINO_DEFAULT;
+    g_wino = WSL_TUNE("WSL_CONV_WINO", WSL_WINO_DEFAULT);
     if (g_wino < 0 || g_wino > 2) g_wino = WSL_WINO_DEFAULT;
   }
   return g_wino != 0;
@@ -242,10 +241,12 @@ static FwdPlan fwd_plan(int N, int H, int W, int Co, int Ci, int ks) {
   FwdPlan f;
   // tuning / test aid: WSL_CONV_PLAN=th,tw,co_t or wsl_debug_conv_plan() force one tile shape wherever it divides the layer
   if (g_forced_plan[0] < 0) {
+    g_forced_plan[0] = 0;
+#ifdef WSL_EXPERIMENTS
     const char* e = getenv("WSL_CONV_PLAN");
     int th = 0, tw = 0, ct = 0;
     if (e && sscanf(e, "%d,%d,%d", &th, &tw, &ct) == 3) g_forced_plan[0] = th, g_forced_plan[1] = tw, g_forced_plan[2] = ct;
-    else g_forced_plan[0] = 0;
+#endif
   }
   if (g_forced_plan[0] > 0) {
     const int th = g_forced_plan[0], tw = g_forced_plan[1], ct = g_forced_plan[2];
@@ -503,7 +504,7 @@ static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co, bool v2 = false, b
   g.tiles_x = cdiv(W, g.tw), g.tiles_y = cdiv(H, g.th);
   g.items = N * g.tiles_x * g.tiles_y;
   g.co_blocks = cdiv(Co, g.cb), g.ci_blocks = cdiv(Ci, g.ib);
-  static const int wgs = getenv("WSL_WGRAD_WGS") ? atoi(getenv("WSL_WGRAD_WGS")) : 768;   // 3 resident workgroups x 256 CUs
+  static const int wgs = WSL_TUNE("WSL_WGRAD_WGS", 768);   // 3 resident workgroups x 256 CUs
   int want = (wide ? 512 : wgs) / (g.co_blocks * g.ci_blocks);
   if (want < 1) want = 1;
   g.nsplit = g.items < want ? g.items : want;
@@ -593,11 +594,13 @@ extern "C" int wsl_conv2d_wino_ok(int N, int H, int W, int Ca, int Cb, int Co, i
   return fwd_plan(N, H, W, Co, Ca + Cb, ks).wino && !conv3_enabled() ? 1 : 0;
 }
 
+#ifdef WSL_EXPERIMENTS
 extern "C" int wsl_debug_conv_variant(int v) {
   WSL_REQUIRE(v == 2 || v == 3, "debug_conv_variant: 2 (lock-step, default) or 3 (wave-specialised, experimental)");
   conv_set_variant(v);
   return WSL_OK;
 }
+#endif
 
 extern "C" int wsl_conv2d_pack_weights(const float* w, float* packed, int Co, int Ci, int ks, int wmode_raw, void* stream) {
   WSL_REQUIRE(w && packed && Co > 0 && Ci > 0 && (ks == 1 || ks == 3) && wmode_raw >= 0 && wmode_raw <= 3,
@@ -654,7 +657,7 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
       WSL_REQUIRE(f.wino && !conv3_enabled(), "conv2d_fwd: wmode %d needs wsl_conv2d_wino_ok() != 0 for this layer", wmode);
       return wino_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, wmode == 5, stat_part, stat_cnt, p.slots, stream);
     }
-    static const bool cls_on = !(getenv("WSL_CONV_CLS") && atoi(getenv("WSL_CONV_CLS")) == 0);
+    static const bool cls_on = (WSL_TUNE("WSL_CONV_CLS", 1) != 0);
     if (cls_on && wmode == 2 && conv_cls_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, stat_part))
       return conv_cls_launch(p.in.a, w, bias, y, y_bs, N, H, W, stream);   // 4-class classifier (wsl_conv4.hip)
     if (conv3_enabled() && p.in.Ci <= 256)   // wave-specialised persistent kernel (wsl_conv3.hip)
@@ -699,7 +702,7 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   if (v2 && g.cb == 32 && wgrad_wino_ok(p.in.a, &p.in.b, H, W, Co, ks, g.th, g.tw, g.cb, g.ib)) {
     // the 32 x 32 Winograd weight gradient holds 128 accumulator registers: 2 resident workgroups per CU -> 512 persistent ones
     // (256 when it runs as one 8-wave double-buffered workgroup per CU)
-    static const int wgs_env = getenv("WSL_WGRAD_WINO_WGS") ? atoi(getenv("WSL_WGRAD_WINO_WGS")) : 0;
+    static const int wgs_env = WSL_TUNE("WSL_WGRAD_WINO_WGS", 0);
     const int wgs = wgs_env > 0 ? wgs_env : (wgrad_wino_waves() == 8 ? 256 : 512);
     int want = wgs / (g.co_blocks * g.ci_blocks);
     if (want < 1) want = 1;
@@ -716,7 +719,7 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   p.part_db = p.part_dw + (size_t)g.nsplit * KK * Co * Ci;
   p.tiles_x = g.tiles_x, p.tiles_y = g.tiles_y, p.items = g.items, p.nsplit = g.nsplit, p.co_blocks = g.co_blocks;
   // a ci-block beyond the first never writes db and a (co,ci) element outside the tensor is never written: no memset
-  static const bool small_on = !(getenv("WSL_WGRAD_SMALL") && atoi(getenv("WSL_WGRAD_SMALL")) == 0);
+  static const bool small_on = (WSL_TUNE("WSL_WGRAD_SMALL", 1) != 0);
   const int small_kind = (v2 && small_on) ? wgrad_small_kind(p.in.a, &p.in.b, H, W, Co, ks) : 0;
   if (small_kind) {   // first convolution / 4-class classifier: one narrow operand (wsl_conv4.hip)
     if (int rc = wgrad_small_launch(small_kind, p.in.a, dy, dy_bs, p.part_dw, p.part_db, N, H, W, g.nsplit, stream)) return rc;

@@ -228,14 +228,14 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
   issue(0);
   __syncthreads();  // BN tables visible
   for (int c0 = 0; c0 < Ci; c0 += KC) {
-    if (!(p.ablate & 2) || c0 == 0) commit(c0);
+    if (!WSL_ABLATED(p, 2) || c0 == 0) commit(c0);
     __syncthreads();
-    if (c0 + KC < Ci && !(p.ablate & 2)) issue(c0 + KC);  // prefetch: in flight during the MFMA loop below
+    if (c0 + KC < Ci && !WSL_ABLATED(p, 2)) issue(c0 + KC);  // prefetch: in flight during the MFMA loop below
     // MFMA loop.  Stages = (tap, channel group); the A/B operands of stage s+1 are read from LDS before the MFMAs of
     // stage s are issued (explicit one-stage software pipeline: profiles/r1b showed ds_read -> waitcnt -> mfma chains).
     // Channels past Ci were staged as zeros, so a short last chunk needs no branch here; a chunk holding <= 4 channels
     // (Ci = 1 or 4 layers) runs the single-group variant.
-    if (!(p.ablate & 1)) {
+    if (!WSL_ABLATED(p, 1)) {
       if (Ci - c0 > 4) conv2_mfma_stages<C, KS, KC, KC / 4>(in_t, w_t, abase, bbase, acc);
       else conv2_mfma_stages<C, KS, KC, 1>(in_t, w_t, abase, bbase, acc);
     }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
   }
 
   // ---- epilogue (identical to v1): bias, float4 stores, BatchNorm partial statistics
-  if (p.ablate & 4) {
+  if (WSL_ABLATED(p, 4)) {
     if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;   // keep the accumulators live
     return;
   }
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINWL)) void 
 
 #ifndef WSL_HOST_EMUL
   // debug timeline (WSL_CONV_ABLATE & 128): thread 0 stamps s_memtime at the phase boundaries of this workgroup
-  uint64_t* tl = (p.ablate & 128) ? reinterpret_cast<uint64_t*>(p.stat_part) + (int64_t)tile_id * 32 : nullptr;
+  uint64_t* tl = WSL_ABLATED(p, 128) ? reinterpret_cast<uint64_t*>(p.stat_part) + (int64_t)tile_id * 32 : nullptr;
 #define WSL_MARK(k) do { if (tl && tid == 0) tl[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
   if (tl && tid == 0) tl[29] = __builtin_amdgcn_s_memrealtime(), tl[28] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
 #else
@@ -474,20 +474,20 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINWL)) void 
     if (tl) __builtin_amdgcn_s_waitcnt(0);   // prefetched data has arrived
 #endif
     WSL_MARK(mk);
-    if (!(p.ablate & 2) || c0 == 0) commit(c0);
+    if (!WSL_ABLATED(p, 2) || c0 == 0) commit(c0);
     WSL_MARK(mk + 1);
     __syncthreads();
     WSL_MARK(mk + 2);
-    if (c0 + KC < Ci && !(p.ablate & 2)) issue(c0 + KC);   // in flight during the MFMA loop below
+    if (c0 + KC < Ci && !WSL_ABLATED(p, 2)) issue(c0 + KC);   // in flight during the MFMA loop below
     WSL_MARK(mk + 3);
-    if (!(p.ablate & 1)) conv2_mfma_stages<C, KS, KC, KC / 4>(in_t, w_t, abase, bbase, acc);
+    if (!WSL_ABLATED(p, 1)) conv2_mfma_stages<C, KS, KC, KC / 4>(in_t, w_t, abase, bbase, acc);
     WSL_MARK(mk + 4);
     __syncthreads();
     WSL_MARK(mk + 5);
   }
 
   // ---- epilogue: bias, float4 stores, BatchNorm partial statistics (tile and channel block are full by eligibility)
-  if (p.ablate & 4) {
+  if (WSL_ABLATED(p, 4)) {
     if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;   // keep the accumulators live
     return;
   }
@@ -813,12 +813,12 @@ template <int KS, int TH, int TW, int CO_T>
 static int launch_conv2(Conv2P& p, int wmode_for_prof, void* stream) {
   using C = Conv2Cfg<KS, TH, TW, CO_T, 8>;
   // the lean kernel takes every shape it is eligible for (WSL_CONV_LEAN=0 forces the generic one, for A/B timing)
-  static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
+  static const bool lean_on = (WSL_TUNE("WSL_CONV_LEAN", 1) != 0);
   const int64_t span = (int64_t)(p.a.C > p.b.C ? p.a.C : p.b.C) * p.H * p.W;
   if (lean_on && p.Ci % 8 == 0 && (p.b.C == 0 || p.a.C % 8 == 0) && p.Co % CO_T == 0 && p.H % TH == 0 && p.W % TW == 0 &&
       span < (int64_t(1) << 31) && (int64_t)KS * KS * p.Ci * p.Co < (int64_t(1) << 31)) {
     // measured neutral (+-3 % per layer, +0.2 % per step: profiles/r1g_conv_timeline.md), so it stays opt-in
-    static const bool dma_on = getenv("WSL_CONV_DMA") && atoi(getenv("WSL_CONV_DMA")) != 0;
+    static const bool dma_on = WSL_TUNE("WSL_CONV_DMA", 0) != 0;
     const bool raw = !p.a.scale && !p.a.emask && !p.a.cmask && (p.b.C == 0 || (!p.b.scale && !p.b.emask && !p.b.cmask));
     if constexpr (KS == 3) {   // (1x1 tiles are padded per plane: their slots are not lane-contiguous)
       if (dma_on && raw) return launch_conv2r<KS, TH, TW, CO_T>(p, wmode_for_prof, stream);   // plain sources: LDS DMA
@@ -873,7 +873,7 @@ int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = cdiv(W, tw), p.tiles_y = cdiv(H, th);
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
-  static const int ablate = getenv("WSL_CONV_ABLATE") ? atoi(getenv("WSL_CONV_ABLATE")) : 0;
+  static const int ablate = WSL_TUNE("WSL_CONV_ABLATE", 0);
   p.ablate = ablate;
 #define WSL_CASE(KS_, TH_, TW_, CO_) \
   if (ks == KS_ && th == TH_ && tw == TW_ && co_t == CO_) return launch_conv2<KS_, TH_, TW_, CO_>(p, is_dgrad, stream);
@@ -1246,9 +1246,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2l_kernel(Wgrad2P p) {
   const float* ap = a_t + (cit * 16 + (lane & 15)) * C::PLA + (lane >> 4) + (C::PADL - C::P);
   const bool dbw = want_db && cit == 0;
   for (int item = it0; item < it1; ++item) {
-    if (!(p.ablate & 2) || item == it0) commit();
+    if (!WSL_ABLATED(p, 2) || item == it0) commit();
     __syncthreads();
-    if (item + 1 < it1 && !(p.ablate & 2)) issue();   // prefetch the next tile; in flight during the MFMA loop
+    if (item + 1 < it1 && !WSL_ABLATED(p, 2)) issue();   // prefetch the next tile; in flight during the MFMA loop
     constexpr int RW = TH / WK, NX = TW / 4, NSTEP = RW * NX;
     float avv[2], bvv[2][C::KK];
     auto load = [&](int st, int buf) {   // step st = (row, group of 4 pixels)
@@ -1258,11 +1258,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2l_kernel(Wgrad2P p) {
       for (int t = 0; t < C::KK; ++t) bvv[buf][t] = ap[(r + t / KS) * C::ROWP + x4 * 4 + (t % KS)];
     };
     load(0, 0);
-    if (p.ablate & 1) continue;
+    if (WSL_ABLATED(p, 1)) continue;
 #pragma unroll 2
     for (int st = 0; st < NSTEP; ++st) {   // operands of step st+1 are read before the MFMAs of step st issue
       const int cur = st & 1;
-      if (st + 1 < NSTEP && !(p.ablate & 8)) load(st + 1, cur ^ 1);
+      if (st + 1 < NSTEP && !WSL_ABLATED(p, 8)) load(st + 1, cur ^ 1);
       if (dbw) accb = WSL_MFMA16(avv[cur], 1.0f, accb);
 #pragma unroll
       for (int t = 0; t < C::KK; ++t) acc[t] = WSL_MFMA16(avv[cur], bvv[cur][t], acc[t]);
@@ -1456,9 +1456,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
   const float* ap = a_t + (cit * 16 + (lane & 15)) * C::PLA + (lane >> 4) + (C::PADL - C::P);
   const bool dbw = want_db && cit == 0;
   for (int item = it0; item < it1; ++item) {
-    if (!(p.ablate & 2) || item == it0) commit();
+    if (!WSL_ABLATED(p, 2) || item == it0) commit();
     __syncthreads();
-    if (item + 1 < it1 && !(p.ablate & 2)) issue();   // prefetch the next tile; in flight during the MFMA loop
+    if (item + 1 < it1 && !WSL_ABLATED(p, 2)) issue();   // prefetch the next tile; in flight during the MFMA loop
     constexpr int RW = TH / WK, NX = TW / 4, NSTEP = RW * NX;
     float avv[2][C::PP][KS], bvv[2][KS];
     auto load = [&](int st, int buf) {   // step st = (row, group of 4 pixels)
@@ -1472,11 +1472,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
       for (int kx = 0; kx < KS; ++kx) bvv[buf][kx] = ap[r * C::ROWP + x4 * 4 + kx];           // a shifted by +(kx-P) cols
     };
     load(0, 0);
-    if (p.ablate & 1) continue;
+    if (WSL_ABLATED(p, 1)) continue;
 #pragma unroll 2
     for (int st = 0; st < NSTEP; ++st) {   // operands of step st+1 are read before the MFMAs of step st issue
       const int cur = st & 1;
-      if (st + 1 < NSTEP && !(p.ablate & 8)) load(st + 1, cur ^ 1);
+      if (st + 1 < NSTEP && !WSL_ABLATED(p, 8)) load(st + 1, cur ^ 1);
 #pragma unroll
       for (int j = 0; j < C::PP; ++j) {
         if (dbw) accb[j] = WSL_MFMA16(avv[cur][j][C::P], 1.0f, accb[j]);
@@ -1561,11 +1561,11 @@ static int launch_wgrad2l(Wgrad2P& p, int ci_blocks, void* stream) {
 template <int KS, int TH, int TW, int CB, int IB, int WK>
 static int launch_wgrad2(Wgrad2P& p, int ci_blocks, void* stream) {
   using C = Wgrad2Cfg<KS, TH, TW, CB, IB, WK>;
-  static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
+  static const bool lean_on = (WSL_TUNE("WSL_CONV_LEAN", 1) != 0);
   const int64_t span = (int64_t)(p.a.C > p.b.C ? p.a.C : p.b.C) * p.H * p.W;
   if (lean_on && p.Ci % IB == 0 && p.Co % CB == 0 && (p.b.C == 0 || p.a.C % IB == 0) && p.H % TH == 0 && p.W % TW == 0 &&
       span < (int64_t(1) << 31) && (int64_t)p.Co * p.H * p.W < (int64_t(1) << 31)) {
-    static const bool split_on = !(getenv("WSL_WGRAD_SPLIT") && atoi(getenv("WSL_WGRAD_SPLIT")) == 0);
+    static const bool split_on = (WSL_TUNE("WSL_WGRAD_SPLIT", 1) != 0);
     if (split_on) return launch_wgrad2s<KS, TH, TW, CB, IB, WK>(p, ci_blocks, stream);
     return launch_wgrad2l<KS, TH, TW, CB, IB, WK>(p, ci_blocks, stream);
   }
@@ -1590,9 +1590,9 @@ bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t 
 // 64 output channels x 32 input channels per workgroup (wgrad_mfma2s_kernel with two co tiles per wave): non-small layers
 // with Co % 64 == 0 that satisfy the lean contract.  WSL_WGRAD_CB64=0 keeps the 32 x 32 blocking.
 bool wgrad2s_wide_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks) {
-  static const bool on = getenv("WSL_WGRAD_CB64") && atoi(getenv("WSL_WGRAD_CB64")) != 0;
-  static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
-  static const bool split_on = !(getenv("WSL_WGRAD_SPLIT") && atoi(getenv("WSL_WGRAD_SPLIT")) == 0);
+  static const bool on = WSL_TUNE("WSL_WGRAD_CB64", 0) != 0;
+  static const bool lean_on = (WSL_TUNE("WSL_CONV_LEAN", 1) != 0);
+  static const bool split_on = (WSL_TUNE("WSL_WGRAD_SPLIT", 1) != 0);
   if (!on || !lean_on || !split_on) return false;
   const int bC = b ? b->C : 0, Ci = a.C + bC;
   if (Co <= 16 || Ci <= 16 || (Co % 64) || (Ci % 32) || (bC > 0 && (a.C % 32))) return false;
@@ -1616,9 +1616,9 @@ int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_
   p.dy = dy, p.dy_bs = dy_bs, p.part_dw = part_dw, p.part_db = part_db;
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
-  static const int ablate = getenv("WSL_WGRAD_ABLATE") ? atoi(getenv("WSL_WGRAD_ABLATE")) : 0;
+  static const int ablate = WSL_TUNE("WSL_WGRAD_ABLATE", 0);
   p.ablate = ablate;
-  static const bool lean_on = !(getenv("WSL_CONV_LEAN") && atoi(getenv("WSL_CONV_LEAN")) == 0);
+  static const bool lean_on = (WSL_TUNE("WSL_CONV_LEAN", 1) != 0);
   if (lean_on && !ablate && wgrad_wino_ok(a, b, H, W, Co, ks, th, tw, cb, ib))   // Winograd form (wsl_conv5.hip)
     return wgrad_wino_launch(a, b, dy, dy_bs, part_dw, part_db, N, H, W, Co, th, tw, cb, nsplit, items, tiles_x, tiles_y,
                              co_blocks, ci_blocks, stream);

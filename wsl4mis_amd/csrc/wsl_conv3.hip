@@ -19,6 +19,21 @@
 
 #include "wsl_rt.h"
 
+#ifndef WSL_EXPERIMENTS
+// Measured slower than the lock-step kernel (profiles/r1d_conv_variants.md): this translation unit is compiled only into the
+// EXPERIMENTS build (build.sh exp) and the test-only host emulator; the product library holds these three stubs instead.
+namespace wsl {
+bool conv3_enabled() { return false; }
+void conv_set_variant(int) {}
+int conv3_fwd(const WslSrc&, const WslSrc*, const float*, const float*, float*, int64_t, int, int, int, int, int, int, int, int, int,
+              float*, float*, void*) {
+  set_error("conv3: the wave-specialised variant is not part of the product build");
+  return WSL_EUNSUPPORTED;
+}
+}  // namespace wsl
+#else
+
+
 namespace wsl {
 
 struct Src3 {
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma3_kernel(Conv3P p) {
     if (nsteps > 1) issue(1);
     __syncthreads();  // (B) stage 0 ready
     for (int g = 0; g < nsteps; ++g) {  // MFMA waves compute step g meanwhile
-      if (!(p.ablate & 2)) {
+      if (!WSL_ABLATED(p, 2)) {
         if (g + 1 < nsteps) commit(g + 1);
         if (g + 2 < nsteps) issue(g + 2);
       }
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma3_kernel(Conv3P p) {
     const float* in_b = lds + (g & 1) * C::BUF;
     // channels past Ci were staged as zeros: no branch inside; a chunk holding <= 4 channels (Ci = 1 or 4 layers) runs
     // the single-group variant
-    if (p.ablate & 1) {
+    if (WSL_ABLATED(p, 1)) {
     } else if (Ci - k * KC > 4) conv3_mfma_stages<C, KS, KC, KC / 4>(in_b, in_b + C::IN_FLOATS, abase, bbase, acc);
     else conv3_mfma_stages<C, KS, KC, 1>(in_b, in_b + C::IN_FLOATS, abase, bbase, acc);
 
@@ -349,7 +364,7 @@ static Src3 to_src3(const WslSrc& s) { return Src3{s.x, s.emask, s.scale, s.shif
 // or env WSL_CONV_V3=1) for the next round; the default is v2.
 static int g_variant = 0;
 bool conv3_enabled() {
-  if (g_variant == 0) g_variant = getenv("WSL_CONV_V3") ? 3 : 2;
+  if (g_variant == 0) g_variant = WSL_TUNE("WSL_CONV_V3", 0) ? 3 : 2;
   return g_variant == 3;
 }
 void conv_set_variant(int v) { g_variant = (v == 3) ? 3 : 2; }
@@ -364,7 +379,7 @@ int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = cdiv(W, tw), p.tiles_y = cdiv(H, th);
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
-  static const int ablate = getenv("WSL_CONV_ABLATE") ? atoi(getenv("WSL_CONV_ABLATE")) : 0;
+  static const int ablate = WSL_TUNE("WSL_CONV_ABLATE", 0);
   p.ablate = ablate;
 #define WSL_CASE(KS_, TH_, TW_, CO_) \
   if (ks == KS_ && th == TH_ && tw == TW_ && co_t == CO_) return launch_conv3<KS_, TH_, TW_, CO_>(p, is_dgrad, stream);
@@ -378,3 +393,5 @@ int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bi
 }
 
 }  // namespace wsl
+
+#endif  // WSL_EXPERIMENTS

@@ -394,6 +394,8 @@ int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* 
   return check_launch("conv_cls_kernel");
 }
 
+// ---- machine probes (EXPERIMENTS build only; tools/mfma_ceiling.py, tools/probe_lds_dma.py, tools/probe_mfma4.py)
+#ifdef WSL_EXPERIMENTS
 // Pure MFMA stream (no memory): the practical f32 matrix ceiling of the machine at its sustained clock, per MFMA shape.
 // shape 0: 16x16x4 (16 independent accumulators), 1: 32x32x2 (4 accumulators), 2: 4x4x1 (16 accumulators).
 #ifndef WSL_HOST_EMUL
@@ -495,8 +497,11 @@ __global__ void mfma4_probe_kernel(const float* a, const float* b, float* d) {
 }
 #endif
 
+#endif  // WSL_EXPERIMENTS
+
 }  // namespace wsl
 
+#ifdef WSL_EXPERIMENTS
 extern "C" int wsl_debug_lds_dma_probe(const float* g, float* out, void* stream) {
 #ifndef WSL_HOST_EMUL
   WSL_LAUNCH(wsl::lds_dma_probe_kernel, dim3(1), dim3(256), 0, stream, g, out);
@@ -541,3 +546,4 @@ extern "C" int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, v
   return WSL_EUNSUPPORTED;
 #endif
 }
+#endif  // WSL_EXPERIMENTS

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
   };
 
 #ifndef WSL_HOST_EMUL
-  uint64_t* tl = (p.ablate & 128) ? reinterpret_cast<uint64_t*>(p.stat_part) + (int64_t)tile_id * 32 : nullptr;
+  uint64_t* tl = WSL_ABLATED(p, 128) ? reinterpret_cast<uint64_t*>(p.stat_part) + (int64_t)tile_id * 32 : nullptr;
 #define WSL_MARK(k) do { if (tl && tid == 0) tl[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
   if (tl && tid == 0) tl[29] = __builtin_amdgcn_s_memrealtime(), tl[28] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
 #else
@@ -873,12 +873,18 @@ bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, 
   return true;
 }
 
-// kernel variants (defaults from the environment; wsl_debug_wino_variant() overrides them for tests / A-B timing)
+// kernel variants.  Product: form 2 (input transform in the MFMA operand) and the 4-wave weight gradient, fixed.  EXPERIMENTS
+// build: env WSL_WINO_FORM / WSL_WGRAD_WINO_WAVES or wsl_debug_wino_variant() select the measured-slower first form / the
+// 8-wave weight gradient for A-B timing.
+#ifdef WSL_EXPERIMENTS
 static int g_wino_form = -1, g_wgrad_waves = -1;
 static int wino_form() {
-  if (g_wino_form < 0) g_wino_form = (getenv("WSL_WINO_FORM") && atoi(getenv("WSL_WINO_FORM")) == 1) ? 1 : 2;
+  if (g_wino_form < 0) g_wino_form = WSL_TUNE("WSL_WINO_FORM", 2) == 1 ? 1 : 2;
   return g_wino_form;
 }
+#else
+static constexpr int wino_form() { return 2; }
+#endif
 
 template <int TH, int TW, int NT>
 static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
@@ -900,7 +906,7 @@ static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
 
 template <int TH, int TW, int NT>
 static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
-  static const bool dma_on = !(getenv("WSL_WINO_DMA") && atoi(getenv("WSL_WINO_DMA")) == 0);
+  static const bool dma_on = (WSL_TUNE("WSL_WINO_DMA", 1) != 0);
   const bool raw = !p.a.scale && !p.a.emask && !p.a.cmask && (p.b.C == 0 || (!p.b.scale && !p.b.emask && !p.b.cmask));
   if (dma_on && raw && wino_form() == 2) return launch_wino2r<TH, TW, NT>(p, is_dgrad, stream);   // plain sources: LDS DMA
   using C = Wino2Cfg<TH, TW, NT>;
@@ -946,7 +952,7 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
   p.u = u, p.bias = bias, p.y = y, p.y_bs = y_bs;
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt, p.slots = slots;
-  static const int ablate = getenv("WSL_CONV_ABLATE") ? atoi(getenv("WSL_CONV_ABLATE")) : 0;
+  static const int ablate = WSL_TUNE("WSL_CONV_ABLATE", 0);
   p.ablate = ablate;
   int th = 0, tw = 0, co_t = 0;
   if (!wino_shape_ok(H, W, p.Ci, Co, 3, true, &th, &tw, &co_t) || (p.b.C && (p.a.C % 8))) {
@@ -960,9 +966,12 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
     if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);
     return launch_wino2<16, 16, 2>(p, is_dgrad, stream);
   }
+#ifdef WSL_EXPERIMENTS
   if (th == 8 && co_t == 32) return launch_wino<8, 32, 32>(p, is_dgrad, stream);
-  if (th == 8 && co_t == 16) return launch_wino<8, 32, 16>(p, is_dgrad, stream);
   if (th == 16 && co_t == 32) return launch_wino<16, 16, 32>(p, is_dgrad, stream);
+#endif
+  // 16-channel blocks at widths below 64 (small inputs only: the networks' 16-channel layers run at full resolution)
+  if (th == 8 && co_t == 16) return launch_wino<8, 32, 16>(p, is_dgrad, stream);
   return launch_wino<16, 16, 16>(p, is_dgrad, stream);
 }
 
@@ -1288,15 +1297,19 @@ static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
 // waves per workgroup of the 32 x 32 variant: 4 (default: two workgroups per CU) or 8 = one double-buffered workgroup per CU
 // with the next tile's loads in flight during the compute phase -- measured equal (+-5 % per layer), so it stays opt-in
 // (env WSL_WGRAD_WINO_WAVES=8)
+#ifdef WSL_EXPERIMENTS
 int wgrad_wino_waves() {
-  if (g_wgrad_waves < 0) g_wgrad_waves = (getenv("WSL_WGRAD_WINO_WAVES") && atoi(getenv("WSL_WGRAD_WINO_WAVES")) == 8) ? 8 : 4;
+  if (g_wgrad_waves < 0) g_wgrad_waves = WSL_TUNE("WSL_WGRAD_WINO_WAVES", 4) == 8 ? 8 : 4;
   return g_wgrad_waves;
 }
+#else
+int wgrad_wino_waves() { return 4; }
+#endif
 
 // takes the launches wgrad_mfma2s_kernel would get with the same plan: 3x3, 32 x 32 channel blocks (two dY tiles per wave,
 // two input-channel tiles per workgroup) or 16 x 16 (the 16-channel layers: one tile each, four tile subsets)
 bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib) {
-  static const int on = getenv("WSL_WGRAD_WINO") ? atoi(getenv("WSL_WGRAD_WINO")) : 2;   // 0 off, 1 only 32 x 32 blocks, 2 all
+  static const int on = WSL_TUNE("WSL_WGRAD_WINO", 2);   // 0 off, 1 only 32 x 32 blocks, 2 all
   if (!on || ks != 3 || cb != ib) return false;
   if (cb == 32) {
     if (!((th == 4 && tw == 32) || (th == 8 && tw == 16))) return false;
@@ -1321,8 +1334,10 @@ int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
   if (cb == 32) {
+#ifdef WSL_EXPERIMENTS
     if (wgrad_wino_waves() == 8)
       return th == 4 ? launch_wgrad_wino<4, 32, 2, 2, 8>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2, 8>(p, ci_blocks, stream);
+#endif
     return th == 4 ? launch_wgrad_wino<4, 32, 2, 2, 4>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2, 4>(p, ci_blocks, stream);
   }
   if (tw == 64) return launch_wgrad_wino<4, 64, 1, 1, 4>(p, ci_blocks, stream);
@@ -1331,8 +1346,10 @@ int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t
 
 }  // namespace wsl
 
+#ifdef WSL_EXPERIMENTS
 extern "C" int wsl_debug_wino_variant(int conv_form, int wgrad_waves) {
   wsl::g_wino_form = conv_form == 1 ? 1 : conv_form == 2 ? 2 : -1;
   wsl::g_wgrad_waves = wgrad_waves == 8 ? 8 : wgrad_waves == 4 ? 4 : -1;
   return WSL_OK;
 }
+#endif

@@ -1,0 +1,26 @@
+/* PRIVATE header of libwslhip.so: hooks for the test-suite and the tuning tools.  Not part of the drop-in boundary
+ * (include/wsl_hip.h); nothing in wsl4mis_amd/ (the product's host side) calls these.
+ *
+ * In every build (results stay correct; tests use them to run every kernel instantiation at small sizes): */
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Force the conv tile shape (rows, columns, output-channel block) wherever it divides the layer; th <= 0 restores the
+ * built-in per-layer table. */
+int wsl_debug_conv_plan(int th, int tw, int co_t);
+/* Winograd F(2x2,3x3) path: 0 off (wsl_conv2d_wino_ok() returns 0), 1 only layers with Co % 32 == 0, 2 (default) also
+ * layers with Co % 16 == 0; -1 restores the default. */
+int wsl_debug_conv_wino(int on);
+
+/* Only in the EXPERIMENTS build (-DWSL_EXPERIMENTS: `build.sh exp` -> tools/exp/libwslhip_exp.so, and the host emulator):
+ * measured-slower kernel families kept for A/B timing, ablation switches (env WSL_CONV_ABLATE / WSL_WGRAD_ABLATE: they skip
+ * work, results are WRONG by design), ~20 env tuning knobs (WSL_TUNE in wsl_rt.h) and three machine probes. */
+int wsl_debug_wino_variant(int conv_form, int wgrad_waves);   /* 1 = first Winograd form | 8-wave weight gradient */
+int wsl_debug_conv_variant(int v);                            /* 3 = wave-specialised persistent conv (wsl_conv3.hip) */
+int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, void* stream);          /* tools/probe_mfma4.py */
+int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* out, void* stream);      /* tools/mfma_ceiling.py */
+int wsl_debug_lds_dma_probe(const float* g, float* out, void* stream);                      /* tools/probe_lds_dma.py */
+#ifdef __cplusplus
+}
+#endif

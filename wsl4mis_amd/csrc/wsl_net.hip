@@ -462,7 +462,7 @@ extern "C" int wsl_net_forward(const WslNetDesc* d, const float* params, float* 
   }
   // the two decoders only share read-only inputs: the auxiliary one runs on the library's side stream with its own
   // scratch set and is joined before returning (fills the other's launch gaps and workgroup tails)
-  void* side = d->n_dec == 2 ? side_stream() : nullptr;
+  void* side = d->n_dec == 2 ? side_stream(stream) : nullptr;
   if (side) {
     Ctx c2 = c;
     c2.stream = side, c2.si = 1;
@@ -490,7 +490,7 @@ extern "C" int wsl_net_backward(const WslNetDesc* d, const float* params, const 
   }
   Ctx c{P, params, nullptr, nullptr, grads, static_cast<float*>(ws), stream, 1};
   if (phase == 0 || phase == 1) {
-    void* side = d->n_dec == 2 ? side_stream() : nullptr;
+    void* side = d->n_dec == 2 ? side_stream(stream) : nullptr;
     if (side) {
       Ctx c2 = c;
       c2.stream = side, c2.si = 1;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/wsl_hip.h"
+#include "wsl_debug.h"
 
 #ifdef WSL_HOST_EMUL
 #include "hip_emul.h"
@@ -41,6 +42,22 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define WSL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Tuning / ablation / probe switches exist only in the EXPERIMENTS build (build.sh exp -> tools/exp/libwslhip_exp.so, and
+// the test-only host emulator).  The product library reads no environment variable: every switch is its default there, and
+// the ablation paths (which produce WRONG results by design) are compiled out.
+#ifdef WSL_EXPERIMENTS
+#include <stdlib.h>
+static inline int wsl_tune_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#define WSL_TUNE(name, dflt) wsl_tune_int(name, dflt)
+#define WSL_ABLATED(p, bits) (((p).ablate & (bits)) != 0)
+#else
+#define WSL_TUNE(name, dflt) (dflt)
+#define WSL_ABLATED(p, bits) (false)
+#endif
+
 namespace wsl {
 
 void set_error(const char* fmt, ...);
@@ -64,7 +81,7 @@ int device_cu_count();   // compute units of the current device (cached)
 // Library-owned side stream for work that is independent of the caller's stream for a while (the second decoder of
 // unet_cct).  fork: side waits for everything enqueued on `main` so far; join: `main` waits for the side stream.
 // Both are event waits enqueued on the streams -- the host never blocks.  Returns null when disabled / emulated.
-void* side_stream();
+void* side_stream(void* main);
 void set_concurrent(int on);
 int stream_fork(void* main, void* side);
 int stream_join(void* main, void* side);

@@ -23,7 +23,6 @@ encoder's slice.  Losses stay on the device; `losses()` is the only host sync.
 """
 import ctypes as C
 import math
-import os
 
 import torch
 import torch.distributed as dist
@@ -76,7 +75,7 @@ class TrainEngine:
         self._diag = None                                  # comm_diag(True): [(event, event)] around the waits for the comm stream
         self.teacher = None
         self._tstream, self._zt = None, None
-        self.concurrent = os.environ.get("WSL_NET_CONCURRENT") != "0"   # side streams (teacher forward); see DESIGN 4
+        self.concurrent = True                             # teacher forward on a side stream; set False to serialise
         if loss in ("mean_teacher", "ustm"):
             if self.dual:
                 raise _lib.WslError(f"'{loss}' is defined for the single-decoder unet")
