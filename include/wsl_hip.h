@@ -106,6 +106,19 @@ int wsl_net_concurrent(int on);
 int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db,
                      int N, int H, int W, int Co, int ks, void* ws, size_t ws_bytes, void* stream);
 size_t wsl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co, int ks);
+/* The two stages separately, so that a whole network's second stages (36 tiny launches per step) run as ONE launch:
+ * wsl_conv2d_wgrad_partial = stage 1 (partials into ws, which must stay untouched until the batch ran) and a record of the
+ * pending stage 2; wsl_wgrad_reduce_batch = stage 2 of n such records, order-fixed sums (bit-reproducible). */
+typedef struct WslWgradPending {
+  const float* part_dw;
+  const float* part_db;
+  float* dw;
+  float* db;
+  int Co, Ci, KK, nsplit;
+} WslWgradPending;
+int wsl_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db, int N, int H,
+                             int W, int Co, int ks, void* ws, size_t ws_bytes, WslWgradPending* pending, void* stream);
+int wsl_wgrad_reduce_batch(const WslWgradPending* items, int n, void* stream);
 
 /* BatchNorm2d, training mode (ref: unet.py:20,24; eps 1e-5, momentum 0.1): merge the conv epilogue's partials
  * (Chan's parallel variance), write mean/invstd (saved for backward) and the fused apply coefficients
@@ -138,6 +151,29 @@ int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const float* mea
                   const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
                   float* dgamma, float* dbeta, int N, int C, int H, int W, void* ws, size_t ws_bytes, void* stream);
 size_t wsl_bnact_bwd_ws_bytes(int N, int C, int H, int W);
+
+/* Stage 1 of wsl_bnact_bwd fused into the kernel that PRODUCES g (autograd of ref: unet.py:18-29; saves the reduction pass'
+ * 8 bytes per element of HBM traffic).  Producers that can emit the partial sums S1, S2 per workgroup:
+ *   wsl_conv2d_dgrad_bn      the data-gradient convolution (wmode 1 | 3 | 5 of wsl_conv2d_fwd, one plain source dy, no bias)
+ *                            whose output g [N,Co,H,W] (dense) is dL/d(out) of the BatchNorm that normalised bn_y [N,Co,H,W];
+ *                            bn_st = mean | invstd | scale | shift (4 * Co floats), bn_emask the nn.Dropout keep mask or
+ *                            NULL.  *fused = 1: bn_part holds [Co][wsl_conv2d_stat_blocks(N,H,W,Ci,Co,ks)][2] partials
+ *                            (channel-major); *fused = 0: the kernel this shape dispatches to has no such epilogue, g is
+ *                            written as usual and the caller runs wsl_bnact_bwd().
+ *   wsl_feat_grad_combine_bn wsl_feat_grad_combine() for a feature f = leaky(bn(y)) (plain scale/shift source): bn_part holds
+ *                            [wsl_feat_grad_combine_blocks(N,H,W)][C][2] partials (block-major).
+ * wsl_bnact_bwd_finish = stage 2 from such partials: dgamma, dbeta, dy.  ws: 2 * C floats. */
+int wsl_conv2d_dgrad_bn(const WslSrc* dy, const float* w, float* g, int64_t g_bs, int N, int H, int W, int Co, int ks,
+                        int wmode, const float* bn_y, const float* bn_st, const uint8_t* bn_emask, float bn_emask_scale,
+                        float* bn_part, int* fused, void* stream);
+int wsl_feat_grad_combine_blocks(int N, int H, int W);
+int wsl_feat_grad_combine_bn(const WslSrc* f, const float* ga, int64_t ga_bs, const float* gb, int64_t gb_bs,
+                             const float* gb_cmask, const float* gp, float* g, int N, int H, int W, const float* bn_mean,
+                             const float* bn_invstd, float* bn_part, void* stream);
+int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                         float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
+                         int channel_major, void* ws, size_t ws_bytes, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (ref: unet.py:56-57) and its transpose. */
 int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream);

@@ -120,3 +120,111 @@ def test_src_materialize_and_eval_affine(be):
     ref = F.leaky_relu(F.batch_norm(torch.from_numpy(x), torch.from_numpy(rm), torch.from_numpy(rv),
                                     torch.from_numpy(gamma), torch.from_numpy(beta), False, 0.1, 1e-5), 0.01)
     assert rel_err(be.np(out), ref.numpy()) < 1e-5
+
+
+def _bn_setup(rng, N, C, H, W, with_mask):
+    y = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    gamma, beta = (rng.random(C) + 0.5).astype(np.float32), (rng.standard_normal(C) * 0.3).astype(np.float32)
+    mean = y.mean((0, 2, 3)).astype(np.float32)
+    invstd = (1.0 / np.sqrt(y.var((0, 2, 3)) + 1e-5)).astype(np.float32)
+    scale = (gamma * invstd).astype(np.float32)
+    shift = (beta - mean * scale).astype(np.float32)
+    emask = (rng.random((N, C, H, W)) > 0.3).astype(np.uint8) if with_mask else None
+    return y, gamma, beta, mean, invstd, np.concatenate([mean, invstd, scale, shift]).astype(np.float32), emask
+
+
+# (N, H, W, Cdy, Cg, ks, mask, fused): which kernel emits the statistics
+FUSED_CASES = [
+    (2, 16, 32, 32, 32, 3, True, 1),     # conv_wino2r (32-channel blocks)
+    (1, 8, 64, 16, 16, 3, False, 1),     # conv_wino2r 8 x 64 tiles (the 16-channel layers at full width)
+    (2, 16, 16, 64, 32, 3, True, 1),     # conv_wino2r 16 x 16 tiles
+    (2, 16, 32, 64, 32, 1, False, 1),    # direct lean kernel, 1x1 (decoder conv1x1 data gradient), 32-channel block
+    (1, 16, 64, 4, 16, 3, False, 1),     # generic direct kernel (classifier data gradient 4 -> 16)
+    (2, 16, 32, 32, 64, 1, False, 2),    # 64 output channels: a 64-channel block (64 accumulators) has no epilogue -> the caller
+                                         # falls back; on a 256-CU device the plan shrinks the block to 32 -> fused (2 = either)
+    (2, 8, 32, 16, 16, 3, True, 0),      # first Winograd form (16-channel block below width 64): no epilogue
+    (1, 6, 10, 8, 8, 3, False, 0),       # odd shape, raw weights: no epilogue
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_dgrad_with_bn_backward_statistics_equals_the_two_pass_form(be, case):
+    """wsl_conv2d_dgrad_bn + wsl_bnact_bwd_finish (statistics from the convolution's epilogue) against the plain data gradient
+    followed by wsl_bnact_bwd (stand-alone reduction pass): same dy, dgamma, dbeta up to the summation order"""
+    import ctypes as C_
+    N, H, W, Cdy, Cg, ks, with_mask, expect_fused = case
+    rng = np.random.default_rng(sum(case[:6]) * 7 + 1)
+    dyv = (rng.standard_normal((N, Cdy, H, W)) * 0.1).astype(np.float32)
+    w = (rng.standard_normal((Cdy, Cg, ks, ks)) * 0.2).astype(np.float32)      # layer Cg -> Cdy: its data gradient maps dy -> g
+    y, gamma, beta, mean, invstd, st, emask = _bn_setup(rng, N, Cg, H, W, with_mask)
+    es = 1.0 / 0.7
+    d = {k: be.arr(v) for k, v in dict(dy=dyv, w=w, y=y, gamma=gamma, beta=beta, mean=mean, invstd=invstd, st=st).items()}
+    dm = be.arr(emask) if with_mask else None
+    src = be.src(d["dy"], Cdy)
+    fast = bool(be.lib.wsl_conv2d_fast_ok(C_.byref(src), None, None, 0, W)) and W % 4 == 0
+    if fast and be.lib.wsl_conv2d_wino_ok(N, H, W, Cdy, 0, Cg, ks):
+        wp, wmode = be.zeros((16 * Cdy * Cg,)), 5
+        be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(wp), Cdy, Cg, ks, 3, be.stream)
+    elif fast:
+        wp, wmode = be.zeros((ks * ks * Cdy * Cg,)), 3
+        be.call("wsl_conv2d_pack_weights", be.ptr(d["w"]), be.ptr(wp), Cdy, Cg, ks, 1, be.stream)
+    else:
+        wp, wmode = d["w"], 1
+    nws = be.lib.wsl_bnact_bwd_ws_bytes(N, Cg, H, W)
+    # --- two-pass reference
+    g_ref, dy_ref = be.zeros((N, Cg, H, W)), be.zeros((N, Cg, H, W))
+    dg_ref, db_ref, ws = be.zeros((Cg,)), be.zeros((Cg,)), be.ws(nws)
+    be.call("wsl_conv2d_fwd", src, be.src(), be.ptr(wp), None, be.ptr(g_ref), Cg * H * W, N, H, W, Cg, ks, wmode, None, None,
+            be.stream)
+    be.call("wsl_bnact_bwd", be.ptr(g_ref), Cg * H * W, be.ptr(d["y"]), be.ptr(d["mean"]), be.ptr(d["invstd"]), be.ptr(d["gamma"]),
+            be.ptr(d["beta"]), be.ptr(dm) if with_mask else None, es, be.ptr(dy_ref), be.ptr(dg_ref), be.ptr(db_ref), N, Cg, H, W,
+            be.ptr(ws), nws, be.stream)
+    # --- fused
+    g, dy = be.zeros((N, Cg, H, W)), be.zeros((N, Cg, H, W))
+    dg, db, part, coef = be.zeros((Cg,)), be.zeros((Cg,)), be.ws(nws), be.zeros((2 * Cg,))
+    fused = C_.c_int(-1)
+    be.call("wsl_conv2d_dgrad_bn", src, be.ptr(wp), be.ptr(g), Cg * H * W, N, H, W, Cg, ks, wmode, be.ptr(d["y"]), be.ptr(d["st"]),
+            be.ptr(dm) if with_mask else None, es, be.ptr(part), C_.byref(fused), be.stream)
+    assert np.array_equal(be.np(g), be.np(g_ref))                           # the gradient itself: same kernel, same bits
+    assert fused.value in ((0, 1) if expect_fused == 2 else (expect_fused,)), (case, fused.value)
+    if fused.value:
+        nblk = be.lib.wsl_conv2d_stat_blocks(N, H, W, Cdy, Cg, ks)
+        be.call("wsl_bnact_bwd_finish", be.ptr(g), Cg * H * W, be.ptr(d["y"]), be.ptr(d["mean"]), be.ptr(d["invstd"]),
+                be.ptr(d["gamma"]), be.ptr(d["beta"]), be.ptr(dm) if with_mask else None, es, be.ptr(dy), be.ptr(dg), be.ptr(db),
+                N, Cg, H, W, be.ptr(part), nblk, 1, be.ptr(coef), 8 * Cg, be.stream)
+        assert rel_err(be.np(dg), be.np(dg_ref)) < 2e-6 and rel_err(be.np(db), be.np(db_ref)) < 2e-6
+        assert rel_err(be.np(dy), be.np(dy_ref)) < 2e-6
+
+
+@pytest.mark.parametrize("shape,pool", [((2, 3, 8, 12), True), ((1, 4, 7, 10), True), ((2, 2, 6, 6), False)])
+def test_fan_in_with_bn_backward_statistics_equals_the_two_pass_form(be, shape, pool):
+    """wsl_feat_grad_combine_bn + wsl_bnact_bwd_finish against wsl_feat_grad_combine + wsl_bnact_bwd"""
+    N, C, H, W = shape
+    rng = np.random.default_rng(H * 17 + W)
+    y, gamma, beta, mean, invstd, st, _ = _bn_setup(rng, N, C, H, W, False)
+    ga = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    gb = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    cm = ((rng.random((N, C)) > 0.5) * 2.0).astype(np.float32)
+    gp = rng.standard_normal((N, C, H // 2, W // 2)).astype(np.float32)
+    d = {k: be.arr(v) for k, v in dict(y=y, gamma=gamma, beta=beta, mean=mean, invstd=invstd, scale=st[2 * C:3 * C], shift=st[3 * C:],
+                                       ga=ga, gb=gb, cm=cm, gp=gp).items()}
+    f = be.src(d["y"], C, scale=d["scale"], shift=d["shift"])
+    nws = be.lib.wsl_bnact_bwd_ws_bytes(N, C, H, W)
+    outs = []
+    for fused in (False, True):
+        g, dy, dg, db, ws, coef = be.zeros(shape), be.zeros(shape), be.zeros((C,)), be.zeros((C,)), be.ws(nws), be.zeros((2 * C,))
+        args = [f, be.ptr(d["ga"]), C * H * W, be.ptr(d["gb"]), C * H * W, be.ptr(d["cm"]), be.ptr(d["gp"]) if pool else None,
+                be.ptr(g), N, H, W]
+        bn = [be.ptr(g), C * H * W, be.ptr(d["y"]), be.ptr(d["mean"]), be.ptr(d["invstd"]), be.ptr(d["gamma"]), be.ptr(d["beta"]),
+              None, 1.0, be.ptr(dy), be.ptr(dg), be.ptr(db), N, C, H, W]
+        if fused:
+            be.call("wsl_feat_grad_combine_bn", *args, be.ptr(d["mean"]), be.ptr(d["invstd"]), be.ptr(ws), be.stream)
+            be.call("wsl_bnact_bwd_finish", *bn, be.ptr(ws), be.lib.wsl_feat_grad_combine_blocks(N, H, W), 0, be.ptr(coef), 8 * C,
+                    be.stream)
+        else:
+            be.call("wsl_feat_grad_combine", *args, be.stream)
+            be.call("wsl_bnact_bwd", *bn, be.ptr(ws), nws, be.stream)
+        outs.append([be.np(t).copy() for t in (g, dy, dg, db)])
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert rel_err(b, a) < 2e-6

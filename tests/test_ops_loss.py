@@ -102,6 +102,32 @@ def test_gatedcrf_golden(be, tag):
     assert close(be.np(dy), g[f"{tag}_dy"], TOL)
 
 
+@pytest.mark.parametrize("shape,r,desc", [((2, 4, 96, 96), 5, (1.0, 6.0, 0.1)), ((1, 4, 70, 100), 5, (0.7, 4.0, 0.25)),
+                                          ((1, 4, 96, 72), 2, (1.0, 6.0, 0.1)), ((1, 4, 40, 44), 3, (1.0, 6.0, 0.1)),
+                                          ((1, 3, 40, 36), 5, (1.0, 6.0, 0.1)), ((1, 4, 33, 38), 5, (1.0, 6.0, 0.1))])
+def test_gatedcrf_interior_and_border_workgroups_against_the_oracle(be, shape, r, desc):
+    """images large enough to hold workgroups with NO tap outside the image (the fast path of the 4-class r = 5 / r = 2 kernel)
+    next to border workgroups, sizes that are not multiples of the 32 x 32 workgroup tile, a y that does NOT sum to one over the
+    classes (nothing may assume a softmax), other descriptors; and the shapes that take the generic kernel (r = 3, 3 classes,
+    W % 4 != 0) -- against oracle.torch_ref.gatedcrf"""
+    import torch
+    from oracle import torch_ref as R
+    N, C, H, W = shape
+    rng = np.random.default_rng(H * W + r)
+    y = (rng.random(shape) * 1.5).astype(np.float32)
+    img = rng.random((N, 1, H, W)).astype(np.float32)
+    img[:, :, : H // 2] = (img[:, :, : H // 2] * 0.05 + 0.4)          # a smooth half: many taps with k close to the maximum
+    w, sxy, srgb = desc
+    ref_loss, ref_msg = R.gatedcrf(torch.from_numpy(y), torch.from_numpy(img), r, sxy, srgb, w)
+    dy_, di = be.arr(y), be.arr(img)
+    msg, loss = be.zeros(shape), be.zeros((1,))
+    ws, n = lws(be, N, C, H * W)
+    be.call("wsl_gatedcrf_fwd", be.ptr(dy_), be.ptr(di), be.ptr(msg), be.ptr(loss), N, C, H, W, r, sxy, srgb, w,
+            be.ptr(ws), n, be.stream)
+    assert close(be.np(msg), ref_msg.numpy(), TOL), (rel_err(be.np(msg), ref_msg.numpy()))
+    assert abs(float(be.np(loss)[0]) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+
+
 def test_gatedcrf_unsupported_radius(be):
     x = be.zeros((1, 4, 8, 8))
     ws, n = lws(be, 1, 4, 64)

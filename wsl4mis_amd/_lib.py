@@ -35,6 +35,11 @@ class WslNetDesc(C.Structure):
                 ("H", C.c_int32), ("W", C.c_int32)]
 
 
+class WslWgradPending(C.Structure):
+    _fields_ = [("part_dw", c_fp), ("part_db", c_fp), ("dw", c_fp), ("db", c_fp), ("Co", C.c_int32), ("Ci", C.c_int32),
+                ("KK", C.c_int32), ("nsplit", C.c_int32)]
+
+
 class WslNetEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("kind", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
                 ("offset", C.c_int64)]
@@ -64,6 +69,9 @@ _PROTOS = {
     "wsl_conv2d_wino_ok": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "wsl_conv2d_wgrad": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "wsl_conv2d_wgrad_partial": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz,
+                                       C.POINTER(WslWgradPending), c_fp]),
+    "wsl_wgrad_reduce_batch": (i32, [C.POINTER(WslWgradPending), i32, c_fp]),
     "wsl_bn_stats_finalize": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, f32, f32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                     c_fp, c_fp]),
     "wsl_bn_eval_affine": (i32, [c_fp, c_fp, c_fp, c_fp, f32, i32, c_fp, c_fp, c_fp]),
@@ -73,6 +81,11 @@ _PROTOS = {
     "wsl_bnact_bwd": (i32, [c_fp, i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32,
                             c_fp, sz, c_fp]),
     "wsl_bnact_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),
+    "wsl_conv2d_dgrad_bn": (i32, [PS, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, f32, c_fp, C.POINTER(C.c_int), c_fp]),
+    "wsl_feat_grad_combine_blocks": (i32, [i32, i32, i32]),
+    "wsl_feat_grad_combine_bn": (i32, [PS, c_fp, i64, c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    "wsl_bnact_bwd_finish": (i32, [c_fp, i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32,
+                                   c_fp, i32, i32, c_fp, sz, c_fp]),
     "wsl_bilinear_up2_fwd": (i32, [c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),
     "wsl_bilinear_up2_bwd": (i32, [c_fp, i64, c_fp, i32, i32, i32, i32, c_fp]),
     "wsl_softmax_fwd": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),

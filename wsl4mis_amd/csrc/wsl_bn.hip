@@ -144,6 +144,69 @@ __global__ __launch_bounds__(256) void feat_grad_combine_kernel(WslSrc f, const 
   }
 }
 
+// feat_grad_combine_kernel that ALSO emits the BatchNorm + LeakyReLU backward statistics of the feature it produces the
+// gradient of (the second BatchNorm of an encoder block: no dropout after it): sum(dz), sum(dz * xhat) per workgroup =
+// (chunk, channel, sample), layout part[(n * chunks + chunk) * C + c][2] -- what bnact_bwd_reduce_kernel would write, without
+// its 8 bytes per element of traffic (the raw feature is read here anyway for the max-pool routing).
+__global__ __launch_bounds__(256) void feat_grad_combine_bn_kernel(WslSrc f, const float* ga, int64_t ga_bs, const float* gb,
+                                                                   int64_t gb_bs, const float* gb_cmask, const float* gp,
+                                                                   float* g, int H, int W, const float* bn_mean,
+                                                                   const float* bn_invstd, float* bn_part) {
+  __shared__ float red[8];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
+  const int64_t HW = (int64_t)H * W;
+  const float cm = gb_cmask ? gb_cmask[(int64_t)n * f.C + c] : 1.f;
+  const float sc = f.scale[c], sh = f.shift[c], mean = bn_mean[c], invstd = bn_invstd[c];
+  const float* fy = f.x + n * f.bs + c * HW;
+  float s1 = 0.f, s2 = 0.f;
+  const int base = blockIdx.x * kChunk;
+  for (int o = base + threadIdx.x; o < base + kChunk && o < Hc * Wc; o += kThreads) {
+    const int cy = o / Wc, cx = o - cy * Wc;
+    float yv[4], zv[4];
+    bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 2 * cy + (k >> 1), x = 2 * cx + (k & 1);
+      in[k] = y < H && x < W;
+      yv[k] = in[k] ? fy[(int64_t)y * W + x] : 0.f;
+      zv[k] = fmaf(yv[k], sc, sh);
+    }
+    int arg = -1;
+    float gpool = 0.f;
+    if (gp && cy < Ho && cx < Wo) {
+      float best = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = leaky(zv[k]);            // the pooled quantity: leaky(bn(y)), as src_value() computes it
+        if (k == 0 || v > best) best = v, arg = k;
+      }
+      gpool = gp[((int64_t)n * f.C + c) * Ho * Wo + (int64_t)cy * Wo + cx];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (in[k]) {
+        const int64_t off = (int64_t)(2 * cy + (k >> 1)) * W + 2 * cx + (k & 1);
+        float v = 0.f;
+        if (ga) v = ga[n * ga_bs + c * HW + off];
+        if (gb) v = fmaf(gb[n * gb_bs + c * HW + off], cm, v);
+        if (k == arg) v += gpool;
+        g[((int64_t)n * f.C + c) * HW + off] = v;
+        const float d = zv[k] > 0.f ? v : WSL_LEAKY_SLOPE * v;
+        s1 += d;
+        s2 = fmaf(d, (yv[k] - mean) * invstd, s2);
+      }
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red + 4);
+  if (threadIdx.x == 0) {
+    float* dst = bn_part + (((int64_t)n * gridDim.x + blockIdx.x) * f.C + c) * 2;
+    dst[0] = s1;
+    dst[1] = s2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ BN + act backward
 struct BnBwdP {
   const float* g;
@@ -253,14 +316,18 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const f
   }
 }
 
-__global__ __launch_bounds__(256) void bnact_bwd_finalize_kernel(const float* part, int nblk, int C, double count,
-                                                                 float* dgamma, float* dbeta, float* coef) {
+// part: [nblk][C][2] (sb = C, sc = 1: the stand-alone reduction pass and the fan-in kernel) or [C][nblk][2] (sb = 1, sc = nblk:
+// the convolution epilogues)
+__global__ __launch_bounds__(256) void bnact_bwd_finalize_kernel(const float* part, int nblk, int C, int64_t sb, int64_t sc,
+                                                                 double count, float* dgamma, float* dbeta, float* coef) {
   __shared__ double red[kThreads];
   const int c = blockIdx.x;
   double s1 = 0, s2 = 0;
+#pragma unroll 4
   for (int b = threadIdx.x; b < nblk; b += kThreads) {
-    s1 += part[((int64_t)b * C + c) * 2];
-    s2 += part[((int64_t)b * C + c) * 2 + 1];
+    const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)b * sb + (int64_t)c * sc) * 2);
+    s1 += v.x;
+    s2 += v.y;
   }
   s1 = block_sum_d(s1, red);
   s2 = block_sum_d(s2, red);
@@ -405,6 +472,53 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwdc_kernel(const float* u, 
   }
 }
 
+// forward, third form: the source rows an output row block touches are staged in LDS with coalesced float4 loads, a thread
+// owns FOUR consecutive output columns (their coordinates / weights in registers) and walks rows -> one 16-byte store per
+// output quad instead of four 4-byte ones, sources read from LDS.  Same expressions as the kernels above.
+constexpr int kUpFR = 32;                    // output rows per workgroup
+__global__ __launch_bounds__(256) void bilinear_up2_fwd4_kernel(const float* u, float* out, int64_t out_bs, int C, int h, int w,
+                                                                int lq) {
+  __shared__ __attribute__((aligned(16))) float st[(kUpFR / 2 + 3) * 128];
+  const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
+  const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+  const float* src = u + ((int64_t)n * C + c) * h * w;
+  float* dst = out + n * out_bs + (int64_t)c * Ho * Wo;
+  const int oy0 = blockIdx.x * kUpFR;
+  int oy1 = oy0 + kUpFR;
+  if (oy1 > Ho) oy1 = Ho;
+  int ya, yb, dummy;
+  float fdummy;
+  lerp_coord(oy0, sy, h, &ya, &dummy, &fdummy);          // first source row of the block
+  lerp_coord(oy1 - 1, sy, h, &dummy, &yb, &fdummy);      // last one
+  const int nrows = yb - ya + 1, w4 = w >> 2;
+  for (int e = threadIdx.x; e < nrows * w4; e += kThreads) {
+    const int r = e / w4, q = e - r * w4;
+    *reinterpret_cast<float4*>(st + r * w + 4 * q) = *reinterpret_cast<const float4*>(src + (int64_t)(ya + r) * w + 4 * q);
+  }
+  const int quads = Wo >> 2;                              // 2^lq column quads per output row
+  const int cq = threadIdx.x & (quads - 1), rl = threadIdx.x >> lq, rstep = kThreads >> lq;
+  int x0[4], x1[4];
+  float lx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lerp_coord(4 * cq + j, sx, w, &x0[j], &x1[j], &lx[j]);
+  __syncthreads();
+  for (int oy = oy0 + rl; oy < oy1; oy += rstep) {
+    int y0, y1;
+    float ly;
+    lerp_coord(oy, sy, h, &y0, &y1, &ly);
+    const float* s0 = st + (y0 - ya) * w;
+    const float* s1 = st + (y1 - ya) * w;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float top = (1.f - lx[j]) * s0[x0[j]] + lx[j] * s0[x1[j]];
+      const float bot = (1.f - lx[j]) * s1[x0[j]] + lx[j] * s1[x1[j]];
+      o[j] = (1.f - ly) * top + ly * bot;
+    }
+    *reinterpret_cast<float4*>(dst + (int64_t)oy * Wo + 4 * cq) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 constexpr int kUpTI = 16;                    // input rows per workgroup of the transpose kernel
 constexpr int kUpRows = 2 * kUpTI + 3;       // output-gradient rows its stencils touch
 constexpr int kUpMaxPitch = 2 * 64 + 8;
@@ -412,6 +526,7 @@ constexpr int kUpMaxPitch = 2 * 64 + 8;
 __global__ __launch_bounds__(256) void bilinear_up2_bwd4_kernel(const float* dout, int64_t dout_bs, float* du, int C, int h,
                                                                 int w, int ltj) {
   __shared__ __attribute__((aligned(16))) float tile[kUpRows * kUpMaxPitch];
+  __shared__ float wyt[kUpTI * 5];   // row weights of the workgroup's input rows: computed once instead of per output element
   const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
   const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
   const float* g = dout + n * dout_bs + (int64_t)c * Ho * Wo;
@@ -425,6 +540,17 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd4_kernel(const float* dou
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (Y >= 0 && Y < Ho && X >= 0 && X < Wo) v = *reinterpret_cast<const float4*>(g + (int64_t)Y * Wo + X);
     *reinterpret_cast<float4*>(tile + row * pitch + 4 * q) = v;
+  }
+  if (threadIdx.x < kUpTI * 5) {
+    const int ti = threadIdx.x / 5, ky = threadIdx.x - 5 * ti, i = i0 + ti, Y = 2 * i - 2 + ky;
+    float wy = 0.f;
+    if (Y >= 0 && Y < Ho) {
+      int a, b;
+      float l;
+      lerp_coord(Y, sy, h, &a, &b, &l);
+      wy = (a == i ? 1.f - l : 0.f) + (b == i ? l : 0.f);
+    }
+    wyt[threadIdx.x] = wy;
   }
   const int tj = threadIdx.x & (TJ - 1), ty = threadIdx.x >> ltj, tstep = kThreads >> ltj;
   const int j = j0 + tj;
@@ -446,14 +572,7 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd4_kernel(const float* dou
     float acc = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) {
-      const int Y = 2 * i - 2 + ky;
-      float wy = 0.f;
-      if (Y >= 0 && Y < Ho) {
-        int a, b;
-        float l;
-        lerp_coord(Y, sy, h, &a, &b, &l);
-        wy = (a == i ? 1.f - l : 0.f) + (b == i ? l : 0.f);
-      }
+      const float wy = wyt[5 * ti + ky];
       if (wy != 0.f) {   // same skipping and order as the reference kernel above
         const float* tr = tile + (2 * ti + ky) * pitch + 2 * tj + 2;
         float row = 0.f;
@@ -527,7 +646,9 @@ extern "C" int wsl_feat_grad_combine(const WslSrc* f, const float* ga, int64_t g
 
 extern "C" size_t wsl_bnact_bwd_ws_bytes(int N, int C, int H, int W) {
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-  return sizeof(float) * ((size_t)N * cdiv(H * W, kChunk) * C * 2 + 2 * (size_t)C);
+  // partials: one per 4096-element chunk (reduction pass, fan-in kernel) or one per conv tile (>= 256 pixels) when the
+  // statistics come from a convolution epilogue; + 2 C coefficients
+  return sizeof(float) * ((size_t)N * cdiv(H * W, 256) * C * 2 + 2 * (size_t)C);
 }
 
 extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
@@ -552,17 +673,60 @@ extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const
                    (!emask || (reinterpret_cast<uintptr_t>(emask) & 3) == 0);
   if (vec) WSL_LAUNCH(bnact_bwd_reduce4_kernel, grid, dim3(kThreads), 0, stream, p, part);
   else WSL_LAUNCH(bnact_bwd_reduce_kernel, grid, dim3(kThreads), 0, stream, p, part);
-  WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, N * p.chunks, C,
+  WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, N * p.chunks, C, (int64_t)C, (int64_t)1,
              (double)N * H * W, dgamma, dbeta, coef);
   if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
   else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
   return check_launch("bnact_bwd");
 }
 
+extern "C" int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                                    float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
+                                    int channel_major, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(g && y && mean && invstd && gamma && beta && dy && ws && part, "bnact_bwd_finish: null argument");
+  WSL_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && nblk > 0, "bnact_bwd_finish: bad shape");
+  WSL_REQUIRE(ws_bytes >= sizeof(float) * 2 * (size_t)C, "bnact_bwd_finish: workspace needs 2 * C floats");
+  BnBwdP p{g, g_bs, y, mean, invstd, gamma, beta, emask, emask_scale, C, H * W, cdiv(H * W, kChunk)};
+  ProfScope ps(PF_BN_BWD, 0.0, (double)N * C * H * W * (12.0 + (emask ? 1.0 : 0.0)), stream);     // the apply pass alone
+  float* coef = static_cast<float*>(ws);
+  dim3 grid(p.chunks, C, N);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool vec = (H * W) % 4 == 0 && (g_bs % 4) == 0 && al16(g) && al16(y) && al16(dy) &&
+                   (!emask || (reinterpret_cast<uintptr_t>(emask) & 3) == 0);
+  WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, nblk, C,
+             channel_major ? (int64_t)1 : (int64_t)C, channel_major ? (int64_t)nblk : (int64_t)1, (double)N * H * W, dgamma, dbeta,
+             coef);
+  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
+  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
+  return check_launch("bnact_bwd_finish");
+}
+
+extern "C" int wsl_feat_grad_combine_blocks(int N, int H, int W) {
+  return N > 0 && H > 0 && W > 0 ? N * cdiv(((H + 1) / 2) * ((W + 1) / 2), kChunk) : 0;
+}
+
+extern "C" int wsl_feat_grad_combine_bn(const WslSrc* f, const float* ga, int64_t ga_bs, const float* gb, int64_t gb_bs,
+                                        const float* gb_cmask, const float* gp, float* g, int N, int H, int W,
+                                        const float* bn_mean, const float* bn_invstd, float* bn_part, void* stream) {
+  WSL_REQUIRE(f && f->x && f->scale && f->shift && !f->emask && !f->cmask && g && N > 0 && H > 0 && W > 0 && f->C > 0,
+              "feat_grad_combine_bn: the feature must be a plain BatchNorm + LeakyReLU source");
+  WSL_REQUIRE(bn_mean && bn_invstd && bn_part, "feat_grad_combine_bn: null BatchNorm argument");
+  ProfScope ps(PF_POOL_FANIN, 0.0, (double)N * f->C * H * W * (4.0 * (ga ? 1 : 0) + 4.0 * (gb ? 1 : 0) + (gp ? 1.0 : 0.0) + 8.0), stream);
+  WSL_LAUNCH(feat_grad_combine_bn_kernel, dim3(cdiv(((H + 1) / 2) * ((W + 1) / 2), kChunk), f->C, N), dim3(kThreads), 0,
+             stream, *f, ga, ga_bs, gb, gb_bs, gb_cmask, gp, g, H, W, bn_mean, bn_invstd, bn_part);
+  return check_launch("feat_grad_combine_bn_kernel");
+}
+
 extern "C" int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream) {
   WSL_REQUIRE(u && out && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_fwd: bad args");
   WSL_REQUIRE(out_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_fwd: out batch stride too small");
   ProfScope ps(PF_BILINEAR, 0.0, 20.0 * (double)N * C * h * w, stream);            // read 4 B per input, write 4 x 4 B
+  if (up2_fast_ok(out, out_bs, w) && (reinterpret_cast<uintptr_t>(u) & 15) == 0) {
+    WSL_LAUNCH(bilinear_up2_fwd4_kernel, dim3(cdiv(2 * h, kUpFR), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C, h, w,
+               ilog2(2 * w) - 2);
+    return check_launch("bilinear_up2_fwd4_kernel");
+  }
   if (up2_fast_ok(out, out_bs, w)) {
     const int lw = ilog2(2 * w);                                    // output row width = 2^lw <= 256
     int rows = 8192 / (2 * w);                                      // ~8K outputs per workgroup

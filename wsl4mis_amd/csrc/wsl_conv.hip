@@ -550,7 +550,7 @@ bool conv2_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_
 int conv2_pack(const float* w, float* wp, int Co, int Ci, int ks, int wmode, void* stream);
 int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
               int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
-              int slots, void* stream);
+              int slots, void* stream, const BnBwdEpi* bn = nullptr, int* bn_done = nullptr);
 // wsl_conv3.hip
 int wgrad_small_kind(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks);   // wsl_conv4.hip
 int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
@@ -561,7 +561,8 @@ int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* 
                     void* stream);
 int wino_pack(const float* w, float* u, int Co, int Ci, int dgrad, void* stream);   // wsl_conv5.hip
 int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias, float* y, int64_t y_bs, int N, int H,
-             int W, int Co, int is_dgrad, float* stat_part, float* stat_cnt, int slots, void* stream);
+             int W, int Co, int is_dgrad, float* stat_part, float* stat_cnt, int slots, void* stream,
+             const BnBwdEpi* bn = nullptr, int* bn_done = nullptr);
 bool conv3_enabled();
 void conv_set_variant(int v);
 int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
@@ -625,9 +626,10 @@ extern "C" int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int k
   return (conv3_enabled() ? 4 : 1) * N * cdiv(H, f.th) * cdiv(W, f.tw);
 }
 
-extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y,
-                              int64_t y_bs, int N, int H, int W, int Co, int ks, int wmode, float* stat_part,
-                              float* stat_cnt, void* stream) {
+static int conv2d_fwd_impl(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y, int64_t y_bs, int N,
+                           int H, int W, int Co, int ks, int wmode, float* stat_part, float* stat_cnt, void* stream,
+                           const BnBwdEpi* bn, int* bn_done) {
+  if (bn_done) *bn_done = 0;
   WSL_REQUIRE(a && w && y, "conv2d_fwd: null argument");
   WSL_REQUIRE(N > 0 && H > 0 && W > 0 && Co > 0, "conv2d_fwd: bad shape N=%d H=%d W=%d Co=%d", N, H, W, Co);
   WSL_REQUIRE(ks == 1 || ks == 3, "conv2d_fwd: kernel size %d not built (1 and 3 are)", ks);
@@ -655,7 +657,7 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
     }
     if (wmode >= 4) {   // `w` is the Winograd image of wsl_conv2d_pack_weights(wmode_raw 2 | 3)
       WSL_REQUIRE(f.wino && !conv3_enabled(), "conv2d_fwd: wmode %d needs wsl_conv2d_wino_ok() != 0 for this layer", wmode);
-      return wino_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, wmode == 5, stat_part, stat_cnt, p.slots, stream);
+      return wino_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, wmode == 5, stat_part, stat_cnt, p.slots, stream, bn, bn_done);
     }
     static const bool cls_on = (WSL_TUNE("WSL_CONV_CLS", 1) != 0);
     if (cls_on && wmode == 2 && conv_cls_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, stat_part))
@@ -664,11 +666,30 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
       return conv3_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
                        stat_cnt, stream);
     return conv2_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
-                     stat_cnt, p.slots, stream);
+                     stat_cnt, p.slots, stream, bn, bn_done);
   }
   p.tiles_x = cdiv(W, f.tw), p.tiles_y = cdiv(H, f.th);
   p.vec_ok = (W % 4 == 0) && (y_bs % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
   return ks == 3 ? dispatch_conv<3>(p, f, stream) : dispatch_conv<1>(p, f, stream);
+}
+
+extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y,
+                              int64_t y_bs, int N, int H, int W, int Co, int ks, int wmode, float* stat_part,
+                              float* stat_cnt, void* stream) {
+  return conv2d_fwd_impl(a, b, w, bias, y, y_bs, N, H, W, Co, ks, wmode, stat_part, stat_cnt, stream, nullptr, nullptr);
+}
+
+extern "C" int wsl_conv2d_dgrad_bn(const WslSrc* dy, const float* w, float* g, int64_t g_bs, int N, int H, int W, int Co,
+                                   int ks, int wmode, const float* bn_y, const float* bn_st, const uint8_t* bn_emask,
+                                   float bn_emask_scale, float* bn_part, int* fused, void* stream) {
+  WSL_REQUIRE(bn_y && bn_st && bn_part && fused, "conv2d_dgrad_bn: null BatchNorm argument");
+  WSL_REQUIRE(wmode == 1 || wmode == 3 || wmode == 5, "conv2d_dgrad_bn: wmode %d is not a data-gradient mode", wmode);
+  BnBwdEpi e;
+  e.y = bn_y, e.st = bn_st, e.emask = bn_emask, e.es = bn_emask_scale, e.part = bn_part;
+  if (g_bs != (int64_t)Co * H * W || (W & 3) || (reinterpret_cast<uintptr_t>(bn_y) & 15) ||
+      (bn_emask && (reinterpret_cast<uintptr_t>(bn_emask) & 3)))
+    e.part = nullptr;        // the statistics address y through the dense index of g: same shape, float4-aligned rows
+  return conv2d_fwd_impl(dy, nullptr, w, nullptr, g, g_bs, N, H, W, Co, ks, wmode, nullptr, nullptr, stream, &e, fused);
 }
 
 extern "C" size_t wsl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co, int ks) {
@@ -679,8 +700,9 @@ extern "C" size_t wsl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co,
   return sizeof(float) * (size_t)ns * ((size_t)ks * ks * Co * Ci + Co);
 }
 
-extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db,
-                                int N, int H, int W, int Co, int ks, void* ws, size_t ws_bytes, void* stream) {
+// first stage of the weight gradient: per-split partial sums into `ws`; *out describes the pending second stage
+static int wgrad_stage1(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db, int N, int H, int W,
+                        int Co, int ks, void* ws, size_t ws_bytes, void* stream, WslWgradPending* out) {
   WSL_REQUIRE(a && dy && dw && ws, "conv2d_wgrad: null argument");
   WSL_REQUIRE(N > 0 && H > 0 && W > 0 && Co > 0, "conv2d_wgrad: bad shape");
   WSL_REQUIRE(ks == 1 || ks == 3, "conv2d_wgrad: kernel size %d not built (1 and 3 are)", ks);
@@ -730,6 +752,94 @@ extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* d
   } else if (int rc = (ks == 3 ? dispatch_wgrad<3>(p, g, stream) : dispatch_wgrad<1>(p, g, stream))) {
     return rc;
   }
+  out->part_dw = p.part_dw, out->part_db = p.part_db, out->dw = dw, out->db = db;
+  out->Co = Co, out->Ci = Ci, out->KK = KK, out->nsplit = g.nsplit;
+  return WSL_OK;
+}
+
+extern "C" int wsl_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db,
+                                        int N, int H, int W, int Co, int ks, void* ws, size_t ws_bytes, WslWgradPending* pending,
+                                        void* stream) {
+  WSL_REQUIRE(pending, "conv2d_wgrad_partial: null pending record");
+  return wgrad_stage1(a, b, dy, dy_bs, dw, db, N, H, W, Co, ks, ws, ws_bytes, stream, pending);
+}
+
+// second stage of up to kReduceMax pending weight gradients in ONE launch: a workgroup = 32 consecutive elements of one
+// layer x 8 split groups, merged through LDS in a fixed order (same scheme as wgrad_reduce_kernel)
+constexpr int kReduceMax = 40;
+struct ReduceTable {
+  int n;
+  int _pad;
+  struct E {
+    const float* pdw;
+    const float* pdb;
+    float* dw;
+    float* db;
+    int Co, Ci, KK, nsplit;
+    int64_t blk0;          // first workgroup of this layer
+  } e[kReduceMax];
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(ReduceTable t) {
+  __shared__ float red[kThreads];
+  constexpr int SG = 8, EPB = kThreads / SG;
+  int li = 0;
+  for (int i = 1; i < t.n; ++i) li = (int64_t)blockIdx.x >= t.e[i].blk0 ? i : li;   // uniform
+  const ReduceTable::E& L = t.e[li];
+  const int64_t E = (int64_t)L.KK * L.Co * L.Ci;
+  const int64_t total = E + (L.db ? L.Co : 0);
+  const int el = threadIdx.x % EPB, sg = threadIdx.x / EPB;
+  const int64_t e = ((int64_t)blockIdx.x - L.blk0) * EPB + el;
+  float s = 0.f;
+  if (e < total) {
+    const float* src = e < E ? L.pdw + e : L.pdb + (e - E);
+    const int64_t stride = e < E ? E : L.Co;
+    for (int k = sg; k < L.nsplit; k += SG) s += src[k * stride];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sg == 0 && e < total) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < SG; ++k) v += red[k * EPB + el];
+    if (e < E) {
+      const int tap = (int)(e / ((int64_t)L.Co * L.Ci));
+      const int64_t rem = e - (int64_t)tap * L.Co * L.Ci;  // co*Ci + ci
+      L.dw[rem * L.KK + tap] = v;
+    } else {
+      L.db[e - E] = v;
+    }
+  }
+}
+
+extern "C" int wsl_wgrad_reduce_batch(const WslWgradPending* items, int n, void* stream) {
+  WSL_REQUIRE(items && n > 0, "wgrad_reduce_batch: nothing to reduce");
+  for (int i0 = 0; i0 < n; i0 += kReduceMax) {
+    ReduceTable t;
+    t.n = n - i0 < kReduceMax ? n - i0 : kReduceMax, t._pad = 0;
+    int64_t blk = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < t.n; ++i) {
+      const WslWgradPending& q = items[i0 + i];
+      WSL_REQUIRE(q.part_dw && q.dw && q.Co > 0 && q.Ci > 0 && q.KK > 0 && q.nsplit > 0, "wgrad_reduce_batch: item %d is malformed", i0 + i);
+      const int64_t total = (int64_t)q.KK * q.Co * q.Ci + (q.db ? q.Co : 0);
+      t.e[i] = ReduceTable::E{q.part_dw, q.part_db, q.dw, q.db, q.Co, q.Ci, q.KK, q.nsplit, blk};
+      blk += (total + 31) / 32;
+      bytes += 4.0 * (double)total * (q.nsplit + 1);
+    }
+    ProfScope ps(PF_WGRAD_REDUCE, 0.0, bytes, stream);
+    WSL_LAUNCH(wgrad_reduce_batch_kernel, dim3((unsigned)blk), dim3(kThreads), 0, stream, t);
+  }
+  return check_launch("wgrad_reduce_batch_kernel");
+}
+
+extern "C" int wsl_conv2d_wgrad(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db,
+                                int N, int H, int W, int Co, int ks, void* ws, size_t ws_bytes, void* stream) {
+  WslWgradPending q;
+  if (int rc = wgrad_stage1(a, b, dy, dy_bs, dw, db, N, H, W, Co, ks, ws, ws_bytes, stream, &q)) return rc;
+  const int KK = q.KK, Ci = q.Ci;
+  struct { int nsplit; } g{q.nsplit};
+  struct { const float* part_dw; const float* part_db; } p{q.part_dw, q.part_db};
   const int64_t total = (int64_t)KK * Co * Ci + (db ? Co : 0);
   void* tok = prof_begin(PF_WGRAD_REDUCE, 0.0, 4.0 * (double)total * (g.nsplit + 1), stream);
   struct EndProf { void* t; void* s; ~EndProf() { prof_end(t, s); } } endprof{tok, stream};

@@ -38,6 +38,7 @@ struct Conv2P {
   float* stat_cnt;
   int slots;    // BatchNorm partial slots per tile (1; 4 when the wave-specialised variant is active)
   int ablate;   // debug (env WSL_CONV_ABLATE): 1 skip MFMA, 2 skip staging after the first chunk, 4 skip epilogue
+  BnBwdEpi bn;  // data-gradient launches: BatchNorm-backward statistics of the consumer of y (wsl_rt.h)
 };
 
 template <int KS, int TH, int TW, int CO_T, int KC>
@@ -266,6 +267,27 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
         bsum[j] += (v[0] + v[1]) + (v[2] + v[3]);
       }
     }
+  }
+  if (p.bn.part) {   // BatchNorm-backward statistics of the layer that consumes this gradient (dense y, same [N][Co][H][W] shape)
+    float s1[C::NT], s2[C::NT];
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int co = co0 + j * 16 + (lane & 15);
+      s1[j] = 0.f, s2[j] = 0.f;
+      if (co < p.Co) {
+        const float mean = p.bn.st[co], invstd = p.bn.st[p.Co + co], sc = p.bn.st[2 * p.Co + co], sh = p.bn.st[3 * p.Co + co];
+#pragma unroll
+        for (int i = 0; i < C::MT; ++i) {
+          const int mt = wave * C::MT + i;
+          const int oy = y0 + mt / C::SEGS, ox = x0 + (mt % C::SEGS) * 16 + (lane >> 4) * 4;
+          if (oy < H && ox < W)
+            bn_bwd_acc4(p.bn, ((int64_t)n * p.Co + co) * HW + (int64_t)oy * W + ox, acc[i][j][0], acc[i][j][1], acc[i][j][2],
+                        acc[i][j][3], mean, invstd, sc, sh, s1[j], s2[j]);
+        }
+      }
+    }
+    bn_bwd_store<C::NT, CO_T>(p.bn, s1, s2, in_t, co0, p.Co, tile_id, (int)gridDim.x);
+    return;
   }
   if (p.stat_part) {
     float* red1 = in_t;
@@ -520,6 +542,26 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINWL)) void 
     return;
   }
 #endif
+  // BatchNorm-backward statistics of the layer that consumes this gradient (tile and channel block are full).  Only in the
+  // instantiations with <= 32 accumulator registers: with 64 the extra loads push the allocator into scratch (72-92 spills)
+  if constexpr (C::MT * C::NT * 4 <= 32) if (p.bn.part) {
+    constexpr int RPW = C::MT / C::SEGS;
+    float s1[C::NT], s2[C::NT];
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int co = co0 + j * 16 + (lane & 15);
+      const float mean = p.bn.st[co], invstd = p.bn.st[Co + co], sc = p.bn.st[2 * Co + co], sh = p.bn.st[3 * Co + co];
+      const int64_t base = ((int64_t)n * Co + co) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+      s1[j] = 0.f, s2[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i) {
+        bn_bwd_acc4(p.bn, base + (i / C::SEGS) * W + (i % C::SEGS) * 16, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3],
+                    mean, invstd, sc, sh, s1[j], s2[j]);
+      }
+    }
+    bn_bwd_store<C::NT, CO_T>(p.bn, s1, s2, in_t, co0, Co, tile_id, nb);
+    return;
+  }
   if (p.stat_part) {
     float* red1 = in_t;
     float* red2 = in_t + 4 * CO_T;
@@ -821,7 +863,7 @@ static int launch_conv2(Conv2P& p, int wmode_for_prof, void* stream) {
     static const bool dma_on = WSL_TUNE("WSL_CONV_DMA", 0) != 0;
     const bool raw = !p.a.scale && !p.a.emask && !p.a.cmask && (p.b.C == 0 || (!p.b.scale && !p.b.emask && !p.b.cmask));
     if constexpr (KS == 3) {   // (1x1 tiles are padded per plane: their slots are not lane-contiguous)
-      if (dma_on && raw) return launch_conv2r<KS, TH, TW, CO_T>(p, wmode_for_prof, stream);   // plain sources: LDS DMA
+      if (dma_on && raw && !p.bn.part) return launch_conv2r<KS, TH, TW, CO_T>(p, wmode_for_prof, stream);   // plain sources: LDS DMA (... except this opt-in one)
     }
     return launch_conv2l<KS, TH, TW, CO_T>(p, wmode_for_prof, stream);
   }
@@ -864,9 +906,13 @@ int conv2_pack(const float* w, float* wp, int Co, int Ci, int ks, int wmode, voi
 
 int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
               int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
-              int slots, void* stream) {
+              int slots, void* stream, const BnBwdEpi* bn, int* bn_done) {
   Conv2P p;
   p.slots = slots;
+  // the generic and the lean kernel carry the statistics epilogue -- the lean one in its instantiations with <= 32
+  // accumulator registers (th * tw * co_t <= 8192); the caller falls back to the stand-alone reduction pass otherwise
+  if (bn && bn->part && th * tw * co_t <= 8192) p.bn = *bn;
+  if (bn_done) *bn_done = p.bn.part ? 1 : 0;
   p.a = to_src2(a);
   p.b = (b && b->C > 0) ? to_src2(*b) : Src2{};
   p.wp = wp, p.bias = bias, p.y = y, p.y_bs = y_bs;

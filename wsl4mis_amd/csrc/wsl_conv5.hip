@@ -48,6 +48,7 @@ struct WinoP {
   float* stat_cnt;
   int slots;
   int ablate;   // debug (env WSL_CONV_ABLATE): 128 = per-workgroup timeline stamps into stat_part (tools/microbench_conv.py)
+  BnBwdEpi bn;  // data-gradient launches: BatchNorm-backward statistics of the consumer of y (wsl_rt.h)
 };
 
 template <int TH, int TW, int CO_T>
@@ -415,6 +416,28 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2]
       *reinterpret_cast<float4*>(yj + W + 4) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
       bsum[j] += bs;
     }
+  }
+  if (p.bn.part) {   // BatchNorm-backward statistics of the layer that consumes this gradient (o[][] holds 2 rows x 8 pixels)
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = co0 + j * 16 + (lane & 15);
+      const float mean = p.bn.st[co], invstd = p.bn.st[p.Co + co], sc = p.bn.st[2 * p.Co + co], sh = p.bn.st[3 * p.Co + co];
+      s1[j] = 0.f, s2[j] = 0.f;
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const int tb = (wave * MTW + m) * 16 + 4 * (lane >> 4);
+        const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
+        const int64_t base = ((int64_t)n * p.Co + co) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
+        const int a = m * NT + j;
+        bn_bwd_acc4(p.bn, base, o[a][0], o[a][1], o[a][2], o[a][3], mean, invstd, sc, sh, s1[j], s2[j]);
+        bn_bwd_acc4(p.bn, base + 4, o[a][4], o[a][5], o[a][6], o[a][7], mean, invstd, sc, sh, s1[j], s2[j]);
+        bn_bwd_acc4(p.bn, base + W, o[a][8], o[a][9], o[a][10], o[a][11], mean, invstd, sc, sh, s1[j], s2[j]);
+        bn_bwd_acc4(p.bn, base + W + 4, o[a][12], o[a][13], o[a][14], o[a][15], mean, invstd, sc, sh, s1[j], s2[j]);
+      }
+    }
+    bn_bwd_store<NT, CO_T>(p.bn, s1, s2, in_t, co0, p.Co, tile_id, nb);
+    return;
   }
   if (p.stat_part) {
     float* red1 = in_t;
@@ -945,7 +968,8 @@ static int launch_wino(WinoP& p, int is_dgrad, void* stream) {
 }
 
 int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias, float* y, int64_t y_bs, int N, int H,
-             int W, int Co, int is_dgrad, float* stat_part, float* stat_cnt, int slots, void* stream) {
+             int W, int Co, int is_dgrad, float* stat_part, float* stat_cnt, int slots, void* stream, const BnBwdEpi* bn,
+             int* bn_done) {
   WinoP p;
   p.a = to_wsrc(a);
   p.b = (b && b->C > 0) ? to_wsrc(*b) : WSrc{};
@@ -961,6 +985,10 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
   }
   p.tiles_x = W / tw, p.tiles_y = H / th;
   const int form = wino_form();   // 1: V through LDS, 2: V in registers
+  // the BatchNorm-backward statistics ride in the epilogue shared by conv_wino2 / conv_wino2r (not in the first form)
+  const bool bn_ok = bn && bn->part && (tw == 64 || (form == 2 && co_t == 32));
+  if (bn_ok) p.bn = *bn;
+  if (bn_done) *bn_done = bn_ok ? 1 : 0;
   if (tw == 64) return launch_wino2<8, 64, 1>(p, is_dgrad, stream);
   if (form == 2 && co_t == 32) {
     if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);

@@ -426,6 +426,176 @@ __global__ __launch_bounds__(256) void gatedcrf_fwd_kernel(CrfP q, float* part) 
   write_partials<2>(v, part, red);
 }
 
+// ---- fast form: C == 4, radius R known at compile time, W % 4 == 0.
+// A workgroup owns 32 x 32 pixels, a thread 4 consecutive pixels of one row.  K(p, q) = w exp(-(dx^2 + dy^2) / (2 sxy^2)) *
+// exp(-(I_q - I_p)^2 / (2 srgb^2)): the position factor does not depend on the pixel, so it enters as a per-tap constant
+// lxy = log2(w) - log2(e) (dx^2 + dy^2) / (2 sxy^2) (kernel argument, scalar registers) and the image is staged pre-scaled by
+// sqrt(log2(e) / 2) / srgb -- one subtract, one fma and one v_exp_f32 per tap and pixel:  k = exp2(lxy - (I'_q - I'_p)^2).
+// Per tap row a thread reads the 4 + 2R image values and class vectors its four pixels need ONCE (aligned 16-byte LDS
+// reads; y is staged class-interleaved, one float4 per pixel, row pitch odd in pixels -> conflict-free) and reuses them
+// across the 2R + 1 column offsets: 3.1x fewer LDS reads than a read per tap.
+// Taps outside the image (zero-padded unfold, gate_crf_loss.py:184-188) see the all-zero feature vector and y = 0: they add
+// w exp(-(fx^2 + fy^2 + fi^2) / 2) of the PIXEL's own features to sum(K) and nothing to the message.  Only workgroups
+// within R of the image border (BORDER, workgroup-uniform) pay for that: a staged validity plane turns sum(K) into
+// sum(k * valid) + (#outside taps) * k_outside.
+template <int R>
+struct Crf4P {
+  const float* y;
+  const float* img;
+  float* msg;
+  int N, H, W, tiles_x, tiles_y;
+  float sxy, srgb, weight, iscale;
+  float lxy[R + 1][R + 1];   // [|dy|][|dx|]
+};
+
+template <int R>
+struct Crf4Cfg {
+  static constexpr int TW = 32, TH = 32;   // tile column c is image column x0 - R + c: the window of segment s starts at column 4 s
+  static constexpr int WIN = 4 + 2 * R, WIN4 = (WIN + 3) / 4;                        // values / float4s per window
+  static constexpr int COLS = 4 * (TW / 4 - 1) + 4 * WIN4;                           // columns a window read may touch
+  static constexpr int YP = (COLS % 4 == 1) ? COLS : COLS + ((5 - COLS % 4) % 4);    // y pitch in pixels, == 1 (mod 4)
+  static constexpr int IP = (COLS + 3) / 4 * 4;                                      // image / validity pitch in floats
+  static constexpr int ROWS = TH + 2 * R;
+  static constexpr size_t SMEM = sizeof(float) * ((size_t)ROWS * YP * 4 + 2 * (size_t)ROWS * IP);
+};
+
+__device__ __forceinline__ float crf_exp2(float x) {
+#ifdef WSL_HOST_EMUL
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);   // v_exp_f32 (results below 2^-126 flush to zero: 40 orders below any term that counts)
+#endif
+}
+
+template <int R, bool BORDER>
+__device__ __forceinline__ void gatedcrf4_body(const Crf4P<R>& q, float* part, float* red, unsigned char* smem) {
+  using C = Crf4Cfg<R>;
+  constexpr int TW = C::TW, TH = C::TH, YP = C::YP, IP = C::IP, ROWS = C::ROWS, WIN4 = C::WIN4;
+  float4* yt = reinterpret_cast<float4*>(smem);                 // [ROWS][YP] class vectors, 0 outside the image
+  float* it = reinterpret_cast<float*>(yt + ROWS * YP);         // [ROWS][IP] image * iscale, 0 outside
+  float* vt = it + ROWS * IP;                                   // [ROWS][IP] 1 inside the image, 0 outside (BORDER only)
+  int bid = blockIdx.x;
+  const int tx_i = bid % q.tiles_x;
+  bid /= q.tiles_x;
+  const int ty_i = bid % q.tiles_y, n = bid / q.tiles_y;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = q.H, W = q.W;
+  const int64_t HW = (int64_t)H * W;
+  const float* yn = q.y + (int64_t)n * 4 * HW;
+  const float* in = q.img + (int64_t)n * HW;
+  // ---- stage: column c of the tile arrays is image column x0 - R + c
+  for (int e = threadIdx.x; e < ROWS * C::COLS; e += kThreads) {
+    const int ty = e / C::COLS, tx = e - ty * C::COLS, gy = y0 + ty - R, gx = x0 + tx - R;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int64_t g = (int64_t)gy * W + gx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float iv = 0.f;
+    if (ok) v = make_float4(yn[g], yn[HW + g], yn[2 * HW + g], yn[3 * HW + g]), iv = in[g] * q.iscale;
+    yt[ty * YP + tx] = v;
+    it[ty * IP + tx] = iv;
+    if (BORDER) vt[ty * IP + tx] = ok ? 1.f : 0.f;
+  }
+  __syncthreads();
+  const int seg = threadIdx.x & 7, ly = threadIdx.x >> 3;          // 8 segments of 4 pixels x 32 rows
+  const int gy = y0 + ly, gx = x0 + 4 * seg;
+  float v[2] = {0.f, 0.f};
+  if (gy < H && gx < W) {                                           // (W % 4 == 0: a segment is inside or outside as a whole)
+    float ip[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ip[p] = it[(ly + R) * IP + 4 * seg + R + p];
+    wsl_v2f m01[4], m23[4];
+    float ks[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) m01[p] = wsl_v2f{0.f, 0.f}, m23[p] = wsl_v2f{0.f, 0.f}, ks[p] = 0.f;
+#pragma unroll 1
+    for (int dy = -R; dy <= R; ++dy) {
+      const int ady = dy < 0 ? -dy : dy;
+      const float* irow = it + (ly + R + dy) * IP + 4 * seg;
+      const float4* yrow = yt + (ly + R + dy) * YP + 4 * seg;
+      float iw[4 * WIN4], vw[4 * WIN4];
+#pragma unroll
+      for (int j = 0; j < WIN4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(irow + 4 * j);
+        iw[4 * j] = t.x, iw[4 * j + 1] = t.y, iw[4 * j + 2] = t.z, iw[4 * j + 3] = t.w;
+        if (BORDER) {
+          const float4 u = *reinterpret_cast<const float4*>(vt + (ly + R + dy) * IP + 4 * seg + 4 * j);
+          vw[4 * j] = u.x, vw[4 * j + 1] = u.y, vw[4 * j + 2] = u.z, vw[4 * j + 3] = u.w;
+        }
+      }
+      // per-tap constants of this row: a uniform (scalar) select over |dy|
+      float lrow[R + 1];
+#pragma unroll
+      for (int a = 0; a <= R; ++a) {
+        float l = q.lxy[0][a];
+#pragma unroll
+        for (int b = 1; b <= R; ++b) l = ady == b ? q.lxy[b][a] : l;
+        lrow[a] = l;
+      }
+#pragma unroll
+      for (int j = 0; j < 4 + 2 * R; ++j) {        // window column j = pixel offset (p + dx + R)
+        const float4 yq = yrow[j];
+        const wsl_v2f y01 = {yq.x, yq.y}, y23 = {yq.z, yq.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int dx = j - p - R;
+          if (dx < -R || dx > R) continue;
+          const int adx = dx < 0 ? -dx : dx;
+          const float d = iw[j] - ip[p];
+          float k = crf_exp2(fmaf(-d, d, lrow[adx]));
+          if (dx == 0) k = dy == 0 ? 0.f : k;                      // centre tap := 0 (gate_crf_loss.py:171)
+          const wsl_v2f kk = {k, k};
+          m01[p] = __builtin_elementwise_fma(kk, y01, m01[p]);
+          m23[p] = __builtin_elementwise_fma(kk, y23, m23[p]);
+          if (BORDER) ks[p] = fmaf(k, vw[j], ks[p]);
+          else ks[p] += k;
+        }
+      }
+    }
+    float ym = 0.f, ksum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float4 yc = yt[(ly + R) * YP + 4 * seg + R + p];
+      ym = fmaf(m01[p][0], yc.x, ym), ym = fmaf(m01[p][1], yc.y, ym), ym = fmaf(m23[p][0], yc.z, ym), ym = fmaf(m23[p][1], yc.w, ym);
+      float kp = ks[p];
+      if (BORDER) {
+        // taps outside the image: all-zero feature vector against the pixel's own (x / sxy, y / sxy, I / srgb)
+        const int px = gx + p;
+        const int ny = (gy + R < H ? gy + R : H - 1) - (gy - R > 0 ? gy - R : 0) + 1;
+        const int nx = (px + R < W ? px + R : W - 1) - (px - R > 0 ? px - R : 0) + 1;
+        const int n_out = (2 * R + 1) * (2 * R + 1) - ny * nx;
+        if (n_out > 0) {
+          const float fx = (float)px / q.sxy, fy = (float)gy / q.sxy, fi = in[(int64_t)gy * W + px] / q.srgb;
+          const float e = (-0.5f * (fx * fx)) + (-0.5f * (fy * fy)) + (-0.5f * (fi * fi));
+          kp = fmaf((float)n_out, q.weight * expf(e), kp);
+        }
+      }
+      ksum += kp;
+    }
+    float* mo = q.msg + (int64_t)n * 4 * HW + (int64_t)gy * W + gx;
+    *reinterpret_cast<float4*>(mo) = make_float4(m01[0][0], m01[1][0], m01[2][0], m01[3][0]);
+    *reinterpret_cast<float4*>(mo + HW) = make_float4(m01[0][1], m01[1][1], m01[2][1], m01[3][1]);
+    *reinterpret_cast<float4*>(mo + 2 * HW) = make_float4(m23[0][0], m23[1][0], m23[2][0], m23[3][0]);
+    *reinterpret_cast<float4*>(mo + 3 * HW) = make_float4(m23[0][1], m23[1][1], m23[2][1], m23[3][1]);
+    v[0] = ksum, v[1] = ym;
+  }
+  write_partials<2>(v, part, red);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void gatedcrf_fwd4_kernel(Crf4P<R> q, float* part) {
+  WSL_DYN_SMEM(smem);
+  __shared__ float red[4];
+  using C = Crf4Cfg<R>;
+  int bid = blockIdx.x;
+  const int tx_i = bid % q.tiles_x;
+  bid /= q.tiles_x;
+  const int ty_i = bid % q.tiles_y;
+  const int y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+  const bool interior = y0 - R >= 0 && y0 + C::TH + R <= q.H && x0 - R >= 0 && x0 + C::TW + R <= q.W;   // uniform
+  if (interior) gatedcrf4_body<R, false>(q, part, red, smem);
+  else gatedcrf4_body<R, true>(q, part, red, smem);
+}
+
 __global__ __launch_bounds__(256) void gatedcrf_finalize_kernel(const float* part, int nblk, double denom, float* loss) {
   __shared__ double red[kThreads];
   const double ks = col_sum(part, nblk, 2, 0, red), ym = col_sum(part, nblk, 2, 1, red);
@@ -892,6 +1062,28 @@ extern "C" int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t*
   return check_launch("head_fwd_bwd");
 }
 
+template <int R>
+static int crf4_launch(const float* y, const float* img, float* msg, int N, int H, int W, float sxy, float srgb, float weight,
+                       float* part, int nb, void* stream) {
+  using C = Crf4Cfg<R>;
+  Crf4P<R> q;
+  q.y = y, q.img = img, q.msg = msg, q.N = N, q.H = H, q.W = W, q.tiles_x = cdiv(W, C::TW), q.tiles_y = cdiv(H, C::TH);
+  q.sxy = sxy, q.srgb = srgb, q.weight = weight;
+  const double l2e = 1.4426950408889634;
+  q.iscale = (float)(sqrt(0.5 * l2e) / (double)srgb);
+  for (int b = 0; b <= R; ++b)
+    for (int a = 0; a <= R; ++a)
+      q.lxy[b][a] = (float)(log2((double)weight) - l2e * 0.5 * (double)(a * a + b * b) / ((double)sxy * (double)sxy));
+  auto kern = gatedcrf_fwd4_kernel<R>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  WSL_LAUNCH(kern, dim3(nb), dim3(kThreads), C::SMEM, stream, q, part);
+  return check_launch("gatedcrf_fwd4_kernel");
+}
+
 extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, float* loss, int N, int C, int H, int W,
                                 int radius, float sigma_xy, float sigma_rgb, float weight, void* ws, size_t ws_bytes,
                                 void* stream) {
@@ -904,9 +1096,19 @@ extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, fl
   WSL_WS_OK("gatedcrf_fwd");
   CrfP q{y, img, msg, N, C, H, W, radius, sigma_xy, sigma_rgb, weight, cdiv(W, kCrfTW), cdiv(H, kCrfTH)};
   const int nb = N * q.tiles_x * q.tiles_y;
+  float* part = static_cast<float*>(ws);
+  if (C == 4 && (radius == 5 || radius == 2) && (W & 3) == 0 && weight > 0.f &&
+      (reinterpret_cast<uintptr_t>(msg) & 15) == 0) {
+    const int nb4 = N * cdiv(W, 32) * cdiv(H, 32);
+    ProfScope ps(PF_GATEDCRF, 0.0, 4.0 * (double)N * H * W * (2 * C + 1), stream);
+    const int rc = radius == 5 ? crf4_launch<5>(y, img, msg, N, H, W, sigma_xy, sigma_rgb, weight, part, nb4, stream)
+                               : crf4_launch<2>(y, img, msg, N, H, W, sigma_xy, sigma_rgb, weight, part, nb4, stream);
+    if (rc) return rc;
+    WSL_LAUNCH(gatedcrf_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb4, (double)N * H * W, loss);
+    return check_launch("gatedcrf_fwd");
+  }
   const int TSX = kCrfTW + 2 * radius, TSY = kCrfTH + 2 * radius;
   const size_t smem = sizeof(float) * ((size_t)(C + 1) * TSX * TSY + TSX + TSY);
-  float* part = static_cast<float*>(ws);
   void* tok = prof_begin(PF_GATEDCRF, 0.0, 4.0 * (double)N * H * W * (2 * C + 1), stream);   // 36 B/px at C = 4
   if (C == 4) WSL_LAUNCH((gatedcrf_fwd_kernel<4>), dim3(nb), dim3(kThreads), smem, stream, q, part);
   else if (C == 2) WSL_LAUNCH((gatedcrf_fwd_kernel<2>), dim3(nb), dim3(kThreads), smem, stream, q, part);

@@ -33,10 +33,10 @@ struct Plan {
   size_t pooled[5];
   struct DecWs { size_t u[4], up[4], dcat[4], glow4; BlkWs blk[4]; } wdec[2];
   // scratch reused from layer to layer; a second set lets the two decoders of unet_cct run on two streams
-  struct Scratch { size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws; } scr[2];
+  struct Scratch { size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws, bn_coef; } scr[2];
   size_t packf, packd;
   size_t winof, winod;   // Winograd filter images [16][Ci][Co] of the 3x3 layers, at twice the raw weight's offset
-  size_t wg_bytes, bn_bytes, total_floats;
+  size_t wg_bytes, bn_bytes, total_floats;   // wg_bytes: per scratch set, room for the partials of EVERY layer of a phase
 };
 
 struct Bump {
@@ -94,7 +94,12 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   Bump B;
   const size_t N = d->N;
   size_t max_stat = 0, max_cnt = 0;
-  P.wg_bytes = 0, P.bn_bytes = 0;
+  // weight-gradient partials stay alive until the phase's single second-stage launch: one region per layer.  A scratch set
+  // holds a decoder's layers or (set 0, after the main decoder's batch ran) the encoder's -> the larger of the two sums
+  size_t wg_enc = 0, wg_dec = 0;
+  P.bn_bytes = 0;
+  auto wg_add = [](size_t& acc, size_t bytes) { acc += (bytes + 255) & ~(size_t)255; };
+  size_t* wg_acc = &wg_enc;
   auto plan_blkws = [&](BlkWs& w, const BlockRef& k, int l) {
     const size_t e = N * k.c1.Co * P.H[l] * P.W[l];
     w.y1 = B.take(e), w.y2 = B.take(e);
@@ -103,8 +108,7 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
       const size_t nb = wsl_conv2d_stat_blocks(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
       if (nb * c->Co * 2 > max_stat) max_stat = nb * c->Co * 2;
       if (nb > max_cnt) max_cnt = nb;
-      const size_t wb = wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
-      if (wb > P.wg_bytes) P.wg_bytes = wb;
+      wg_add(*wg_acc, wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3));
     }
     const size_t bb = wsl_bnact_bwd_ws_bytes(d->N, k.c1.Co, P.H[l], P.W[l]);
     if (bb > P.bn_bytes) P.bn_bytes = bb;
@@ -114,26 +118,26 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
     P.pooled[l] = l ? B.take(N * kFt[l - 1] * P.H[l] * P.W[l]) : 0;
   }
   for (int k = 0; k < d->n_dec; ++k) {
+    wg_dec = 0, wg_acc = &wg_dec;
     for (int i = 0; i < 4; ++i) {
       const int l = 3 - i, c2 = kFt[l];
       P.wdec[k].u[i] = B.take(N * c2 * P.H[l + 1] * P.W[l + 1]);
       P.wdec[k].up[i] = B.take(N * c2 * P.H[l] * P.W[l]);
       P.wdec[k].dcat[i] = B.take(N * 2 * c2 * P.H[l] * P.W[l]);
       plan_blkws(P.wdec[k].blk[i], P.dec[k].blk[i], l);
-      const size_t wb = wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l + 1], P.W[l + 1], kFt[l + 1], c2, 1);
-      if (wb > P.wg_bytes) P.wg_bytes = wb;
+      wg_add(wg_dec, wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l + 1], P.W[l + 1], kFt[l + 1], c2, 1));
     }
     P.wdec[k].glow4 = B.take(N * kFt[4] * P.H[4] * P.W[4]);
-    const size_t wb = wsl_conv2d_wgrad_ws_bytes(d->N, P.H[0], P.W[0], kFt[0], d->n_class, 3);
-    if (wb > P.wg_bytes) P.wg_bytes = wb;
+    wg_add(wg_dec, wsl_conv2d_wgrad_ws_bytes(d->N, P.H[0], P.W[0], kFt[0], d->n_class, 3));
   }
+  P.wg_bytes = wg_enc > wg_dec ? wg_enc : wg_dec;
   const size_t big = N * kFt[0] * P.H[0] * P.W[0];  // largest activation (level 0; every deeper level is <= half)
   for (int k = 0; k < d->n_dec; ++k) {
     Plan::Scratch& S = P.scr[k];
     S.tmp_g = B.take(big), S.tmp_g1 = B.take(big), S.tmp_dy = B.take(big);
     S.tmp_du = B.take(big / 4), S.tmp_gpool = B.take(big / 4);
     S.stat_part = B.take(max_stat), S.stat_cnt = B.take(max_cnt);
-    S.wg_ws = B.take((P.wg_bytes + 3) / 4), S.bn_ws = B.take((P.bn_bytes + 3) / 4);
+    S.wg_ws = B.take((P.wg_bytes + 3) / 4), S.bn_ws = B.take((P.bn_bytes + 3) / 4), S.bn_coef = B.take(2 * kFt[4]);
   }
   if (d->n_dec == 1) P.scr[1] = P.scr[0];
   P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);  // packed [tap][ci][co] weight images (fwd / data-gradient)
@@ -143,6 +147,11 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
 }
 
 // ------------------------------------------------------------------------------------------------ helpers
+#define WSL_TRY(expr)           \
+  do {                          \
+    if (int rc_ = (expr)) return rc_; \
+  } while (0)
+
 struct Ctx {
   const Plan& P;
   const float* params;
@@ -153,8 +162,40 @@ struct Ctx {
   void* stream;
   int training;
   int si = 0;   // scratch set
+  struct WgBatch* wb = nullptr;   // weight gradients whose second stage is pending (one launch per phase)
   const Plan::Scratch& S() const { return P.scr[si]; }
 };
+
+// pending second stages of a phase (a decoder's backward, the encoder's backward) + the bump pointer into the set's wg_ws
+struct WgBatch {
+  WslWgradPending items[24];
+  int n = 0;
+  size_t off = 0;   // bytes
+};
+
+// weight gradient of one layer: stage 1 now (its partials get their own region of wg_ws), stage 2 with the phase's batch
+static int wgrad_layer(const Ctx& c, const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db, int H,
+                       int W, int Co, int ks) {
+  const int N = c.P.d.N, Ci = a->C + (b ? b->C : 0);
+  const size_t need = (wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks) + 255) & ~(size_t)255;
+  WgBatch* wb = c.wb;
+  if (!wb || wb->n >= 24 || wb->off + need > c.P.wg_bytes) {
+    set_error("net: weight-gradient batch overflow (%d pending, %zu + %zu of %zu bytes)", wb ? wb->n : -1, wb ? wb->off : 0, need,
+              c.P.wg_bytes);
+    return WSL_EWORKSPACE;
+  }
+  char* ws = reinterpret_cast<char*>(c.ws + c.S().wg_ws) + wb->off;
+  WSL_TRY(wsl_conv2d_wgrad_partial(a, b, dy, dy_bs, dw, db, N, H, W, Co, ks, ws, need, &wb->items[wb->n], c.stream));
+  wb->n += 1, wb->off += need;
+  return WSL_OK;
+}
+static int wgrad_flush(const Ctx& c) {
+  WgBatch* wb = c.wb;
+  if (!wb || wb->n == 0) return WSL_OK;
+  const int rc = wsl_wgrad_reduce_batch(wb->items, wb->n, c.stream);
+  wb->n = 0, wb->off = 0;
+  return rc;
+}
 
 static WslSrc raw_src(const float* x, int C, int64_t bs) {
   WslSrc s{};
@@ -170,11 +211,6 @@ static WslSrc act_src(const Ctx& c, size_t y, size_t st, int C, int HW, const ui
   return s;
 }
 
-#define WSL_TRY(expr)           \
-  do {                          \
-    if (int rc_ = (expr)) return rc_; \
-  } while (0)
-
 // forward (dgrad == 0) or data-gradient (dgrad == 1) convolution of layer `cv`: the packed fast path when the shapes
 // are float4-aligned (every layer of a net whose H, W are multiples of 16), the generic kernel otherwise.
 static int conv_any(const Ctx& c, const ConvRef& cv, int dgrad, const WslSrc* a, const WslSrc* b, const float* bias,
@@ -188,6 +224,47 @@ static int conv_any(const Ctx& c, const ConvRef& cv, int dgrad, const WslSrc* a,
                           dgrad ? 3 : 2, stp, stc, c.stream);
   }
   return wsl_conv2d_fwd(a, b, c.params + cv.w, bias, y, y_bs, N, H, W, Co, cv.ks, dgrad, stp, stc, c.stream);
+}
+
+// Partial sums of a BatchNorm-backward statistics pass that the producer of g already emitted (into the scratch set's bn_ws)
+struct GStats {
+  int nblk = 0;            // 0: none, run the stand-alone reduction pass
+  int channel_major = 0;
+};
+
+// data-gradient convolution of layer `cv` (dy -> g, dense) that also emits the backward statistics of the BatchNorm whose raw
+// input is ws[y] (coefficients ws[st], dropout keep mask emask) when the kernel it dispatches to can (wsl_conv2d_dgrad_bn)
+static int conv_dgrad_bn(const Ctx& c, const ConvRef& cv, const float* dy, float* g, int H, int W, size_t y, size_t st,
+                         const uint8_t* emask, float es, GStats* gs) {
+  const int N = c.P.d.N, Cg = cv.Ci;
+  const WslSrc dys = raw_src(dy, cv.Co, (int64_t)cv.Co * H * W);
+  const int64_t g_bs = (int64_t)Cg * H * W;
+  const float* w = c.params + cv.w;
+  int wmode = 1;
+  if (wsl_conv2d_fast_ok(&dys, nullptr, g, g_bs, W)) {
+    if (wsl_conv2d_wino_ok(N, H, W, cv.Co, 0, Cg, cv.ks)) w = c.ws + c.P.winod + 2 * cv.w, wmode = 5;
+    else w = c.ws + c.P.packd + cv.w, wmode = 3;
+  }
+  int fused = 0;
+  WSL_TRY(wsl_conv2d_dgrad_bn(&dys, w, g, g_bs, N, H, W, Cg, cv.ks, wmode, c.ws + y, c.ws + st, emask, es, c.ws + c.S().bn_ws,
+                              &fused, c.stream));
+  gs->nblk = fused ? wsl_conv2d_stat_blocks(N, H, W, cv.Co, Cg, cv.ks) : 0;
+  gs->channel_major = 1;
+  return WSL_OK;
+}
+
+// BatchNorm + LeakyReLU (+ Dropout) backward of one conv output: from the producer's partial sums when it emitted them
+static int bn_bwd(const Ctx& c, const float* g, int64_t g_bs, size_t y, size_t st, const BnRef& bn, const uint8_t* emask, float es,
+                  float* dy, int H, int W, const GStats& gs) {
+  const Plan& P = c.P;
+  const int C = bn.C;
+  const float* s = c.ws + st;
+  if (gs.nblk)
+    return wsl_bnact_bwd_finish(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy,
+                                c.grads + bn.gamma, c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, gs.nblk, gs.channel_major,
+                                c.ws + c.S().bn_coef, 2 * sizeof(float) * (size_t)C, c.stream);
+  return wsl_bnact_bwd(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy, c.grads + bn.gamma,
+                       c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, P.bn_bytes, c.stream);
 }
 
 static int pack_all(const Ctx& c, int with_dgrad) {
@@ -231,30 +308,25 @@ static int block_fwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslS
   return conv_bn_fwd(c, k.c2, k.b2, &mid, nullptr, w.y2, w.st2, H, W);
 }
 
-// backward of one ConvBlock given g = dL/d(block output) in `g` (batch stride g_bs).  Writes parameter grads;
-// if dgrad_out != NULL also d(block input) (all Ci channels, dense).
+// backward of one ConvBlock given g = dL/d(block output) in `g` (batch stride g_bs; `gs`: the statistics of the second
+// BatchNorm's backward when the producer of g emitted them).  Writes parameter grads; if dgrad_out != NULL also d(block input)
+// (all Ci channels, dense).
 static int block_bwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslSrc* a, const WslSrc* b, int l,
-                     const uint8_t* emask, float es, const float* g, int64_t g_bs, float* dgrad_out) {
+                     const uint8_t* emask, float es, const float* g, int64_t g_bs, const GStats& gs, float* dgrad_out) {
   const Plan& P = c.P;
-  const int N = P.d.N, H = P.H[l], W = P.W[l], C = k.c1.Co;
+  const int H = P.H[l], W = P.W[l], C = k.c1.Co;
   const int64_t CHW = (int64_t)C * H * W;
   float* dy = c.ws + c.S().tmp_dy;
   float* g1 = c.ws + c.S().tmp_g1;
-  const float* s1 = c.ws + w.st1;
-  const float* s2 = c.ws + w.st2;
   // BN2 + LeakyReLU (no dropout after the second activation)
-  WSL_TRY(wsl_bnact_bwd(g, g_bs, c.ws + w.y2, s2, s2 + C, c.params + k.b2.gamma, c.params + k.b2.beta, nullptr, 1.f, dy,
-                        c.grads + k.b2.gamma, c.grads + k.b2.beta, N, C, H, W, c.ws + c.S().bn_ws, P.bn_bytes, c.stream));
+  WSL_TRY(bn_bwd(c, g, g_bs, w.y2, w.st2, k.b2, nullptr, 1.f, dy, H, W, gs));
   const WslSrc mid = act_src(c, w.y1, w.st1, C, H * W, emask, es, nullptr);
-  WSL_TRY(wsl_conv2d_wgrad(&mid, nullptr, dy, CHW, c.grads + k.c2.w, c.grads + k.c2.b, N, H, W, C, 3, c.ws + c.S().wg_ws,
-                           P.wg_bytes, c.stream));
-  const WslSrc dys = raw_src(dy, C, CHW);
-  WSL_TRY(conv_any(c, k.c2, 1, &dys, nullptr, nullptr, g1, CHW, H, W, nullptr, nullptr));
-  // BN1 + LeakyReLU + Dropout(p)
-  WSL_TRY(wsl_bnact_bwd(g1, CHW, c.ws + w.y1, s1, s1 + C, c.params + k.b1.gamma, c.params + k.b1.beta, emask, es, dy,
-                        c.grads + k.b1.gamma, c.grads + k.b1.beta, N, C, H, W, c.ws + c.S().bn_ws, P.bn_bytes, c.stream));
-  WSL_TRY(wsl_conv2d_wgrad(a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, N, H, W, C, 3, c.ws + c.S().wg_ws, P.wg_bytes,
-                           c.stream));
+  WSL_TRY(wgrad_layer(c, &mid, nullptr, dy, CHW, c.grads + k.c2.w, c.grads + k.c2.b, H, W, C, 3));
+  // data gradient of the second convolution; its epilogue carries the statistics of BN1 + LeakyReLU + Dropout(p)
+  GStats g1s;
+  WSL_TRY(conv_dgrad_bn(c, k.c2, dy, g1, H, W, w.y1, w.st1, emask, es, &g1s));
+  WSL_TRY(bn_bwd(c, g1, CHW, w.y1, w.st1, k.b1, emask, es, dy, H, W, g1s));
+  WSL_TRY(wgrad_layer(c, a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, H, W, C, 3));
   if (dgrad_out) {
     const WslSrc dys1 = raw_src(dy, C, CHW);
     WSL_TRY(conv_any(c, k.c1, 1, &dys1, nullptr, nullptr, dgrad_out, (int64_t)k.c1.Ci * H * W, H, W, nullptr, nullptr));
@@ -294,30 +366,32 @@ static int decoder_bwd(const Ctx& c, int k, const float* const* cmasks, const fl
   float* g = c.ws + c.S().tmp_g;
   const ConvRef& oc = P.dec[k].out;
   const WslSrc last = act_src(c, P.wdec[k].blk[3].y2, P.wdec[k].blk[3].st2, kFt[0], H0 * W0, nullptr, 1.f, nullptr);
-  WSL_TRY(wsl_conv2d_wgrad(&last, nullptr, dlogits, (int64_t)oc.Co * H0 * W0, c.grads + oc.w, c.grads + oc.b, N, H0, W0,
-                           oc.Co, 3, c.ws + c.S().wg_ws, P.wg_bytes, c.stream));
-  const WslSrc dl = raw_src(dlogits, oc.Co, (int64_t)oc.Co * H0 * W0);
-  WSL_TRY(conv_any(c, oc, 1, &dl, nullptr, nullptr, g, (int64_t)kFt[0] * H0 * W0, H0, W0, nullptr, nullptr));
+  WSL_TRY(wgrad_layer(c, &last, nullptr, dlogits, (int64_t)oc.Co * H0 * W0, c.grads + oc.w, c.grads + oc.b, H0, W0, oc.Co, 3));
+  // data gradient of the classifier = dL/d(output of up4's block): its epilogue carries that block's BN2 statistics
+  GStats gs;
+  WSL_TRY(conv_dgrad_bn(c, oc, dlogits, g, H0, W0, P.wdec[k].blk[3].y2, P.wdec[k].blk[3].st2, nullptr, 1.f, &gs));
   for (int i = 3; i >= 0; --i) {
     const int l = 3 - i, c1 = kFt[l + 1], c2 = kFt[l];
     const int h = P.H[l + 1], w = P.W[l + 1], H = P.H[l], W = P.W[l];
     const WslSrc skip = feat_src(c, l, cmasks ? cmasks[l] : nullptr);
     const WslSrc up = raw_src(c.ws + P.wdec[k].up[i], c2, (int64_t)c2 * H * W);
     float* dcat = c.ws + P.wdec[k].dcat[i];
-    WSL_TRY(block_bwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f, g, (int64_t)c2 * H * W, dcat));
+    WSL_TRY(block_bwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f, g, (int64_t)c2 * H * W, gs, dcat));
     // d(up) = dcat[:, c2:]  ->  d(u)  ->  conv1x1 backward
     float* du = c.ws + c.S().tmp_du;
     WSL_TRY(wsl_bilinear_up2_bwd(dcat + (int64_t)c2 * H * W, (int64_t)2 * c2 * H * W, du, N, c2, h, w, c.stream));
     const WslSrc low = i == 0 ? feat_src(c, 4, cmasks ? cmasks[4] : nullptr)
                               : act_src(c, P.wdec[k].blk[i - 1].y2, P.wdec[k].blk[i - 1].st2, c1, h * w, nullptr, 1.f, nullptr);
     const ConvRef& cv = P.dec[k].c1x1[i];
-    WSL_TRY(wsl_conv2d_wgrad(&low, nullptr, du, (int64_t)c2 * h * w, c.grads + cv.w, c.grads + cv.b, N, h, w, c2, 1,
-                             c.ws + c.S().wg_ws, P.wg_bytes, c.stream));
-    const WslSrc dus = raw_src(du, c2, (int64_t)c2 * h * w);
-    float* glow = i == 0 ? c.ws + P.wdec[k].glow4 : g;
-    WSL_TRY(conv_any(c, cv, 1, &dus, nullptr, nullptr, glow, (int64_t)c1 * h * w, h, w, nullptr, nullptr));
+    WSL_TRY(wgrad_layer(c, &low, nullptr, du, (int64_t)c2 * h * w, c.grads + cv.w, c.grads + cv.b, h, w, c2, 1));
+    if (i == 0) {   // gradient of the bottleneck feature: joins the other decoder's in the encoder's fan-in
+      const WslSrc dus = raw_src(du, c2, (int64_t)c2 * h * w);
+      WSL_TRY(conv_any(c, cv, 1, &dus, nullptr, nullptr, c.ws + P.wdec[k].glow4, (int64_t)c1 * h * w, h, w, nullptr, nullptr));
+    } else {        // = dL/d(output of the previous stage's block): carries that block's BN2 statistics
+      WSL_TRY(conv_dgrad_bn(c, cv, du, g, h, w, P.wdec[k].blk[i - 1].y2, P.wdec[k].blk[i - 1].st2, nullptr, 1.f, &gs));
+    }
   }
-  return WSL_OK;
+  return wgrad_flush(c);   // second stage of this decoder's 13 weight gradients: one launch
 }
 
 static int encoder_bwd(const Ctx& c, const float* x, const uint8_t* const* emasks, const float* const* cmasks) {
@@ -339,14 +413,18 @@ static int encoder_bwd(const Ctx& c, const float* x, const uint8_t* const* emask
       ga = c.ws + P.wdec[0].dcat[i], bs = (int64_t)2 * C * H * W;
       if (dual) gb = c.ws + P.wdec[1].dcat[i];
     }
-    WSL_TRY(wsl_feat_grad_combine(&f, ga, bs, gb, bs, dual ? cmasks[l] : nullptr, l < 4 ? gpool : nullptr, g, N, H, W,
-                                  c.stream));
+    // fan-in of the feature's gradient + the statistics of its BatchNorm's backward in one pass
+    const float* st2 = c.ws + P.wenc[l].st2;
+    WSL_TRY(wsl_feat_grad_combine_bn(&f, ga, bs, gb, bs, dual ? cmasks[l] : nullptr, l < 4 ? gpool : nullptr, g, N, H, W, st2,
+                                     st2 + C, c.ws + c.S().bn_ws, c.stream));
+    GStats gs;
+    gs.nblk = wsl_feat_grad_combine_blocks(N, H, W), gs.channel_major = 0;
     const WslSrc in = l == 0 ? raw_src(x, P.d.in_chns, (int64_t)P.d.in_chns * H * W)
                              : raw_src(c.ws + P.pooled[l], kFt[l - 1], (int64_t)kFt[l - 1] * H * W);
-    WSL_TRY(block_bwd(c, P.enc[l], P.wenc[l], &in, nullptr, l, emasks[l], 1.f / (1.f - kDrop[l]), g, (int64_t)C * H * W,
+    WSL_TRY(block_bwd(c, P.enc[l], P.wenc[l], &in, nullptr, l, emasks[l], 1.f / (1.f - kDrop[l]), g, (int64_t)C * H * W, gs,
                       l > 0 ? gpool : nullptr));
   }
-  return WSL_OK;
+  return wgrad_flush(c);   // second stage of the encoder's 10 weight gradients: one launch
 }
 
 }  // namespace wsl
@@ -489,11 +567,13 @@ extern "C" int wsl_net_backward(const WslNetDesc* d, const float* params, const 
     return WSL_EWORKSPACE;
   }
   Ctx c{P, params, nullptr, nullptr, grads, static_cast<float*>(ws), stream, 1};
+  WgBatch wb0, wb1;
+  c.wb = &wb0;
   if (phase == 0 || phase == 1) {
     void* side = d->n_dec == 2 ? side_stream(stream) : nullptr;
     if (side) {
       Ctx c2 = c;
-      c2.stream = side, c2.si = 1;
+      c2.stream = side, c2.si = 1, c2.wb = &wb1;
       WSL_TRY(stream_fork(stream, side));
       WSL_TRY(decoder_bwd(c, 0, nullptr, dlogits_main));
       WSL_TRY(decoder_bwd(c2, 1, cmasks, dlogits_aux));

@@ -141,6 +141,68 @@ __device__ __forceinline__ float src_value(const WslSrc& s, int n, int c, int64_
   return v;
 }
 
+// BatchNorm + LeakyReLU (+ Dropout) BACKWARD statistics fused into the epilogue of the kernel that PRODUCES g = dL/d(block
+// activation): per tile and channel  sum(dz)  and  sum(dz * xhat),  dz = g * leaky'(bn(y)) [* keep * scale], xhat = (y - mean) *
+// invstd -- the reduction pass of wsl_bnact_bwd (8 bytes per element of HBM traffic) without its own launch.  Same per-element
+// arithmetic as bn_dz4() in wsl_bn.hip (identical sign decisions at the LeakyReLU kink).
+struct BnBwdEpi {
+  const float* y = nullptr;        // raw conv output the BatchNorm normalised, dense [N][C][H][W]
+  const float* st = nullptr;       // mean | invstd | scale | shift (4 * C floats)
+  const uint8_t* emask = nullptr;  // keep mask of the nn.Dropout after the activation (or null)
+  float es = 1.f;
+  float* part = nullptr;           // [C][tiles][2]; null = no statistics
+};
+
+// four consecutive gradient values g of channel statistics (mean, invstd, sc, sh) at dense element index idx
+__device__ __forceinline__ void bn_bwd_acc4(const BnBwdEpi& e, int64_t idx, float g0, float g1, float g2, float g3, float mean,
+                                            float invstd, float sc, float sh, float& s1, float& s2) {
+  const float4 yv = *reinterpret_cast<const float4*>(e.y + idx);
+  const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+  float g4[4] = {g0, g1, g2, g3};
+  if (e.emask) {
+    const uint32_t m = *reinterpret_cast<const uint32_t*>(e.emask + idx);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g4[k] = ((m >> (8 * k)) & 0xffu) ? g4[k] * e.es : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float z = fmaf(y4[k], sc, sh);
+    const float xh = (y4[k] - mean) * invstd;
+    const float d = z > 0.f ? g4[k] : WSL_LEAKY_SLOPE * g4[k];
+    s1 += d;
+    s2 = fmaf(d, xh, s2);
+  }
+}
+
+// merge the per-lane sums of a 4-wave workgroup whose lanes (l & 15) own channel column col = j * 16 + (l & 15): lane groups
+// (l >> 4), then waves (through `red`, >= 8 * CO_T floats), then one store per channel into part[C][nb][2]
+template <int NT, int CO_T>
+__device__ __forceinline__ void bn_bwd_store(const BnBwdEpi& e, float (&s1)[NT], float (&s2)[NT], float* red, int co0, int Co,
+                                             int tile_id, int nb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* r1 = red;
+  float* r2 = red + 4 * CO_T;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float a = s1[j], b = s2[j];
+    a += __shfl_xor(a, 16), b += __shfl_xor(b, 16);
+    a += __shfl_xor(a, 32), b += __shfl_xor(b, 32);
+    if (lane < 16) r1[wave * CO_T + j * 16 + lane] = a, r2[wave * CO_T + j * 16 + lane] = b;
+  }
+  __syncthreads();
+  if (wave == 0 && lane < 16) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = j * 16 + lane, co = co0 + col;
+      if (co < Co) {
+        float* dst = e.part + ((int64_t)co * nb + tile_id) * 2;
+        dst[0] = (r1[col] + r1[CO_T + col]) + (r1[2 * CO_T + col] + r1[3 * CO_T + col]);
+        dst[1] = (r2[col] + r2[CO_T + col]) + (r2[2 * CO_T + col] + r2[3 * CO_T + col]);
+      }
+    }
+  }
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // table of the conv layers of one network (kernel argument of pack_table_kernel, wsl_conv2.hip)
