@@ -208,6 +208,15 @@ int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int
                      float gscale, float* out, int64_t* pseudo, float* dz1, float* dz2, int N, int C, int HW,
                      void* ws, size_t ws_bytes, void* stream);
 size_t wsl_loss_ws_bytes(int N, int C, int HW);
+/* The headline composition in one call (ref: ..._pCE_GatedCRFLoss_2D.py:108-123; dual branch: train_ACDC_scribblevc.py:171-206):
+ * loss = pCE(z1 [, z2]) + crf_weight * GatedCRF(y, img), y = beta*softmax(z1) + (1-beta)*softmax(z2) (z2 == NULL: softmax(z1)).
+ * Equals wsl_head_fwd_bwd(w_pse 0) + wsl_mixprob_fwd + wsl_gatedcrf_fwd + wsl_mixprob_bwd bit for bit, with y written by the
+ * head's reduction pass and the gradient through y added inside the head's backward pass (two launches and the re-reads of
+ * the logits / logit gradients fewer).  out[0..3] as wsl_head_fwd_bwd, out[4] = raw GatedCRF loss; y, msg: [N,C,H,W]. */
+int wsl_head_gatedcrf_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int ignore, double beta, const float* img,
+                              int radius, float sigma_xy, float sigma_rgb, float weight, float crf_weight, float* out,
+                              float* dz1, float* dz2, float* y, float* msg, int N, int C, int H, int W, void* ws,
+                              size_t ws_bytes, void* stream);
 
 /* y = beta*softmax(z1) + (1-beta)*softmax(z2) (z2 == NULL: softmax(z1)) -- the prediction the GatedCRF term regularises
  * in the dual-branch composition (ref: train_ACDC_scribblevc.py:171-206; single branch: ...pCE_GatedCRFLoss_2D.py:112).
@@ -282,6 +291,12 @@ int wsl_augment_batch(const WslAugSample* samples, int n, float* out_img, uint8_
 int wsl_surface_u8(const uint8_t* vol, uint8_t* border, int D, int H, int W, void* stream);
 int wsl_nearest_dist2(const int64_t* a_zyx, int na, const int64_t* b_zyx, int nb, int64_t* out, void* stream);
 
+/* Noisy copies of a batch for the mean-teacher / USTM teachers (ref: train_mean_teacher_2D.py:147-149, ..._ustm_2D.py:125-135):
+ * out[r*n + i] = x[i] + d,  r < reps, with d = noise[r*n + i] when `noise` is given (parity tests replay the reference's draw)
+ * or clamp(N(0,1) * sigma, -clip, clip) drawn by the library (Philox4x32-10 + Box-Muller, reproducible per seed). */
+int wsl_noisy_copy(const float* x, const float* noise, float* out, int64_t n, int reps, float sigma, float clip, uint64_t seed,
+                   void* stream);
+
 /* Bernoulli masks for nn.Dropout / F.dropout2d in ONE launch (Philox4x32-10, counter-based: reproducible per seed).
  * Mask i: is_f32[i] == 0 -> uint8 keep mask (1 with probability keep_probs[i]); == 1 -> float multiplier
  * (scales[i] with probability keep_probs[i], else 0).  uint8 outputs must be 4-byte aligned.  n_masks <= 12. */
@@ -326,6 +341,33 @@ int wsl_net_forward(const WslNetDesc* d, const float* params, float* buffers, in
 int wsl_net_backward(const WslNetDesc* d, const float* params, const float* x, const uint8_t* const* emasks,
                      const float* const* cmasks, const float* dlogits_main, const float* dlogits_aux, float* grads,
                      void* ws, size_t ws_bytes, int phase, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ transposed-conv UpBlock
+ * (opt-in: ref networks/unet.py:47-68 with bilinear=False -- a branch the reference's Decoder never selects.)
+ * nn.ConvTranspose2d(Ci, Co, kernel_size=2, stride=2): out[n][co][2i+a][2j+b] = bias[co] + sum_ci x[n][ci][i][j] w[ci][co][a][b],
+ * its data gradient and its weight gradient (ws: wsl_convt2x2_wgrad_ws_bytes; per-sample partials summed in sample order). */
+int wsl_convt2x2_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Ci, int Co, int h, int wd,
+                     void* stream);
+int wsl_convt2x2_dgrad(const float* dy, int64_t dy_bs, const float* w, float* dx, int N, int Ci, int Co, int h, int wd,
+                       void* stream);
+size_t wsl_convt2x2_wgrad_ws_bytes(int N, int Ci, int Co);
+int wsl_convt2x2_wgrad(const float* x, const float* dy, int64_t dy_bs, float* dw, float* db, int N, int Ci, int Co, int h, int wd,
+                       void* ws, size_t ws_bytes, void* stream);
+/* The whole block: x1 [N,C1,h,w], x2 [N,C2,2h,2w] -> ConvBlock(2 C2, Co, dropout_p)(cat([x2, ConvTranspose2d(x1)], 1)), with
+ * the reference module's parameter order (up.weight [C1][C2][2][2], up.bias, conv.conv_conv.{0,1,4,5}.{weight,bias}) in one
+ * arena; buffers = running mean / var of the two BatchNorms (4 Co floats), nbt = their two num_batches_tracked.  forward keeps
+ * what backward needs in ws (same ws for both calls). */
+typedef struct WslUpBlockDesc {
+  int32_t C1, C2, Co, N, h, w;
+  float dropout_p;
+} WslUpBlockDesc;
+int64_t wsl_upblock_t_param_count(const WslUpBlockDesc* d);
+size_t wsl_upblock_t_ws_bytes(const WslUpBlockDesc* d);
+int wsl_upblock_t_forward(const WslUpBlockDesc* d, const float* params, float* buffers, int64_t* nbt, const float* x1,
+                          const float* x2, const uint8_t* emask, int training, float* out, void* ws, size_t ws_bytes,
+                          void* stream);
+int wsl_upblock_t_backward(const WslUpBlockDesc* d, const float* params, const float* x1, const float* x2, const uint8_t* emask,
+                           const float* dout, float* grads, float* dx1, float* dx2, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,13 @@ def decoder(sd, d, feats, training):
     return F.conv2d(x, sd[f"{d}.out_conv.weight"], sd[f"{d}.out_conv.bias"], padding=1)
 
 
+def upblock_t(sd, x1, x2, p, emask, training, pre=""):
+    """UpBlock.forward with bilinear=False (unet.py:58-60, 63-68): ConvTranspose2d(k=2, s=2) -> cat([x2, x1]) -> ConvBlock.
+    SURVEY 8f rank 4 (opt-in; the reference's Decoder never selects this branch)."""
+    u = F.conv_transpose2d(x1, sd[pre + "up.weight"], sd[pre + "up.bias"], stride=2)
+    return conv_block(sd, pre + "conv.conv_conv", torch.cat([x2, u], dim=1), p, emask, training)
+
+
 def net_forward(sd, x, net="unet_cct", emasks=None, cmasks=None, training=True):
     """UNet.forward (unet.py:300-303) / UNet_CCT.forward (unet.py:341-346).
     emasks: 5 uint8 [N,C,H,W] keep masks (training only); cmasks: 5 float [N,C]

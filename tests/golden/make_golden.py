@@ -625,6 +625,42 @@ def gen_crf_curve():
     save("g9_crf_curve", **out)
 
 
+def gen_upblock_t():
+    """G10: the transposed-convolution branch of UpBlock (unet.py:58-60, bilinear=False) -- forward, input / parameter
+    gradients, BatchNorm buffers, eval forward; and the default initialisation draws of the module."""
+    cases = [  # (tag, C1, C2, Co, p, N, h, w)
+        ("a", 32, 16, 16, 0.0, 2, 8, 8),
+        ("b", 64, 32, 32, 0.1, 2, 8, 16),
+        ("c", 12, 6, 10, 0.2, 3, 5, 7),
+    ]
+    out = {}
+    for tag, c1, c2, co, p, N, h, w in cases:
+        torch.manual_seed(300 + ord(tag))
+        blk = UpBlock(c1, c2, co, p, bilinear=False).train()
+        out[f"{tag}_keys"] = np.array(list(blk.state_dict().keys()))
+        out[f"{tag}_init_sum"] = np.array([float(v.double().sum()) for v in blk.state_dict().values()])
+        load_det(blk, 13)
+        x1 = torch.randn(N, c1, h, w, requires_grad=True)
+        x2 = torch.randn(N, c2, 2 * h, 2 * w, requires_grad=True)
+        r = torch.randn(N, co, 2 * h, 2 * w)
+        with DropoutRecorder() as rec:
+            y = blk(x1, x2)
+        (y * r).sum().backward()
+        out[f"{tag}_cfg"] = np.array([c1, c2, co, N, h, w], dtype=np.int64)
+        out[f"{tag}_p"] = np.float32(p)
+        out.update({f"{tag}_x1": x1.detach().numpy(), f"{tag}_x2": x2.detach().numpy(), f"{tag}_r": r.numpy(),
+                    f"{tag}_y": y.detach().numpy(), f"{tag}_dx1": x1.grad.numpy(), f"{tag}_dx2": x2.grad.numpy()})
+        if rec.elem:
+            out[f"{tag}_mask"] = rec.elem[0][0]
+        for k, g in grads_of(blk).items():
+            out[f"{tag}_g.{k}"] = g
+        for k, b in buffers_of(blk).items():
+            out[f"{tag}_b.{k}"] = b
+        blk.eval()
+        out[f"{tag}_y_eval"] = blk(x1.detach(), x2.detach()).detach().numpy()
+    save("g10_upblock_t", **out)
+
+
 def gen_init_digest():
     """net_factory parity of the *default* torch initialisation (net_factory.py:6-22 builds the module under the
     global torch seed): digest of the reference state_dict for seed 2022."""
@@ -640,9 +676,10 @@ def gen_init_digest():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["init", "convblock", "pool_up", "head", "crf", "tv_ms", "sgd", "net", "curve", "crf_curve"]
+    which = sys.argv[1:] or ["init", "convblock", "pool_up", "head", "crf", "tv_ms", "sgd", "net", "curve", "crf_curve", "upblock_t"]
     fns = dict(init=gen_init_digest, convblock=gen_convblock, pool_up=gen_pool_up, head=gen_head, crf=gen_crf,
-               tv_ms=gen_tv_ms, sgd=gen_sgd_ema, net=gen_net, curve=gen_curve_and_ddp, crf_curve=gen_crf_curve)
+               tv_ms=gen_tv_ms, sgd=gen_sgd_ema, net=gen_net, curve=gen_curve_and_ddp, crf_curve=gen_crf_curve,
+               upblock_t=gen_upblock_t)
     for w in which:
         print(w)
         fns[w]()

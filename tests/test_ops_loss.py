@@ -204,3 +204,60 @@ def test_draw_masks_statistics_and_determinism(be):
     assert abs(a[1].mean() - 0.5) < 4 * np.sqrt(0.25 / sizes[1])
     assert set(np.unique(a[3])) <= {0.0, 2.0} and abs((a[3] > 0).mean() - 0.5) < 4 * np.sqrt(0.25 / sizes[3])
     assert not np.array_equal(a[1][:7], a[2])             # masks of one call use distinct counter streams
+
+
+def test_noisy_copy_distribution_and_replay(be):
+    """teacher input noise (train_mean_teacher_2D.py:147-149): clamp(N(0,1) * 0.1, +-0.2) drawn by the library -- distribution,
+    clipping, reproducibility per seed, batch doubling -- and the replay form (a given noise tensor is added as is)"""
+    import ctypes as C_
+    rng = np.random.default_rng(2)
+    n = 40000
+    x = rng.standard_normal(n).astype(np.float32)
+    dx_, out, out2 = be.arr(x), be.zeros((2 * n,)), be.zeros((2 * n,))
+    be.call("wsl_noisy_copy", be.ptr(dx_), None, be.ptr(out), n, 2, 0.1, 0.2, C_.c_uint64(1234), be.stream)
+    be.call("wsl_noisy_copy", be.ptr(dx_), None, be.ptr(out2), n, 2, 0.1, 0.2, C_.c_uint64(1234), be.stream)
+    d = be.np(out) - np.concatenate([x, x])
+    assert np.array_equal(be.np(out), be.np(out2))                       # same seed, same draw
+    assert abs(d.mean()) < 2e-3 and d.min() >= -0.2 - 1e-6 and d.max() <= 0.2 + 1e-6
+    assert abs(d.std() - 0.0966) < 3e-3                                   # std of N(0, 0.1) clipped at 2 sigma
+    assert 0.03 < np.mean(np.abs(d) >= 0.2 - 1e-6) < 0.06                 # P(|z| > 2) = 4.55 %
+    assert abs(np.corrcoef(d[:n], d[n:])[0, 1]) < 0.02                    # the two copies carry independent noise
+    be.call("wsl_noisy_copy", be.ptr(dx_), None, be.ptr(out2), n, 2, 0.1, 0.2, C_.c_uint64(99), be.stream)
+    assert not np.array_equal(be.np(out), be.np(out2))
+    nz = (rng.standard_normal(2 * n) * 0.05).astype(np.float32)
+    dnz = be.arr(nz)
+    be.call("wsl_noisy_copy", be.ptr(dx_), be.ptr(dnz), be.ptr(out), n, 2, 0.1, 0.2, C_.c_uint64(0), be.stream)
+    assert np.array_equal(be.np(out), np.concatenate([x, x]) + nz)
+
+
+@pytest.mark.parametrize("dual", [True, False])
+def test_fused_head_gatedcrf_equals_the_four_call_composition(be, dual):
+    """wsl_head_gatedcrf_fwd_bwd == wsl_head_fwd_bwd + wsl_mixprob_fwd + wsl_gatedcrf_fwd + wsl_mixprob_bwd, bit for bit"""
+    rng = np.random.default_rng(31)
+    N, C, H, W, r, beta, cw = 2, 4, 40, 44, 5, 0.37, 0.1
+    z1, z2 = (rng.standard_normal((N, C, H, W)) * 2).astype(np.float32), (rng.standard_normal((N, C, H, W)) * 2).astype(np.float32)
+    lab = np.full((N, H, W), 4, np.uint8)
+    lab[rng.random((N, H, W)) < 0.1] = rng.integers(0, 4)
+    img = rng.random((N, 1, H, W)).astype(np.float32)
+    d = {k: be.arr(v) for k, v in dict(z1=z1, z2=z2, lab=lab, img=img).items()}
+    pz2 = be.ptr(d["z2"]) if dual else None
+    ws, n = lws(be, N, C, H * W)
+    # four calls
+    o1, a1, a2, y1, m1 = be.zeros((8,)), be.zeros(z1.shape), be.zeros(z1.shape), be.zeros(z1.shape), be.zeros(z1.shape)
+    be.call("wsl_head_fwd_bwd", be.ptr(d["z1"]), pz2, be.ptr(d["lab"]), 4, beta, 0.0, 1.0, be.ptr(o1), None, be.ptr(a1),
+            be.ptr(a2) if dual else None, N, C, H * W, be.ptr(ws), n, be.stream)
+    be.call("wsl_mixprob_fwd", be.ptr(d["z1"]), pz2, beta, be.ptr(y1), N, C, H * W, be.stream)
+    crf = be.zeros((1,))
+    be.call("wsl_gatedcrf_fwd", be.ptr(y1), be.ptr(d["img"]), be.ptr(m1), be.ptr(crf), N, C, H, W, r, 6.0, 0.1, 1.0, be.ptr(ws), n,
+            be.stream)
+    be.call("wsl_mixprob_bwd", be.ptr(d["z1"]), pz2, beta, be.ptr(m1), -2.0 * cw / (N * H * W), be.ptr(a1),
+            be.ptr(a2) if dual else None, 1, N, C, H * W, be.stream)
+    # one call
+    o2, b1, b2, y2, m2 = be.zeros((8,)), be.zeros(z1.shape), be.zeros(z1.shape), be.zeros(z1.shape), be.zeros(z1.shape)
+    be.call("wsl_head_gatedcrf_fwd_bwd", be.ptr(d["z1"]), pz2, be.ptr(d["lab"]), 4, beta, be.ptr(d["img"]), r, 6.0, 0.1, 1.0, cw,
+            be.ptr(o2), be.ptr(b1), be.ptr(b2) if dual else None, be.ptr(y2), be.ptr(m2), N, C, H, W, be.ptr(ws), n, be.stream)
+    assert np.array_equal(be.np(y1), be.np(y2)) and np.array_equal(be.np(m1), be.np(m2))
+    assert np.array_equal(be.np(o1)[:4], be.np(o2)[:4]) and be.np(crf)[0] == be.np(o2)[4]
+    assert np.array_equal(be.np(a1), be.np(b1))
+    if dual:
+        assert np.array_equal(be.np(a2), be.np(b2))

@@ -155,3 +155,28 @@ def test_crf_curve_against_reference():
         ref = g["losses"][it]
         tol = 1e-4 if it < 2 else 3e-2           # (later steps drift through kink flips, like G7)
         assert max(abs(a - b) / abs(b) for a, b in zip(got, ref)) < tol, (it, got, ref)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_upblock_transposed(tag):
+    """oracle.upblock_t (ConvTranspose2d branch of UpBlock, unet.py:58-68) against the reference module's outputs"""
+    g = golden("g10_upblock_t")
+    c1, c2, co, N, h, w = (int(v) for v in g[f"{tag}_cfg"])
+    p = float(g[f"{tag}_p"])
+    keys = [str(k) for k in g[f"{tag}_keys"]]
+    shapes = {"up.weight": (c1, c2, 2, 2), "up.bias": (c2,)}
+    for k, s in R.conv_block_keys("conv.conv_conv", 2 * c2, co):
+        shapes[k] = tuple(s)
+    assert list(shapes) == keys                                       # same state_dict layout as the reference module
+    sd = {k: t(v).clone() for k, v in det_state({k: shapes[k] for k in keys}, 13).items()}
+    pk = [k for k in keys if R.is_param(k)]
+    for k in pk:
+        sd[k].requires_grad_(True)
+    x1, x2 = t(g[f"{tag}_x1"]).requires_grad_(), t(g[f"{tag}_x2"]).requires_grad_()
+    y = R.upblock_t(sd, x1, x2, p, t(g[f"{tag}_mask"]) if p > 0 else None, True)
+    assert rel_err(y.detach().numpy(), g[f"{tag}_y"]) < 1e-6
+    (y * t(g[f"{tag}_r"])).sum().backward()
+    assert rel_err(x1.grad.numpy(), g[f"{tag}_dx1"]) < 1e-5 and rel_err(x2.grad.numpy(), g[f"{tag}_dx2"]) < 1e-5
+    for k in pk:
+        if not k.endswith(("conv_conv.0.bias", "conv_conv.4.bias")):
+            assert rel_err(sd[k].grad.numpy(), g[f"{tag}_g.{k}"]) < 1e-5, k

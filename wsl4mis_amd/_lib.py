@@ -40,6 +40,11 @@ class WslWgradPending(C.Structure):
                 ("KK", C.c_int32), ("nsplit", C.c_int32)]
 
 
+class WslUpBlockDesc(C.Structure):
+    _fields_ = [("C1", C.c_int32), ("C2", C.c_int32), ("Co", C.c_int32), ("N", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("dropout_p", C.c_float)]
+
+
 class WslNetEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("kind", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
                 ("offset", C.c_int64)]
@@ -113,8 +118,19 @@ _PROTOS = {
     "wsl_surface_u8": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),
     "wsl_nearest_dist2": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp]),
     "wsl_augment_batch": (i32, [C.POINTER(WslAugSample), i32, c_fp, c_fp, i32, i32, c_fp]),
+    "wsl_noisy_copy": (i32, [c_fp, c_fp, c_fp, i64, i32, f32, f32, C.c_uint64, c_fp]),
+    "wsl_head_gatedcrf_fwd_bwd": (i32, [c_fp, c_fp, c_fp, i32, f64, c_fp, i32, f32, f32, f32, f32, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                        i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_draw_masks": (i32, [i32, PP, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float),
                              C.POINTER(C.c_int), C.c_uint64, c_fp]),
+    "wsl_convt2x2_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "wsl_convt2x2_dgrad": (i32, [c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "wsl_convt2x2_wgrad_ws_bytes": (sz, [i32, i32, i32]),
+    "wsl_convt2x2_wgrad": (i32, [c_fp, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),
+    "wsl_upblock_t_param_count": (i64, [C.POINTER(WslUpBlockDesc)]),
+    "wsl_upblock_t_ws_bytes": (sz, [C.POINTER(WslUpBlockDesc)]),
+    "wsl_upblock_t_forward": (i32, [C.POINTER(WslUpBlockDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, sz, c_fp]),
+    "wsl_upblock_t_backward": (i32, [C.POINTER(WslUpBlockDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, sz, c_fp]),
     "wsl_net_num_entries": (i32, [PD]),
     "wsl_net_entry": (i32, [PD, i32, PE]),
     "wsl_net_param_count": (i64, [PD]),

@@ -226,7 +226,7 @@ struct HeadP {
 
 // CT > 0: class count fixed at compile time (loops unroll, per-class arrays live in registers); CT == 0: generic
 template <int CT>
-__global__ __launch_bounds__(256) void head_reduce_kernel(HeadP h, int64_t* pseudo, float* part) {
+__global__ __launch_bounds__(256) void head_reduce_kernel(HeadP h, int64_t* pseudo, float* part, float* y_mix) {
   __shared__ float red[4];
   float v[3 + 5 * kMaxC];
   for (int k = 0; k < 3 + 5 * kMaxC; ++k) v[k] = 0.f;
@@ -243,11 +243,15 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(HeadP h, int64_t* pseu
       if (valid) v[1] += lse2 - h.z2[base + (int64_t)l * h.HW];
       const int t = mix_argmax_c(s1, s2, C, h.bf, h.omb);
       if (pseudo) pseudo[i] = t;
+      if (y_mix)   // the mixed prediction the GatedCRF term regularises: same expression (and bits) as mixprob_fwd_kernel
+        for (int c = 0; c < C; ++c) y_mix[base + (int64_t)c * h.HW] = __fadd_rn(__fmul_rn(h.bf, s1[c]), __fmul_rn(h.omb, s2[c]));
       for (int c = 0; c < C; ++c) {
         v[3 + kMaxC + c] = fmaf(s1[c], s1[c], v[3 + kMaxC + c]);
         v[3 + 3 * kMaxC + c] = fmaf(s2[c], s2[c], v[3 + 3 * kMaxC + c]);
         if (c == t) v[3 + c] += s1[c], v[3 + 2 * kMaxC + c] += s2[c], v[3 + 4 * kMaxC + c] += 1.f;
       }
+    } else if (y_mix) {
+      for (int c = 0; c < C; ++c) y_mix[base + (int64_t)c * h.HW] = s1[c];
     }
   }
   write_partials<3 + 5 * kMaxC>(v, part, red);
@@ -293,22 +297,30 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* part, i
   }
 }
 
+// gy != NULL: + wgt * softmax_bwd(s, gy) -- the gradient through the mixed prediction y (GatedCRF term), what
+// mixprob_bwd_kernel would accumulate in a pass of its own (same expressions, same order: bit-identical sum)
 __device__ __forceinline__ void head_branch_bwd(const float* s, int C, int t, int l, bool valid, const float* ca,
-                                                const float* cb, float kce, float gscale, float* dz, int64_t stride) {
-  float dsv[kMaxC], dot = 0.f;
+                                                const float* cb, float kce, float gscale, float* dz, int64_t stride,
+                                                const float* gy = nullptr, float wgt = 1.f) {
+  float dsv[kMaxC], dot = 0.f, doty = 0.f;
   for (int c = 0; c < C; ++c) {
     dsv[c] = cb ? ca[c] * (c == t ? 1.f : 0.f) + cb[c] * s[c] : 0.f;
     dot = fmaf(dsv[c], s[c], dot);
   }
+  if (gy)
+    for (int c = 0; c < C; ++c) doty = fmaf(gy[c], s[c], doty);
   for (int c = 0; c < C; ++c) {
     float g = s[c] * (dsv[c] - dot);
     if (valid) g += kce * (s[c] - (c == l ? 1.f : 0.f));
-    dz[c * stride] = g * gscale;
+    g = g * gscale;
+    if (gy) g = g + wgt * s[c] * (gy[c] - doty);
+    dz[c * stride] = g;
   }
 }
 
 template <int CT>
-__global__ __launch_bounds__(256) void head_bwd_kernel(HeadP h, const float* scal, float gscale, float* dz1, float* dz2) {
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadP h, const float* scal, float gscale, float* dz1, float* dz2,
+                                                       const float* dy_mix, float ky) {
   const int C = CT > 0 ? CT : h.C;
   const bool dual = h.z2 != nullptr;
   const float kce = scal[0] * (dual ? 0.5f : 1.f);
@@ -318,15 +330,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadP h, const float* sca
     const int64_t n = i / h.HW, p = i - n * h.HW, base = n * C * h.HW + p;
     const int l = h.label[i];
     const bool valid = (l != h.ignore) && l < C;
-    float s1[kMaxC], s2[kMaxC];
+    float s1[kMaxC], s2[kMaxC], gy[kMaxC];
+    if (dy_mix)
+      for (int c = 0; c < C; ++c) gy[c] = ky * dy_mix[base + (int64_t)c * h.HW];
     softmax_c(h.z1 + base, h.HW, C, s1);
     if (dual) {
       softmax_c(h.z2 + base, h.HW, C, s2);
       const int t = mix_argmax_c(s1, s2, C, h.bf, h.omb);
-      head_branch_bwd(s1, C, t, l, valid, ca1, cb1, kce, gscale, dz1 + base, h.HW);
-      head_branch_bwd(s2, C, t, l, valid, ca2, cb2, kce, gscale, dz2 + base, h.HW);
+      head_branch_bwd(s1, C, t, l, valid, ca1, cb1, kce, gscale, dz1 + base, h.HW, dy_mix ? gy : nullptr, h.bf);
+      head_branch_bwd(s2, C, t, l, valid, ca2, cb2, kce, gscale, dz2 + base, h.HW, dy_mix ? gy : nullptr, h.omb);
     } else {
-      head_branch_bwd(s1, C, 0, l, valid, nullptr, nullptr, kce, gscale, dz1 + base, h.HW);
+      head_branch_bwd(s1, C, 0, l, valid, nullptr, nullptr, kce, gscale, dz1 + base, h.HW, dy_mix ? gy : nullptr, 1.f);
     }
   }
 }
@@ -971,7 +985,9 @@ extern "C" size_t wsl_loss_ws_bytes(int N, int C, int HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
   const size_t tiles = (size_t)N * C * ((HW + 255) / 256 + 64);  // generous bound on 16x16 tile counts (any aspect)
   const size_t part = (tiles > (size_t)kMaxBlocks ? tiles : (size_t)kMaxBlocks) * kMaxK;
-  return sizeof(float) * (part + 64 + (size_t)N * ((HW + 4095) / 4096) * (kMaxC + 1));
+  // + a region of its own for the GatedCRF partials (2 per tile of >= 256 pixels) when the CRF runs between the two passes of
+  //   the fused head (wsl_head_gatedcrf_fwd_bwd): the head's coefficients must survive it
+  return sizeof(float) * (part + 64 + (size_t)N * ((HW + 4095) / 4096) * (kMaxC + 1) + 2 * (size_t)N * ((HW + 255) / 256 + 64));
 }
 
 #define WSL_WS_OK(fn)                                                              \
@@ -1040,6 +1056,19 @@ extern "C" int wsl_pdice_bwd(const float* s, const void* target, int target_i64,
   return check_launch("pdice_bwd_kernel");
 }
 
+static int head_stage1(const HeadP& h, int64_t* pseudo, float* y_mix, float w_pse, float* out, int C, int N, int dual, float* part,
+                       float* scal, int nb, void* stream) {
+  if (C == 4) WSL_LAUNCH((head_reduce_kernel<4>), dim3(nb), dim3(kThreads), 0, stream, h, pseudo, part, y_mix);
+  else WSL_LAUNCH((head_reduce_kernel<0>), dim3(nb), dim3(kThreads), 0, stream, h, pseudo, part, y_mix);
+  WSL_LAUNCH(head_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, C, N, dual, w_pse, out, scal);
+  return WSL_OK;
+}
+static void head_stage2(const HeadP& h, const float* scal, float gscale, float* dz1, float* dz2, const float* dy_mix, float ky, int C,
+                        int nb, void* stream) {
+  if (C == 4) WSL_LAUNCH((head_bwd_kernel<4>), dim3(nb), dim3(kThreads), 0, stream, h, scal, gscale, dz1, dz2, dy_mix, ky);
+  else WSL_LAUNCH((head_bwd_kernel<0>), dim3(nb), dim3(kThreads), 0, stream, h, scal, gscale, dz1, dz2, dy_mix, ky);
+}
+
 extern "C" int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int ignore, double beta,
                                 float w_pse, float gscale, float* out, int64_t* pseudo, float* dz1, float* dz2, int N,
                                 int C, int HW, void* ws, size_t ws_bytes, void* stream) {
@@ -1054,11 +1083,8 @@ extern "C" int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t*
   const int nb = grid_for(h.P);
   float* part = static_cast<float*>(ws);
   float* scal = part + (size_t)kMaxBlocks * kMaxK;
-  if (C == 4) WSL_LAUNCH((head_reduce_kernel<4>), dim3(nb), dim3(kThreads), 0, stream, h, pseudo, part);
-  else WSL_LAUNCH((head_reduce_kernel<0>), dim3(nb), dim3(kThreads), 0, stream, h, pseudo, part);
-  WSL_LAUNCH(head_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, part, nb, C, N, z2 ? 1 : 0, w_pse, out, scal);
-  if (dz1 && C == 4) WSL_LAUNCH((head_bwd_kernel<4>), dim3(nb), dim3(kThreads), 0, stream, h, scal, gscale, dz1, dz2);
-  else if (dz1) WSL_LAUNCH((head_bwd_kernel<0>), dim3(nb), dim3(kThreads), 0, stream, h, scal, gscale, dz1, dz2);
+  head_stage1(h, pseudo, nullptr, w_pse, out, C, N, z2 ? 1 : 0, part, scal, nb, stream);
+  if (dz1) head_stage2(h, scal, gscale, dz1, dz2, nullptr, 0.f, C, nb, stream);
   return check_launch("head_fwd_bwd");
 }
 
@@ -1084,19 +1110,15 @@ static int crf4_launch(const float* y, const float* img, float* msg, int N, int 
   return check_launch("gatedcrf_fwd4_kernel");
 }
 
-extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, float* loss, int N, int C, int H, int W,
-                                int radius, float sigma_xy, float sigma_rgb, float weight, void* ws, size_t ws_bytes,
-                                void* stream) {
+static int gatedcrf_fwd_impl(const float* y, const float* img, float* msg, float* loss, int N, int C, int H, int W, int radius,
+                             float sigma_xy, float sigma_rgb, float weight, float* part, void* stream) {
   WSL_REQUIRE(y && img && msg && loss && N > 0 && H > 0 && W > 0 && C > 0 && C <= kMaxC, "gatedcrf_fwd: bad args");
   if (radius < 1 || radius > 8) {
     set_error("gatedcrf_fwd: radius %d not built (1..8 are)", radius);
     return WSL_EUNSUPPORTED;
   }
-  const int HW_ = H * W;
-  WSL_WS_OK("gatedcrf_fwd");
   CrfP q{y, img, msg, N, C, H, W, radius, sigma_xy, sigma_rgb, weight, cdiv(W, kCrfTW), cdiv(H, kCrfTH)};
   const int nb = N * q.tiles_x * q.tiles_y;
-  float* part = static_cast<float*>(ws);
   if (C == 4 && (radius == 5 || radius == 2) && (W & 3) == 0 && weight > 0.f &&
       (reinterpret_cast<uintptr_t>(msg) & 15) == 0) {
     const int nb4 = N * cdiv(W, 32) * cdiv(H, 32);
@@ -1118,6 +1140,15 @@ extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, fl
   return check_launch("gatedcrf_fwd");
 }
 
+extern "C" int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, float* loss, int N, int C, int H, int W,
+                                int radius, float sigma_xy, float sigma_rgb, float weight, void* ws, size_t ws_bytes,
+                                void* stream) {
+  WSL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "gatedcrf_fwd: bad args");
+  const int HW_ = H * W;
+  WSL_WS_OK("gatedcrf_fwd");
+  return gatedcrf_fwd_impl(y, img, msg, loss, N, C, H, W, radius, sigma_xy, sigma_rgb, weight, static_cast<float*>(ws), stream);
+}
+
 extern "C" int wsl_gatedcrf_bwd(const float* msg, const float* gout, float gscale, float* dy, int N, int C, int H, int W,
                                 void* stream) {
   WSL_REQUIRE(msg && dy && N > 0 && C > 0 && H > 0 && W > 0, "gatedcrf_bwd: bad args");
@@ -1125,6 +1156,41 @@ extern "C" int wsl_gatedcrf_bwd(const float* msg, const float* gout, float gscal
   WSL_LAUNCH(scale_kernel, dim3(grid_for(n / 4 + 1)), dim3(kThreads), 0, stream, msg, gout,
              (float)(-2.0 * gscale / ((double)N * H * W)), dy, n);
   return check_launch("scale_kernel");
+}
+
+// The headline composition in one entry point (ref: train_weakly_supervised_pCE_GatedCRFLoss_2D.py:108-123; dual branch as
+// train_ACDC_scribblevc.py:171-206):  loss = pCE(z1 [, z2]) + crf_weight * GatedCRF(y, image),  y = beta softmax(z1) + (1 - beta)
+// softmax(z2) (single branch: softmax(z1)).  Same kernels as wsl_head_fwd_bwd + wsl_mixprob_fwd + wsl_gatedcrf_fwd + wsl_mixprob_bwd,
+// but y is written by the head's reduction pass and the gradient through y is added inside the head's backward pass: two launches
+// and ~400 MB of logit / gradient re-reads fewer at 64 x 256 x 256, bit-identical logit gradients.
+// out[0..3] as wsl_head_fwd_bwd (w_pse = 0), out[4] = the raw GatedCRF loss.  y, msg: [N,C,H,W] buffers (msg is kept: it is the
+// CRF term's gradient).
+extern "C" int wsl_head_gatedcrf_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int ignore, double beta,
+                                         const float* img, int radius, float sigma_xy, float sigma_rgb, float weight,
+                                         float crf_weight, float* out, float* dz1, float* dz2, float* y, float* msg, int N, int C,
+                                         int H, int W, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(z1 && label && img && out && dz1 && y && msg && N > 0 && H > 0 && W > 0 && C > 0 && C <= kMaxC,
+              "head_gatedcrf_fwd_bwd: bad args");
+  WSL_REQUIRE(z2 == nullptr || dz2 != nullptr, "head_gatedcrf_fwd_bwd: dz2 missing");
+  const int HW = H * W, HW_ = HW;
+  WSL_WS_OK("head_gatedcrf_fwd_bwd");
+  HeadP h{z1, z2, label, ignore, C, HW, N, (int64_t)N * HW, (float)beta, (float)(1.0 - beta)};
+  const int nb = grid_for(h.P);
+  float* part = static_cast<float*>(ws);
+  float* scal = part + (size_t)kMaxBlocks * kMaxK;
+  const double nbr = z2 ? 2.0 : 1.0;
+  {
+    ProfScope ps(PF_LOSS_HEAD, 0.0, (double)N * HW * (4.0 * C * nbr + 1.0 + 4.0 * C), stream);
+    head_stage1(h, nullptr, y, 0.f, out, C, N, z2 ? 1 : 0, part, scal, nb, stream);
+  }
+  // the CRF's partials go behind the head's coefficients (the last region of wsl_loss_ws_bytes), which the backward pass needs
+  float* crf_part = static_cast<float*>(ws) + (ws_bytes / sizeof(float) - 2 * (size_t)N * ((HW + 255) / 256 + 64));
+  if (int rc = gatedcrf_fwd_impl(y, img, msg, out + 4, N, C, H, W, radius, sigma_xy, sigma_rgb, weight, crf_part, stream)) return rc;
+  {
+    ProfScope ps(PF_LOSS_HEAD, 0.0, (double)N * HW * (4.0 * C * nbr + 1.0 + 4.0 * C + 4.0 * C * nbr), stream);
+    head_stage2(h, scal, 1.f, dz1, dz2, msg, (float)(-2.0 * (double)crf_weight / ((double)N * HW)), C, nb, stream);
+  }
+  return check_launch("head_gatedcrf_fwd_bwd");
 }
 
 extern "C" int wsl_tv_fwd_bwd(const float* p, int n0, float* loss, float* dp, float gscale, int N, int C, int H, int W,

@@ -586,3 +586,141 @@ extern "C" int wsl_net_backward(const WslNetDesc* d, const float* params, const 
   if (phase == 0 || phase == 2) WSL_TRY(encoder_bwd(c, x, emasks, cmasks));
   return WSL_OK;
 }
+
+// ================================================================================================ UpBlock, transposed-conv branch
+// UpBlock(in_channels1, in_channels2, out_channels, dropout_p, bilinear=False).forward(x1, x2)  (ref: networks/unet.py:47-68):
+//     x1 = ConvTranspose2d(C1, C2, kernel_size=2, stride=2)(x1);  x = cat([x2, x1], 1);  return ConvBlock(2 C2, Co, p)(x)
+// SURVEY 8f rank 4, opt-in: the reference's Decoder never passes bilinear=False, so this block is not part of UNet / UNet_CCT; it
+// is exported as a module of its own with the reference's state_dict layout (up.weight [C1][C2][2][2], up.bias,
+// conv.conv_conv.{0,1,4,5}.*).  Same ConvBlock machinery as the networks (block_fwd / block_bwd on a one-level plan).
+namespace wsl {
+
+struct UpPlan {
+  Plan P;                  // one level: H[0] x W[0] = the output resolution
+  ConvRef up;              // w: [C1][C2][2][2], b: [C2]
+  BlockRef blk;
+  BlkWs wblk;
+  size_t upt, dcat, tmp_out;
+  int C1, C2, Co, h, w;
+};
+
+static int make_up_plan(const WslUpBlockDesc* d, UpPlan& U) {
+  WSL_REQUIRE(d && d->N > 0 && d->C1 > 0 && d->C1 <= 256 && d->C2 > 0 && d->C2 <= 256 && d->Co > 0 && d->h > 0 && d->w > 0,
+              "upblock_t: bad descriptor (C1, C2 <= 256)");
+  WSL_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "upblock_t: dropout_p %f", (double)d->dropout_p);
+  Plan& P = U.P;
+  memset(&P, 0, sizeof(P));
+  P.d.in_chns = d->C1, P.d.n_class = 1, P.d.n_dec = 1, P.d.N = d->N, P.d.H = 2 * d->h, P.d.W = 2 * d->w;
+  P.H[0] = 2 * d->h, P.W[0] = 2 * d->w;
+  U.C1 = d->C1, U.C2 = d->C2, U.Co = d->Co, U.h = d->h, U.w = d->w;
+  int64_t po = 0, bo = 0, nbn = 0;
+  U.up.Ci = d->C1, U.up.Co = d->C2, U.up.ks = 2;
+  U.up.w = po, po += (int64_t)d->C1 * d->C2 * 4;
+  U.up.b = po, po += d->C2;
+  plan_block(U.blk, 2 * d->C2, d->Co, po, bo, nbn);
+  P.n_param = po, P.n_enc_param = 0, P.n_buf = bo, P.n_bn = nbn;
+  Bump B;
+  const size_t N = d->N, HW = (size_t)P.H[0] * P.W[0];
+  const size_t e = N * d->Co * HW;
+  U.wblk.y1 = B.take(e), U.wblk.y2 = B.take(e), U.wblk.st1 = B.take(4 * d->Co), U.wblk.st2 = B.take(4 * d->Co);
+  U.upt = B.take(N * d->C2 * HW), U.dcat = B.take(N * 2 * d->C2 * HW), U.tmp_out = B.take(e);
+  size_t max_stat = 0, max_cnt = 0, wg = 0;
+  for (const ConvRef* cv : {&U.blk.c1, &U.blk.c2}) {
+    const size_t nb = wsl_conv2d_stat_blocks(d->N, P.H[0], P.W[0], cv->Ci, cv->Co, 3);
+    if (nb * cv->Co * 2 > max_stat) max_stat = nb * cv->Co * 2;
+    if (nb > max_cnt) max_cnt = nb;
+    wg += (wsl_conv2d_wgrad_ws_bytes(d->N, P.H[0], P.W[0], cv->Ci, cv->Co, 3) + 255) & ~(size_t)255;
+  }
+  const size_t ct = wsl_convt2x2_wgrad_ws_bytes(d->N, d->C1, d->C2);
+  P.wg_bytes = wg > ct ? wg : ct;
+  P.bn_bytes = wsl_bnact_bwd_ws_bytes(d->N, d->Co, P.H[0], P.W[0]);
+  Plan::Scratch& S = P.scr[0];
+  S.tmp_g = B.take(e), S.tmp_g1 = B.take(e), S.tmp_dy = B.take(e);
+  S.tmp_du = 0, S.tmp_gpool = 0;
+  S.stat_part = B.take(max_stat), S.stat_cnt = B.take(max_cnt);
+  S.wg_ws = B.take((P.wg_bytes + 3) / 4), S.bn_ws = B.take((P.bn_bytes + 3) / 4), S.bn_coef = B.take(2 * (size_t)d->Co + 64);
+  P.scr[1] = P.scr[0];
+  P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);
+  P.winof = B.take(2 * P.n_param), P.winod = B.take(2 * P.n_param);
+  P.total_floats = B.off;
+  return WSL_OK;
+}
+
+static int up_pack(const Ctx& c, const UpPlan& U, int with_dgrad) {
+  PackTable t;
+  t.n = 0;
+  for (const ConvRef* cv : {&U.blk.c1, &U.blk.c2}) t.e[t.n++] = PackEntry{cv->w, cv->Co, cv->Ci, 9, 0};
+  WSL_TRY(conv2_pack_table(t, c.params, c.ws + U.P.packf, c.ws + U.P.packd, with_dgrad, c.stream));
+  return wino_pack_table(t, c.params, c.ws + U.P.winof, c.ws + U.P.winod, with_dgrad, c.stream);
+}
+
+}  // namespace wsl
+
+extern "C" int64_t wsl_upblock_t_param_count(const WslUpBlockDesc* d) {
+  UpPlan U;
+  return make_up_plan(d, U) ? -1 : U.P.n_param;
+}
+extern "C" size_t wsl_upblock_t_ws_bytes(const WslUpBlockDesc* d) {
+  UpPlan U;
+  return make_up_plan(d, U) ? 0 : U.P.total_floats * sizeof(float);
+}
+
+// buffers: conv.conv_conv.1.running_mean | .running_var | conv.conv_conv.5.running_mean | .running_var (4 * Co floats);
+// nbt: the two num_batches_tracked counters.  emask: keep mask of the ConvBlock's nn.Dropout(p) [N][Co][2h][2w] (training, p > 0).
+extern "C" int wsl_upblock_t_forward(const WslUpBlockDesc* d, const float* params, float* buffers, int64_t* nbt, const float* x1,
+                                     const float* x2, const uint8_t* emask, int training, float* out, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  UpPlan U;
+  WSL_TRY(make_up_plan(d, U));
+  WSL_REQUIRE(params && buffers && x1 && x2 && out && ws, "upblock_t_forward: null argument");
+  WSL_REQUIRE(!(training && d->dropout_p > 0.f) || emask, "upblock_t_forward: training with dropout_p > 0 needs the keep mask");
+  if (ws_bytes < U.P.total_floats * sizeof(float)) {
+    set_error("upblock_t_forward: workspace %zu < %zu", ws_bytes, U.P.total_floats * sizeof(float));
+    return WSL_EWORKSPACE;
+  }
+  const Plan& P = U.P;
+  Ctx c{P, params, buffers, nbt, nullptr, static_cast<float*>(ws), stream, training};
+  const int H = P.H[0], W = P.W[0];
+  WSL_TRY(up_pack(c, U, training));
+  WSL_TRY(wsl_convt2x2_fwd(x1, params + U.up.w, params + U.up.b, c.ws + U.upt, d->N, U.C1, U.C2, U.h, U.w, stream));
+  const WslSrc skip = raw_src(x2, U.C2, (int64_t)U.C2 * H * W);
+  const WslSrc up = raw_src(c.ws + U.upt, U.C2, (int64_t)U.C2 * H * W);
+  const float es = d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f;
+  WSL_TRY(block_fwd(c, U.blk, U.wblk, &skip, &up, 0, d->dropout_p > 0.f ? emask : nullptr, es));
+  const WslSrc act = act_src(c, U.wblk.y2, U.wblk.st2, U.Co, H * W, nullptr, 1.f, nullptr);
+  return wsl_src_materialize(&act, out, (int64_t)U.Co * H * W, d->N, H, W, stream);
+}
+
+// grads: parameter-arena layout; dx1 [N][C1][h][w], dx2 [N][C2][2h][2w] (either may be NULL)
+extern "C" int wsl_upblock_t_backward(const WslUpBlockDesc* d, const float* params, const float* x1, const float* x2,
+                                      const uint8_t* emask, const float* dout, float* grads, float* dx1, float* dx2, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  UpPlan U;
+  WSL_TRY(make_up_plan(d, U));
+  WSL_REQUIRE(params && x1 && x2 && dout && grads && ws, "upblock_t_backward: null argument");
+  if (ws_bytes < U.P.total_floats * sizeof(float)) {
+    set_error("upblock_t_backward: workspace %zu < %zu", ws_bytes, U.P.total_floats * sizeof(float));
+    return WSL_EWORKSPACE;
+  }
+  const Plan& P = U.P;
+  Ctx c{P, params, nullptr, nullptr, grads, static_cast<float*>(ws), stream, 1};
+  WgBatch wb;
+  c.wb = &wb;
+  const int H = P.H[0], W = P.W[0];
+  const int64_t HW = (int64_t)H * W;
+  const WslSrc skip = raw_src(x2, U.C2, U.C2 * HW);
+  const WslSrc up = raw_src(c.ws + U.upt, U.C2, U.C2 * HW);
+  const float es = d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f;
+  float* dcat = c.ws + U.dcat;
+  WSL_TRY(block_bwd(c, U.blk, U.wblk, &skip, &up, 0, d->dropout_p > 0.f ? emask : nullptr, es, dout, U.Co * HW, GStats{}, dcat));
+  WSL_TRY(wgrad_flush(c));
+  const float* dup = dcat + U.C2 * HW;       // d(cat)[:, C2:] = gradient of the transposed convolution's output
+  WSL_TRY(wsl_convt2x2_wgrad(x1, dup, 2 * U.C2 * HW, grads + U.up.w, grads + U.up.b, d->N, U.C1, U.C2, U.h, U.w,
+                             c.ws + c.S().wg_ws, P.wg_bytes, stream));
+  if (dx1) WSL_TRY(wsl_convt2x2_dgrad(dup, 2 * U.C2 * HW, params + U.up.w, dx1, d->N, U.C1, U.C2, U.h, U.w, stream));
+  if (dx2) {
+    const WslSrc dskip = raw_src(dcat, U.C2, 2 * U.C2 * HW);
+    WSL_TRY(wsl_src_materialize(&dskip, dx2, U.C2 * HW, d->N, H, W, stream));
+  }
+  return WSL_OK;
+}

@@ -97,9 +97,52 @@ __global__ __launch_bounds__(256) void masks_kernel(MaskTable t, uint32_t k0, ui
   }
 }
 
+// ------------------------------------------------------------------------------------------------ teacher input noise
+// out[r * n + i] = x[i] + (noise ? noise[r * n + i] : clamp(N(0, 1) * sigma, -clip, clip)),  r < reps
+// (ref: train_mean_teacher_2D.py:147-149 / ..._ustm_2D.py:125-127,133: `torch.clamp(torch.randn_like(x) * 0.1, -0.2, 0.2)` added
+// to the batch, and `volume_batch_r.repeat(2, 1, 1, 1)` + noise for the uncertainty passes).  Normals by Box-Muller on
+// Philox4x32-10 words; like the dropout masks only the distribution is part of the contract, the stream is this library's.
+__global__ __launch_bounds__(256) void noisy_copy_kernel(const float* x, const float* noise, float* out, int64_t n, int reps,
+                                                         float sigma, float clip, uint32_t k0, uint32_t k1) {
+  const int64_t total = n * reps, n4 = (total + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < n4; q += (int64_t)gridDim.x * kThreads) {
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!noise) {
+      uint32_t r[4];
+      philox4(k0, k1, (uint32_t)q, (uint32_t)(q >> 32), 0x6e6f6973u, 0x57534c35u, r);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)r[2 * h] + 1.f) * 2.3283064365386963e-10f;      // (0, 1]
+        const float u2 = (float)r[2 * h + 1] * 2.3283064365386963e-10f;
+        const float rad = sqrtf(-2.f * logf(u1));
+        z[2 * h] = rad * cosf(6.283185307179586f * u2), z[2 * h + 1] = rad * sinf(6.283185307179586f * u2);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t e = (q << 2) + k;
+      if (e < total) {
+        float d = noise ? noise[e] : z[k] * sigma;
+        if (!noise) d = d < -clip ? -clip : (d > clip ? clip : d);
+        out[e] = x[e % n] + d;
+      }
+    }
+  }
+}
+
 }  // namespace wsl
 
 using namespace wsl;
+
+extern "C" int wsl_noisy_copy(const float* x, const float* noise, float* out, int64_t n, int reps, float sigma, float clip,
+                              uint64_t seed, void* stream) {
+  WSL_REQUIRE(x && out && n > 0 && reps > 0 && sigma >= 0.f && clip >= 0.f, "noisy_copy: bad arguments");
+  int64_t blocks = ((n * reps + 3) / 4 + kThreads - 1) / kThreads;
+  if (blocks > 4096) blocks = 4096;
+  WSL_LAUNCH(noisy_copy_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, x, noise, out, n, reps, sigma, clip, (uint32_t)seed,
+             (uint32_t)(seed >> 32));
+  return check_launch("noisy_copy_kernel");
+}
 
 extern "C" int wsl_draw_masks(int n_masks, void* const* outs, const int64_t* numels, const float* keep_probs,
                               const float* scales, const int* is_f32, uint64_t seed, void* stream) {

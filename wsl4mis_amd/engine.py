@@ -120,11 +120,21 @@ class TrainEngine:
         self.forward_backward(x, label_u8, beta, noise)
         self.optimizer_step()
 
+    def _noisy(self, x, noise, reps=1):
+        """x (repeated `reps` times along the batch) + clamp(randn * 0.1, +-0.2) in one library launch (ustm_2D.py:125-127,
+        133-135 / train_mean_teacher_2D.py:147-149); `noise`: a tensor to add instead (parity tests replay the reference's)"""
+        out = torch.empty((reps * x.shape[0],) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        if noise is not None:
+            noise = rt.f32c(noise, "noise")
+            if noise.numel() != out.numel():
+                raise _lib.WslError(f"noise has {noise.numel()} elements, expected {out.numel()}")
+        seed = 0 if noise is not None else int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        rt.call("wsl_noisy_copy", rt.ptr(x), rt.ptr(noise), rt.ptr(out), x.numel(), reps, 0.1, 0.2, C.c_uint64(seed), rt.stream())
+        return out
+
     def _teacher_forward(self, x, noise):
-        if noise is None:                                  # ustm_2D.py:125-127 / train_mean_teacher_2D.py:147-149
-            noise = torch.clamp(torch.randn_like(x) * 0.1, -0.2, 0.2)
         with torch.no_grad():
-            return self.teacher._run_forward(x + noise)[0]
+            return self.teacher._run_forward(self._noisy(x, noise))[0]
 
     def _start_teacher(self, x, noise):
         """The teacher's forward is independent of the student's: on the GPU it runs on a side stream, forked here (before
@@ -195,15 +205,10 @@ class TrainEngine:
         xr = torch.empty_like(x)
         rt.call("wsl_rot90", rt.ptr(x), rt.ptr(xr), N * x.shape[1], H, W, k, rt.stream())
 
-        def nz(i, ref):
-            if noise is not None:
-                return rt.f32c(noise[i], "noise")
-            return torch.clamp(torch.randn_like(ref) * 0.1, -0.2, 0.2)
         with torch.no_grad():
-            zt = self.teacher._run_forward(xr + nz(0, xr))[0]
-            xr2 = xr.repeat(2, 1, 1, 1)
-            for i in range(T_ // 2):                          # T stochastic passes, two per double batch
-                z2 = self.teacher._run_forward(xr2 + nz(1 + i, xr2))[0]
+            zt = self.teacher._run_forward(self._noisy(xr, noise[0] if noise is not None else None))[0]
+            for i in range(T_ // 2):                          # T stochastic passes, two per double batch (xr.repeat(2, 1, 1, 1))
+                z2 = self.teacher._run_forward(self._noisy(xr, noise[1 + i] if noise is not None else None, reps=2))[0]
                 for h in range(2):
                     rt.call("wsl_softmax_accum", rt.ptr(z2[h * N:]), rt.ptr(t["pm"]), 1.0 / T_, int(i == 0 and h == 0), N, C_,
                             HW, rt.stream())
@@ -264,18 +269,17 @@ class TrainEngine:
             self._regularised_losses(x, label_u8, z1, t)
             self._finish_backward(x, t)
             return
+        if self.loss_kind == "pce_gatedcrf":              # pCE + crf_weight * GatedCRF(y): one fused entry point
+            d = self.crf_desc
+            rt.call("wsl_head_gatedcrf_fwd_bwd", rt.ptr(z1), rt.ptr(z2), rt.ptr(label_u8), self.ignore, float(beta), rt.ptr(x),
+                    self.crf_radius, d["xy"], d["rgb"], d["weight"], self.crf_weight, rt.ptr(self.loss_out), rt.ptr(t["dz1"]),
+                    rt.ptr(t["dz2"]), rt.ptr(t["y"]), rt.ptr(t["msg"]), N, m.class_num, H, W, rt.ptr(lws), nl, rt.stream())
+            self._finish_backward(x, t)
+            return
         w_pse = self.w_pse if self.loss_kind == "ours_proposed" else 0.0
         rt.call("wsl_head_fwd_bwd", rt.ptr(z1), rt.ptr(z2), rt.ptr(label_u8), self.ignore, float(beta), w_pse, 1.0,
                 rt.ptr(self.loss_out), None, rt.ptr(t["dz1"]), rt.ptr(t["dz2"]), N, m.class_num, HW, rt.ptr(lws), nl,
                 rt.stream())
-        if self.loss_kind == "pce_gatedcrf":
-            d = self.crf_desc
-            rt.call("wsl_mixprob_fwd", rt.ptr(z1), rt.ptr(z2), float(beta), rt.ptr(t["y"]), N, m.class_num, HW, rt.stream())
-            rt.call("wsl_gatedcrf_fwd", rt.ptr(t["y"]), rt.ptr(x), rt.ptr(t["msg"]), rt.ptr(self.loss_out[4:]), N,
-                    m.class_num, H, W, self.crf_radius, d["xy"], d["rgb"], d["weight"], rt.ptr(lws), nl, rt.stream())
-            k = -2.0 * self.crf_weight / (N * HW)          # d(crf_weight*loss)/dy = -2*w*msg/(N*H*W)
-            rt.call("wsl_mixprob_bwd", rt.ptr(z1), rt.ptr(z2), float(beta), rt.ptr(t["msg"]), k, rt.ptr(t["dz1"]),
-                    rt.ptr(t["dz2"]), 1, N, m.class_num, HW, rt.stream())
         self._finish_backward(x, t)
 
     def _finish_backward(self, x, t):

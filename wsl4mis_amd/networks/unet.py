@@ -253,3 +253,141 @@ class UNet_CCT(_HipUNet):
 
     def __init__(self, in_chns, class_num):
         super().__init__(in_chns, class_num)
+
+
+class _UpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x1, x2, *params):
+        out = mod._run_forward(x1, x2, keep=True)
+        ctx.mod, ctx.token = mod, mod._fwd_token
+        ctx.save_for_backward(x1, x2)
+        ctx.need = (x1.requires_grad, x2.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        mod = ctx.mod
+        if ctx.token != mod._fwd_token:
+            raise _lib.WslError("backward() after a newer training forward of the same UpBlock (its workspace was overwritten)")
+        x1, x2 = ctx.saved_tensors
+        dx1, dx2, grads = mod._run_backward(x1, x2, gout, ctx.need)
+        return (None, dx1, dx2) + grads
+
+
+class UpBlock(nn.Module):
+    """ref: networks/unet.py:47-68 -- `UpBlock(in_channels1, in_channels2, out_channels, dropout_p, bilinear=True)`,
+    forward(x1, x2).  SURVEY 8f rank 4 (opt-in): the TRANSPOSED-CONVOLUTION branch (`bilinear=False`: ConvTranspose2d(k=2,
+    s=2) -> cat([x2, x1]) -> ConvBlock) as a module of its own on the HIP kernels, with the reference's state_dict layout
+    (up.weight [C1,C2,2,2], up.bias, conv.conv_conv.{0,1,4,5}.*) and default initialisation draws.  The reference's Decoder
+    never selects this branch (it builds every UpBlock with the default bilinear=True -- that path lives inside UNet /
+    UNet_CCT), so `bilinear=True` is not offered stand-alone."""
+
+    def __init__(self, in_channels1, in_channels2, out_channels, dropout_p, bilinear=True):
+        super().__init__()
+        if bilinear:
+            raise NotImplementedError("the bilinear UpBlock is built into UNet / UNet_CCT; stand-alone only bilinear=False is")
+        self.bilinear = False
+        self.c1, self.c2, self.co, self.p = int(in_channels1), int(in_channels2), int(out_channels), float(dropout_p)
+        dev = rt.device()
+        n = rt.L().wsl_upblock_t_param_count(C.byref(self._desc(1, 1, 1)))
+        if n <= 0:
+            raise _lib.WslError(rt.L().wsl_last_error().decode())
+        self.n_param = int(n)
+        self._param_arena = torch.zeros(self.n_param + 64, dtype=torch.float32, device=dev)
+        self._grad_arena = torch.zeros(self.n_param + 64, dtype=torch.float32, device=dev)
+        self._buf_arena = torch.zeros(4 * self.co + 64, dtype=torch.float32, device=dev)
+        self._nbt = torch.zeros(2, dtype=torch.int64, device=dev)
+        c1, c2, co = self.c1, self.c2, self.co
+        layout = [("up.weight", (c1, c2, 2, 2)), ("up.bias", (c2,)), ("conv.conv_conv.0.weight", (co, 2 * c2, 3, 3)),
+                  ("conv.conv_conv.0.bias", (co,)), ("conv.conv_conv.1.weight", (co,)), ("conv.conv_conv.1.bias", (co,)),
+                  ("conv.conv_conv.4.weight", (co, co, 3, 3)), ("conv.conv_conv.4.bias", (co,)),
+                  ("conv.conv_conv.5.weight", (co,)), ("conv.conv_conv.5.bias", (co,))]
+        self._plist, off = [], 0
+        for name, shape in layout:
+            *path, leaf = name.split(".")
+            m = self
+            for part in path:
+                if part not in m._modules:
+                    m.add_module(part, nn.Module())
+                m = m._modules[part]
+            k = int(math.prod(shape))
+            prm = nn.Parameter(self._param_arena[off:off + k].view(shape))
+            m.register_parameter(leaf, prm)
+            self._plist.append((prm, off, k, shape))
+            if leaf == "bias" and path[-1] in ("1", "5"):           # BatchNorm: its buffers follow its parameters
+                bi = 0 if path[-1] == "1" else 1
+                m.register_buffer("running_mean", self._buf_arena[2 * bi * co:(2 * bi + 1) * co])
+                m.register_buffer("running_var", self._buf_arena[(2 * bi + 1) * co:(2 * bi + 2) * co])
+                m.register_buffer("num_batches_tracked", self._nbt[bi])
+            off += k
+        assert off == self.n_param
+        self._default_init()
+        self._fwd_token, self._forced_mask, self._saved = 0, None, None
+
+    def _desc(self, N, h, w):
+        return _lib.WslUpBlockDesc(self.c1, self.c2, self.co, N, h, w, self.p)
+
+    @torch.no_grad()
+    def _default_init(self):
+        """the reference's construction-order draws: ConvTranspose2d (kaiming_uniform(a=sqrt(5)) with fan_in = C2 * 4 -- torch
+        takes dim 1 of the [C1,C2,2,2] weight --, bias U(+-1/sqrt(fan_in))), then the ConvBlock's Conv2d / BatchNorm2d"""
+        for prm, off, k, shape in self._plist:
+            name = [n for n, q in self.named_parameters() if q is prm][0]
+            if len(shape) == 4:
+                w = torch.empty(shape)
+                nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                prm.copy_(w)
+                fan_in = shape[1] * shape[2] * shape[3]
+            elif name.split(".")[-2] in ("1", "5"):
+                prm.fill_(1.0 if name.endswith("weight") else 0.0)
+            else:
+                bound = 1 / math.sqrt(fan_in)
+                prm.copy_(torch.empty(shape).uniform_(-bound, bound))
+        self._buf_arena.zero_()
+        self._buf_arena[self.co:2 * self.co] = 1.0
+        self._buf_arena[3 * self.co:4 * self.co] = 1.0
+        self._nbt.zero_()
+
+    def set_dropout_mask(self, emask):
+        """inject the nn.Dropout keep mask [N, Co, 2h, 2w] uint8 of the next forward(s) (parity tests); None = draw"""
+        self._forced_mask = emask
+
+    def _run_forward(self, x1, x2, keep=False):
+        x1, x2 = rt.f32c(x1, "x1"), rt.f32c(x2, "x2")
+        N, c1, h, w = x1.shape
+        if c1 != self.c1 or tuple(x2.shape) != (N, self.c2, 2 * h, 2 * w):
+            raise _lib.WslError(f"UpBlock: x1 {tuple(x1.shape)} / x2 {tuple(x2.shape)} do not fit ({self.c1}, {self.c2})")
+        d = self._desc(N, h, w)
+        nws = rt.L().wsl_upblock_t_ws_bytes(C.byref(d))
+        ws = rt.workspace(("upblock", id(self), "train" if keep else "infer"), nws)
+        training = self.training
+        em = None
+        if training and self.p > 0:
+            em = self._forced_mask
+            if em is None:
+                em = torch.empty((N, self.co, 2 * h, 2 * w), dtype=torch.uint8, device=x1.device)
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+                rt.call("wsl_draw_masks", 1, rt.ptr_array([em]), (C.c_int64 * 1)(em.numel()), (C.c_float * 1)(1.0 - self.p),
+                        (C.c_float * 1)(1.0), (C.c_int * 1)(0), C.c_uint64(seed), rt.stream())
+        out = torch.empty((N, self.co, 2 * h, 2 * w), dtype=torch.float32, device=x1.device)
+        rt.call("wsl_upblock_t_forward", C.byref(d), rt.ptr(self._param_arena), rt.ptr(self._buf_arena), rt.ptr(self._nbt),
+                rt.ptr(x1), rt.ptr(x2), rt.ptr(em), int(training), rt.ptr(out), rt.ptr(ws), nws, rt.stream())
+        if keep:
+            self._fwd_token += 1
+            self._saved = (d, ws, nws, em)
+        return out
+
+    def _run_backward(self, x1, x2, gout, need):
+        d, ws, nws, em = self._saved
+        g = rt.f32c(gout, "grad_output")
+        dx1 = torch.empty_like(x1) if need[0] else None
+        dx2 = torch.empty_like(x2) if need[1] else None
+        rt.call("wsl_upblock_t_backward", C.byref(d), rt.ptr(self._param_arena), rt.ptr(x1), rt.ptr(x2), rt.ptr(em), rt.ptr(g),
+                rt.ptr(self._grad_arena), rt.ptr(dx1), rt.ptr(dx2), rt.ptr(ws), nws, rt.stream())
+        flat = self._grad_arena.clone()
+        return dx1, dx2, tuple(flat[off:off + k].view(shape) for _, off, k, shape in self._plist)
+
+    def forward(self, x1, x2):
+        if self.training and torch.is_grad_enabled():
+            return _UpFn.apply(self, x1, x2, *[p for p, _, _, _ in self._plist])
+        return self._run_forward(x1, x2)
