@@ -210,7 +210,7 @@ int wsl_head_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int
 size_t wsl_loss_ws_bytes(int N, int C, int HW);
 /* The headline composition in one call (ref: ..._pCE_GatedCRFLoss_2D.py:108-123; dual branch: train_ACDC_scribblevc.py:171-206):
  * loss = pCE(z1 [, z2]) + crf_weight * GatedCRF(y, img), y = beta*softmax(z1) + (1-beta)*softmax(z2) (z2 == NULL: softmax(z1)).
- * Equals wsl_head_fwd_bwd(w_pse 0) + wsl_mixprob_fwd + wsl_gatedcrf_fwd + wsl_mixprob_bwd bit for bit, with y written by the
+ * Equals wsl_head_fwd_bwd(w_pse 0) + wsl_mixprob_fwd + wsl_gatedcrf_fwd + wsl_mixprob_bwd (to the last ulp), with y written by the
  * head's reduction pass and the gradient through y added inside the head's backward pass (two launches and the re-reads of
  * the logits / logit gradients fewer).  out[0..3] as wsl_head_fwd_bwd, out[4] = raw GatedCRF loss; y, msg: [N,C,H,W]. */
 int wsl_head_gatedcrf_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int ignore, double beta, const float* img,

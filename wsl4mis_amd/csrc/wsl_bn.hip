@@ -93,14 +93,27 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(WslSrc s, float* out, in
   const int c = blockIdx.y, n = blockIdx.z, Ho = H / 2, Wo = W / 2;
   const int64_t HW = (int64_t)H * W;
   const int base = blockIdx.x * kChunk;
+  // plain BatchNorm + LeakyReLU source with even, 8-byte aligned rows (the encoder features): a window row is one float2
+  const bool vec = s.scale && !s.emask && !s.cmask && !(W & 1) && !(HW & 1) && !(s.bs & 1) && !(reinterpret_cast<uintptr_t>(s.x) & 7);
+  const float sc = vec ? s.scale[c] : 0.f, sh = vec ? s.shift[c] : 0.f;
   for (int o = base + threadIdx.x; o < base + kChunk && o < Ho * Wo; o += kThreads) {
     const int oy = o / Wo, ox = o - oy * Wo;
     float best = 0.f;
+    if (vec) {
+      const float* p0 = s.x + n * s.bs + c * HW + (int64_t)(2 * oy) * W + 2 * ox;
+      const float2 t = *reinterpret_cast<const float2*>(p0), b = *reinterpret_cast<const float2*>(p0 + W);
+      const float v[4] = {leaky(fmaf(t.x, sc, sh)), leaky(fmaf(t.y, sc, sh)), leaky(fmaf(b.x, sc, sh)), leaky(fmaf(b.y, sc, sh))};
+      best = v[0];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t off = (int64_t)(2 * oy + (k >> 1)) * W + 2 * ox + (k & 1);
-      const float v = src_value(s, n, c, n * s.bs + c * HW + off, ((int64_t)n * s.C + c) * HW + off);
-      if (k == 0 || v > best) best = v;
+      for (int k = 1; k < 4; ++k)
+        if (v[k] > best) best = v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t off = (int64_t)(2 * oy + (k >> 1)) * W + 2 * ox + (k & 1);
+        const float v = src_value(s, n, c, n * s.bs + c * HW + off, ((int64_t)n * s.C + c) * HW + off);
+        if (k == 0 || v > best) best = v;
+      }
     }
     out[((int64_t)n * s.C + c) * Ho * Wo + o] = best;
   }
@@ -161,16 +174,28 @@ __global__ __launch_bounds__(256) void feat_grad_combine_bn_kernel(WslSrc f, con
   const float* fy = f.x + n * f.bs + c * HW;
   float s1 = 0.f, s2 = 0.f;
   const int base = blockIdx.x * kChunk;
+  // even H, W and 8-byte aligned planes (every level of the networks): a cell's two pixels of a row travel as one float2
+  const bool vec = !(H & 1) && !(W & 1) && !(HW & 1) && !(f.bs & 1) && !(ga_bs & 1) && !(gb_bs & 1) &&
+                   !(reinterpret_cast<uintptr_t>(f.x) & 7) && !(reinterpret_cast<uintptr_t>(g) & 7) &&
+                   !(reinterpret_cast<uintptr_t>(ga) & 7) && !(reinterpret_cast<uintptr_t>(gb) & 7);
   for (int o = base + threadIdx.x; o < base + kChunk && o < Hc * Wc; o += kThreads) {
     const int cy = o / Wc, cx = o - cy * Wc;
     float yv[4], zv[4];
     bool in[4];
+    if (vec) {
+      const float2 t = *reinterpret_cast<const float2*>(fy + (int64_t)(2 * cy) * W + 2 * cx);
+      const float2 b = *reinterpret_cast<const float2*>(fy + (int64_t)(2 * cy + 1) * W + 2 * cx);
+      yv[0] = t.x, yv[1] = t.y, yv[2] = b.x, yv[3] = b.y;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int y = 2 * cy + (k >> 1), x = 2 * cx + (k & 1);
-      in[k] = y < H && x < W;
-      yv[k] = in[k] ? fy[(int64_t)y * W + x] : 0.f;
-      zv[k] = fmaf(yv[k], sc, sh);
+      for (int k = 0; k < 4; ++k) in[k] = true, zv[k] = fmaf(yv[k], sc, sh);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int y = 2 * cy + (k >> 1), x = 2 * cx + (k & 1);
+        in[k] = y < H && x < W;
+        yv[k] = in[k] ? fy[(int64_t)y * W + x] : 0.f;
+        zv[k] = fmaf(yv[k], sc, sh);
+      }
     }
     int arg = -1;
     float gpool = 0.f;
@@ -183,19 +208,39 @@ __global__ __launch_bounds__(256) void feat_grad_combine_bn_kernel(WslSrc f, con
       }
       gpool = gp[((int64_t)n * f.C + c) * Ho * Wo + (int64_t)cy * Wo + cx];
     }
+    float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      const int64_t o0 = c * HW + (int64_t)(2 * cy) * W + 2 * cx;
+      if (ga) {
+        const float2 t = *reinterpret_cast<const float2*>(ga + n * ga_bs + o0), b = *reinterpret_cast<const float2*>(ga + n * ga_bs + o0 + W);
+        av[0] = t.x, av[1] = t.y, av[2] = b.x, av[3] = b.y;
+      }
+      if (gb) {
+        const float2 t = *reinterpret_cast<const float2*>(gb + n * gb_bs + o0), b = *reinterpret_cast<const float2*>(gb + n * gb_bs + o0 + W);
+        bv[0] = t.x, bv[1] = t.y, bv[2] = b.x, bv[3] = b.y;
+      }
+    }
+    float vout[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      vout[k] = 0.f;
       if (in[k]) {
         const int64_t off = (int64_t)(2 * cy + (k >> 1)) * W + 2 * cx + (k & 1);
         float v = 0.f;
-        if (ga) v = ga[n * ga_bs + c * HW + off];
-        if (gb) v = fmaf(gb[n * gb_bs + c * HW + off], cm, v);
+        if (ga) v = vec ? av[k] : ga[n * ga_bs + c * HW + off];
+        if (gb) v = fmaf(vec ? bv[k] : gb[n * gb_bs + c * HW + off], cm, v);
         if (k == arg) v += gpool;
-        g[((int64_t)n * f.C + c) * HW + off] = v;
+        if (!vec) g[((int64_t)n * f.C + c) * HW + off] = v;
+        vout[k] = v;
         const float d = zv[k] > 0.f ? v : WSL_LEAKY_SLOPE * v;
         s1 += d;
         s2 = fmaf(d, (yv[k] - mean) * invstd, s2);
       }
+    }
+    if (vec) {
+      float* go = g + ((int64_t)n * f.C + c) * HW + (int64_t)(2 * cy) * W + 2 * cx;
+      *reinterpret_cast<float2*>(go) = make_float2(vout[0], vout[1]);
+      *reinterpret_cast<float2*>(go + W) = make_float2(vout[2], vout[3]);
     }
   }
   s1 = block_sum(s1, red);

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* part, i
 }
 
 // gy != NULL: + wgt * softmax_bwd(s, gy) -- the gradient through the mixed prediction y (GatedCRF term), what
-// mixprob_bwd_kernel would accumulate in a pass of its own (same expressions, same order: bit-identical sum)
+// mixprob_bwd_kernel would accumulate in a pass of its own (same expressions; the contraction of the final sum may differ)
 __device__ __forceinline__ void head_branch_bwd(const float* s, int C, int t, int l, bool valid, const float* ca,
                                                 const float* cb, float kce, float gscale, float* dz, int64_t stride,
                                                 const float* gy = nullptr, float wgt = 1.f) {
@@ -1162,7 +1162,7 @@ extern "C" int wsl_gatedcrf_bwd(const float* msg, const float* gout, float gscal
 // train_ACDC_scribblevc.py:171-206):  loss = pCE(z1 [, z2]) + crf_weight * GatedCRF(y, image),  y = beta softmax(z1) + (1 - beta)
 // softmax(z2) (single branch: softmax(z1)).  Same kernels as wsl_head_fwd_bwd + wsl_mixprob_fwd + wsl_gatedcrf_fwd + wsl_mixprob_bwd,
 // but y is written by the head's reduction pass and the gradient through y is added inside the head's backward pass: two launches
-// and ~400 MB of logit / gradient re-reads fewer at 64 x 256 x 256, bit-identical logit gradients.
+// and ~400 MB of logit / gradient re-reads fewer at 64 x 256 x 256; same results to the last ulp.
 // out[0..3] as wsl_head_fwd_bwd (w_pse = 0), out[4] = the raw GatedCRF loss.  y, msg: [N,C,H,W] buffers (msg is kept: it is the
 // CRF term's gradient).
 extern "C" int wsl_head_gatedcrf_fwd_bwd(const float* z1, const float* z2, const uint8_t* label, int ignore, double beta,
