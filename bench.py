@@ -25,6 +25,12 @@ import random
 import sys
 import time
 
+# Before the HIP runtime loads: ROCclr multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues.  Once RCCL has
+# created its streams, the decoder side stream of libwslhip.so lands on the SAME hardware queue as the main stream and the two
+# decoders of unet_cct stop overlapping: measured 17.96 instead of 16.99 ms/step in a 1-rank RCCL group (tools/pg_overhead.py,
+# profiles/r2_pg_overhead.md).  Eight queues keep them apart.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 import torch.distributed as dist
 
@@ -178,6 +184,9 @@ def main():
         eng.concurrent = False
     for _ in range(args.warmup):
         eng.step(x, lab, random.random() + 1e-10)
+    if world > 1 or args.force_dp:
+        torch.cuda.synchronize()
+        C.CDLL(None).fflush(None)     # RCCL prints its version banner through C stdio: out now, not after the JSON line
     overlapped = (args.net == "unet_cct" or args.loss == "mean_teacher") and not args.serial_decoders
     # per-launch HIP events cost ~2 % of the step rate: when the roofline comes from its own serialised segment anyway
     # (overlapped run) the timed region stays uninstrumented unless --prof-timed asks for its overlapping figures too
@@ -373,6 +382,8 @@ def main():
             out["dp"] = dp_diag
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
+        if world > 1 or args.force_dp:
+            C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dp:
         dist.destroy_process_group()

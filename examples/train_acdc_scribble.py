@@ -13,6 +13,8 @@ import os
 import random
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP loads: keeps RCCL's streams off the decoder side stream's queue (bench.py)
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -9,7 +9,8 @@ import sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 steps = int(sys.argv[2])
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = [r for r in rows if "wsl::" in r["Kernel_Name"]]
+if "--all" not in sys.argv:
+    rows = [r for r in rows if "wsl::" in r["Kernel_Name"]]
 per = len(rows) // steps
 last = rows[-per:]
 t0 = int(last[0]["Start_Timestamp"])
@@ -20,7 +21,7 @@ for i, r in enumerate(last):
     tot += d
     name = r["Kernel_Name"].replace("void wsl::", "").replace("wsl::", "")
     name = name.split("(")[0][:60]
-    out.append(f"| {i} | {name} | {r.get('Grid_Size_X', r.get('Grid_Size', '?'))}x{r.get('Grid_Size_Y', '')}x{r.get('Grid_Size_Z', '')} | {d:.1f} | {(int(r['Start_Timestamp']) - t0) / 1e3:.0f} |")
+    out.append(f"| {i} | {name} | {r.get('Grid_Size_X', r.get('Grid_Size', '?'))}x{r.get('Grid_Size_Y', '')}x{r.get('Grid_Size_Z', '')} | {d:.1f} | {(int(r['Start_Timestamp']) - t0) / 1e3:.0f} | q{r.get('Queue_Id', '?')} |")
 span = (int(last[-1]["End_Timestamp"]) - t0) / 1e3
 out.append(f"\n{per} launches per step, kernel time {tot:.0f} us, span {span:.0f} us (gaps {span - tot:.0f} us)")
 open(sys.argv[3], "w").write("\n".join(out) + "\n")

@@ -764,6 +764,7 @@ extern "C" int wsl_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, const 
   return wgrad_stage1(a, b, dy, dy_bs, dw, db, N, H, W, Co, ks, ws, ws_bytes, stream, pending);
 }
 
+namespace wsl {
 // second stage of up to kReduceMax pending weight gradients in ONE launch: a workgroup = 32 consecutive elements of one
 // layer x 8 split groups, merged through LDS in a fixed order (same scheme as wgrad_reduce_kernel)
 constexpr int kReduceMax = 40;
@@ -811,6 +812,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(ReduceTable t) 
     }
   }
 }
+
+}  // namespace wsl
 
 extern "C" int wsl_wgrad_reduce_batch(const WslWgradPending* items, int n, void* stream) {
   WSL_REQUIRE(items && n > 0, "wgrad_reduce_batch: nothing to reduce");
