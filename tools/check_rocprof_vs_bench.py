@@ -12,7 +12,8 @@ r = d["roofline"]
 # and weight-gradient families of the library's event bracketing)
 NAMES = {"conv_mfma2l_kernel": ("conv_mfma2l_kernel", "conv_mfma2_kernel", "conv_cls_kernel"),
          "conv_wino2_kernel": ("conv_wino2_kernel", "conv_wino2r_kernel", "conv_wino_kernel"),
-         "wgrad_wino_kernel": ("wgrad_wino_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel", "wgrad_small_kernel"),
+         "wgrad_wino_kernel": ("wgrad_wino_kernel",),
+         "wgrad_direct_kernels": ("wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel", "wgrad_small_kernel"),
          "conv_wino_kernel": ("conv_wino_kernel",),
          "wgrad_mfma2s_kernel": ("wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel", "wgrad_small_kernel")}
 for kname, k in r.get("kernels", {r["kernel"]: r}).items():
