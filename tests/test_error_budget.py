@@ -141,7 +141,7 @@ def test_full_batch_forward_and_losses_match_the_oracle(full, mode):
     # pseudo-label map of the mixed softmax, end to end (HIP logits -> HIP softmax -> mix -> argmax) vs the oracle's
     n_px = full["hip"]["pseudo"].size
     labelmap_mismatch(f"full-size ours_proposed pseudo-label map ({mode}, {n_px} px)", full["hip"]["pseudo"], full["f32"]["pseudo"],
-                      allow_px=max(2, n_px // 100000))
+                      allow_px=max(2, n_px // 200000))   # measured: 2 of 4 194 304 (profiles/r2z_labelmap_rates.jsonl); allowance = 10 x that
     same = (full["hip"]["pseudo"] == full["f32"]["pseudo"])[:, None]          # [N,1,H,W]
     for kind in KINDS:
         h, r = full["hip"][kind], full["f32"][kind]
