@@ -11,6 +11,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wsl4mis_amd import _lib  # noqa: E402
 
+if os.environ.get("WSL_TOOLS_EXP", "1") != "0":   # the experiments build carries the knobs / probes these tools drive
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import explib  # noqa: E402
+    explib.use()
+
 N, Ci, Co, H, W = (int(a) for a in sys.argv[1:6])
 ks = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 L = _lib.lib()

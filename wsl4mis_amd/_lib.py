@@ -150,6 +150,7 @@ _DEBUG_PROTOS = {
     "wsl_debug_conv_variant": (i32, [i32]),
     "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
     "wsl_debug_lds_dma_probe": (i32, [c_fp, c_fp, c_fp]),
+    "wsl_debug_pk_probe": (i32, [c_fp, c_fp, c_fp]),
     "wsl_debug_mfma_stream": (i32, [i32, i32, i32, c_fp, c_fp]),
 }
 

@@ -468,6 +468,33 @@ __global__ __launch_bounds__(512) void mfma_valu_mix_kernel(float* out, int iter
   for (int i = 0; i < 8; ++i) r += x[i];
   if (r == 123.456f) out[0] = r;
 }
+
+// The same question for PACKED f32 adds (v_pk_add_f32 with op_sel, as the Winograd transforms use them): K per MFMA in the
+// same wave.  Does one packed instruction cost one vector-instruction slot or two?
+template <int K>
+__global__ __launch_bounds__(256) void mfma_pk_mix_kernel(float* out, int iters) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+  v4 acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = v4{0.f, 0.f, 0.f, 0.f};
+  wsl_v2f x[8];
+  for (int i = 0; i < 8; ++i) x[i] = wsl_v2f{a + i, a - i};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        asm volatile("v_pk_add_f32 %0, %0, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "+v"(x[k & 7]));
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, K, 0);
+    }
+  }
+  float r = 0.f;
+  for (int i = 0; i < 16; ++i) r += acc[i][0];
+  for (int i = 0; i < 8; ++i) r += x[i][0] + x[i][1];
+  if (r == 123.456f) out[0] = r;
+}
 #endif
 
 // Destination-layout probe of global_load_lds_dwordx4 (LDS DMA): every lane fetches its own 16 bytes; where do they land?
@@ -484,6 +511,23 @@ __global__ void lds_dma_probe_kernel(const float* g, float* out) {
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   for (int i = threadIdx.x; i < 2048; i += 256) out[i] = lds[i];
+}
+#endif
+
+// The packed Winograd transforms of wsl_rt.h on given data: in[t] = a 4 x 4 patch + a 2 x 2 tile, out[t] = V[16], Z[16]
+// in transform-position order (tools/probe_pk.py compares with the definitions)
+#ifndef WSL_HOST_EMUL
+__global__ void pk_probe_kernel(const float* in, float* out) {
+  const int t = threadIdx.x;
+  const float* d = in + 20 * t;
+  wsl_v2f lo[4], hi[4], a[4], b[4], q1, q2, m[4];
+  for (int i = 0; i < 4; ++i) lo[i] = wsl_v2f{d[4 * i], d[4 * i + 1]}, hi[i] = wsl_v2f{d[4 * i + 2], d[4 * i + 3]};
+  const wsl_v2f r0 = {d[16], d[17]}, r1 = {d[18], d[19]};
+  wino_btdb_pk(lo, hi, a, b);
+  wino_aya_pk(r0, r1, q1, q2, m);
+  const wsl_v2f q[4] = {r0, q1, q2, r1};
+  float* o = out + 32 * t;
+  for (int xi = 0; xi < 16; ++xi) o[xi] = wino_pick(a, b, xi), o[16 + xi] = wino_pick(q, m, xi);
 }
 #endif
 
@@ -526,6 +570,11 @@ extern "C" int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* ou
   else if (shape == 204) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<1, 4>), dim3(blocks), dim3(512), 0, stream, out, iters);
   else if (shape == 208) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<1, 8>), dim3(blocks), dim3(512), 0, stream, out, iters);
   else if (shape == 216) WSL_LAUNCH((wsl::mfma_valu_mix_kernel<1, 16>), dim3(blocks), dim3(512), 0, stream, out, iters);
+  // 300 + K: K v_pk_add_f32 (op_sel form) per MFMA in the same wave
+  else if (shape == 301) WSL_LAUNCH((wsl::mfma_pk_mix_kernel<1>), dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 302) WSL_LAUNCH((wsl::mfma_pk_mix_kernel<2>), dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 304) WSL_LAUNCH((wsl::mfma_pk_mix_kernel<4>), dim3(blocks), dim3(256), 0, stream, out, iters);
+  else if (shape == 308) WSL_LAUNCH((wsl::mfma_pk_mix_kernel<8>), dim3(blocks), dim3(256), 0, stream, out, iters);
   else {
     wsl::set_error("debug_mfma_stream: shape %d", shape);
     return WSL_EINVAL;
@@ -533,6 +582,16 @@ extern "C" int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* ou
   return wsl::check_launch("mfma_stream_kernel");
 #else
   (void)shape, (void)blocks, (void)iters, (void)out, (void)stream;
+  return WSL_EUNSUPPORTED;
+#endif
+}
+
+extern "C" int wsl_debug_pk_probe(const float* in, float* out, void* stream) {
+#ifndef WSL_HOST_EMUL
+  WSL_LAUNCH(wsl::pk_probe_kernel, dim3(1), dim3(64), 0, stream, in, out);
+  return wsl::check_launch("pk_probe_kernel");
+#else
+  (void)in, (void)out, (void)stream;
   return WSL_EUNSUPPORTED;
 #endif
 }

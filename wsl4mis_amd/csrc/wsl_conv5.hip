@@ -376,7 +376,7 @@ struct Wino2Cfg {
 // epilogue of both conv_wino2 kernels: output transform (register-only), bias, float4 stores, BatchNorm partials
 template <typename C, int TH, int TW, int NT>
 __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2], float* scratch, int n, int co0, int y0, int x0,
-                                               int tile_id, int nb) {
+                                               int tile_id, int nb, int cby) {
   constexpr int CO_T = C::CO_T, MTW = C::MTW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = p.W, HW = p.H * p.W;
@@ -395,15 +395,22 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2]
       const int a = m * NT + j;
       const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
       float bs = 0.f;
+      // first stage (A^T M, down the rows) on register pairs = two of the lane's four tiles per packed add
+      wsl_v2f s0p[4][2], s1p[4][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const wsl_v2f m0 = {acc[c][a][2 * h], acc[c][a][2 * h + 1]}, m1 = {acc[4 + c][a][2 * h], acc[4 + c][a][2 * h + 1]};
+          const wsl_v2f m2 = {acc[8 + c][a][2 * h], acc[8 + c][a][2 * h + 1]}, m3 = {acc[12 + c][a][2 * h], acc[12 + c][a][2 * h + 1]};
+          s0p[c][h] = (m0 + m1) + m2;   // (plain C++: these read MFMA results -- see the hazard note in wsl_rt.h)
+          s1p[c][h] = (m1 - m2) - m3;
+        }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s0[4], s1[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float m0 = acc[c][a][r], m1 = acc[4 + c][a][r], m2 = acc[8 + c][a][r], m3 = acc[12 + c][a][r];
-          s0[c] = (m0 + m1) + m2;
-          s1[c] = (m1 - m2) - m3;
-        }
+        for (int c = 0; c < 4; ++c) s0[c] = s0p[c][r >> 1][r & 1], s1[c] = s1p[c][r >> 1][r & 1];
         const float y00 = ((s0[0] + s0[1]) + s0[2]) + bias, y01 = ((s0[1] - s0[2]) - s0[3]) + bias;
         const float y10 = ((s1[0] + s1[1]) + s1[2]) + bias, y11 = ((s1[1] - s1[2]) - s1[3]) + bias;
         o[a][2 * r] = y00, o[a][2 * r + 1] = y01, o[a][8 + 2 * r] = y10, o[a][8 + 2 * r + 1] = y11;
@@ -476,7 +483,7 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2]
         dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
         dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
       }
-      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
+      if (lane < p.slots && cby == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
     }
   }
 }
@@ -499,7 +506,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
   bid /= p.tiles_x;
   const int ty_i = bid % p.tiles_y;
   const int n = bid / p.tiles_y;
-  const int co0 = blockIdx.y * CO_T;
+  const int cby = blockIdx.y;
+  const int co0 = cby * CO_T;
   const int y0 = ty_i * TH, x0 = tx_i * TW;
   const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
   const int HW = H * W;
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
   const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
   const uint8_t* ma_n = p.a.emask ? p.a.emask + (int64_t)n * p.a.C * HW : nullptr;
   const uint8_t* mb_n = (p.b.C && p.b.emask) ? p.b.emask + (int64_t)n * p.b.C * HW : nullptr;
-  const float* w_n = p.u + (int64_t)blockIdx.y * C::W_FLOATS + 4 * tid;
+  const float* w_n = p.u + (int64_t)cby * C::W_FLOATS + 4 * tid;
   const int64_t w_cstride = (int64_t)(Co / CO_T) * C::W_FLOATS;
 
   float4 pre[C::NLD];
@@ -597,30 +605,40 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
     commit(c0);
     if (c0 + KC < Ci) issue(c0 + KC);   // flies across the whole compute phase
     __syncthreads();
-    v4f rd[MTW][4];
+    // packed input transform (wsl_rt.h) where the registers allow it: the 128-tile variant sits at 256 VGPRs and the even
+    // alignment of the register pairs costs it two spilled dwords, so it keeps the scalar form
+    constexpr bool PK = MTW == 1;
+    wsl_v2f rlo[MTW][4], rhi[MTW][4];   // the 4 x 4 patches, one row per pair of register pairs
+    v4f rd[MTW][4];                     // (scalar form: one row per vector)
     auto fetch = [&](int kg) __attribute__((always_inline)) {
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float* r = in_t + kg * (4 * C::PLANE) + poff[m] + i * C::ROWP;
-          const float2 mm = *reinterpret_cast<const float2*>(r + 1);
-          rd[m][i] = v4f{r[0], mm.x, mm.y, r[3]};
+          if constexpr (PK) {   // (odd float offset: two ds_read2_b32, each into an aligned register pair)
+            rlo[m][i] = wsl_v2f{r[0], r[1]}, rhi[m][i] = wsl_v2f{r[2], r[3]};
+          } else {
+            const float2 mm = *reinterpret_cast<const float2*>(r + 1);
+            rd[m][i] = v4f{r[0], mm.x, mm.y, r[3]};
+          }
         }
     };
     fetch(0);
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
-      float v[MTW][16];
+      wsl_v2f va[MTW][4], vb[MTW][4];   // V[4 i + {0, 3}] = va[i], V[4 i + {1, 2}] = vb[i]: 16 packed adds
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
-        const v4f rt[4] = {rd[m][0] - rd[m][2], rd[m][1] + rd[m][2], rd[m][2] - rd[m][1], rd[m][1] - rd[m][3]};
+        if constexpr (PK) {
+          wino_btdb_pk(rlo[m], rhi[m], va[m], vb[m]);
+        } else {
+          const v4f rt[4] = {rd[m][0] - rd[m][2], rd[m][1] + rd[m][2], rd[m][2] - rd[m][1], rd[m][1] - rd[m][3]};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[m][4 * i + 0] = rt[i][0] - rt[i][2];
-          v[m][4 * i + 1] = rt[i][1] + rt[i][2];
-          v[m][4 * i + 2] = rt[i][2] - rt[i][1];
-          v[m][4 * i + 3] = rt[i][1] - rt[i][3];
+          for (int i = 0; i < 4; ++i) {
+            va[m][i] = wsl_v2f{rt[i][0] - rt[i][2], rt[i][1] - rt[i][3]};
+            vb[m][i] = wsl_v2f{rt[i][1] + rt[i][2], rt[i][2] - rt[i][1]};
+          }
         }
       }
       if (kg == 0) fetch(1);   // the second channel group's patches are read while the first group's MFMAs issue
@@ -645,14 +663,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi % BR][j], acc[xi][m * NT + j]);
+          for (int j = 0; j < NT; ++j) acc[xi][m * NT + j] = WSL_MFMA16(wino_pick(va[m], vb[m], xi), bv[xi % BR][j], acc[xi][m * NT + j]);
         WSL_SCHED_BARRIER();
       }
     }
     __syncthreads();
   }
 
-  wino2_epilogue<C, TH, TW, NT>(p, acc, in_t, n, co0, y0, x0, tile_id, nb);
+  wino2_epilogue<C, TH, TW, NT>(p, acc, in_t, n, co0, y0, x0, tile_id, nb, cby);
 }
 
 // conv_wino2_kernel for launches whose sources carry no loader transform (every data-gradient launch): the raw tile and the
@@ -684,7 +702,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   bid /= p.tiles_x;
   const int ty_i = bid % p.tiles_y;
   const int n = bid / p.tiles_y;
-  const int co0 = blockIdx.y * CO_T;
+  const int cby = blockIdx.y;
+  const int co0 = cby * CO_T;
   const int y0 = ty_i * TH, x0 = tx_i * TW;
   const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
   const int HW = H * W;
@@ -698,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   const int64_t gstride = (int64_t)C::G * HW;
   const float* xa_n = p.a.x + n * p.a.bs;
   const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
-  const float* w_n = p.u + (int64_t)blockIdx.y * C::W_FLOATS + 4 * tid;
+  const float* w_n = p.u + (int64_t)cby * C::W_FLOATS + 4 * tid;
   const int64_t w_cstride = (int64_t)(Co / CO_T) * C::W_FLOATS;
 
   // slots of positions outside the image stay zero in both buffers for the whole kernel: the DMA never touches them
@@ -742,32 +761,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
     if (c0 + KC < Ci) issue(c0 + KC, bsel ^ 1);   // the next chunk streams into the other buffers during this one's compute
     const float* in_t = in_b + bsel * C::IN_FLOATS;
     const float* w_t = w_b + bsel * C::W_FLOATS;
-    v4f rd[MTW][4];
+    wsl_v2f rlo[MTW][4], rhi[MTW][4];   // the 4 x 4 patches, one row per pair of register pairs
     auto fetch = [&](int kg) __attribute__((always_inline)) {
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {   // (odd float offset: two ds_read2_b32, each into an aligned register pair)
           const float* r = in_t + kg * (4 * C::PLANE) + poff[m] + i * C::ROWP;
-          const float2 mm = *reinterpret_cast<const float2*>(r + 1);
-          rd[m][i] = v4f{r[0], mm.x, mm.y, r[3]};
+          rlo[m][i] = wsl_v2f{r[0], r[1]}, rhi[m][i] = wsl_v2f{r[2], r[3]};
         }
     };
     fetch(0);
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
-      float v[MTW][16];
+      wsl_v2f va[MTW][4], vb[MTW][4];   // V[4 i + {0, 3}] = va[i], V[4 i + {1, 2}] = vb[i]: 16 packed adds (wsl_rt.h)
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        const v4f rt[4] = {rd[m][0] - rd[m][2], rd[m][1] + rd[m][2], rd[m][2] - rd[m][1], rd[m][1] - rd[m][3]};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[m][4 * i + 0] = rt[i][0] - rt[i][2];
-          v[m][4 * i + 1] = rt[i][1] + rt[i][2];
-          v[m][4 * i + 2] = rt[i][2] - rt[i][1];
-          v[m][4 * i + 3] = rt[i][1] - rt[i][3];
-        }
-      }
+      for (int m = 0; m < MTW; ++m) wino_btdb_pk(rlo[m], rhi[m], va[m], vb[m]);
       if (kg == 0) fetch(1);
       constexpr int BD = NT == 2 ? 4 : 2, BR = BD + 1;
       float bv[BR][NT];
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
           for (int j = 0; j < NT; ++j) {
             const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
             const v4f cin = (FIRST && kg == 0) ? zero4 : acc[xi][m * NT + j];
-            acc[xi][m * NT + j] = WSL_MFMA16(v[m][xi], bv[xi % BR][j], cin);
+            acc[xi][m * NT + j] = WSL_MFMA16(wino_pick(va[m], vb[m], xi), bv[xi % BR][j], cin);
           }
         WSL_SCHED_BARRIER();
       }
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   };
   chunk(0, 0, std::true_type{});
   for (int c0 = KC, bsel = 1; c0 < Ci; c0 += KC, bsel ^= 1) chunk(c0, bsel, std::false_type{});
-  wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb);
+  wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
 }
 
 // ------------------------------------------------------------------------------------------------ filter transform
@@ -1156,57 +1165,46 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
   // before the MFMAs of group g issue.  Z is formed WITHOUT the two negations of A (rows/columns with index 3 carry the
   // opposite sign: Z'[p][q] = s_p s_q Z[p][q], s_3 = -1); the epilogue puts the signs back into M.
   auto compute = [&](const float* dy_t, const float* a_t) __attribute__((always_inline)) {
-    float2 rdy[NCO][2];   // [jc][row]
-    v4f rd[4];            // the 4 x 4 input patch, one row per vector
+    wsl_v2f rdy[NCO][2];     // [jc][row]
+    wsl_v2f rlo[4], rhi[4];  // the 4 x 4 input patch, one row per pair of register pairs
     auto fetch = [&](int g) __attribute__((always_inline)) {
       const int tau = g * 4 + t4, tyy = tau / C::TTX, txx = tau - tyy * C::TTX;
 #pragma unroll
       for (int jc = 0; jc < NCO; ++jc) {
         const float* dp = dy_t + (jc * 16 + c16) * C::PLD + (2 * tyy) * TW + 2 * txx;
-        rdy[jc][0] = *reinterpret_cast<const float2*>(dp), rdy[jc][1] = *reinterpret_cast<const float2*>(dp + TW);
+        rdy[jc][0] = *reinterpret_cast<const wsl_v2f*>(dp), rdy[jc][1] = *reinterpret_cast<const wsl_v2f*>(dp + TW);
       }
       const float* ap = a_t + (cit * 16 + c16) * C::PLA + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i) {   // (odd float offset: two ds_read2_b32, each into an aligned register pair)
         const float* r = ap + i * C::ROWP;
-        const float2 m = *reinterpret_cast<const float2*>(r + 1);
-        rd[i] = v4f{r[0], m.x, m.y, r[3]};
+        rlo[i] = wsl_v2f{r[0], r[1]}, rhi[i] = wsl_v2f{r[2], r[3]};
       }
     };
     constexpr int GN = C::GROUPS / C::NSUB;
     fetch(sub * GN);
 #pragma unroll   // (fully: a rolled loop pays 24 register moves per group for the prefetched operands)
     for (int gi = 0; gi < GN; ++gi) {
-      float z[NCO][16];
+      // Z[4 i + {0, 3}] = zq[i], Z[4 i + {1, 2}] = zm[i]; V likewise in (va, vb): packed adds (wsl_rt.h), 28 instead of 56
+      wsl_v2f zq[NCO][4], zm[NCO][4], va[4], vb[4];
 #pragma unroll
       for (int jc = 0; jc < NCO; ++jc) {
-        const wsl_v2f r0 = {rdy[jc][0].x, rdy[jc][0].y}, r1 = {rdy[jc][1].x, rdy[jc][1].y};
-        const wsl_v2f q[4] = {r0, r0 + r1, r0 - r1, r1};   // q[3] = +dY[1] (sign folded)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          z[jc][4 * i + 0] = q[i][0];
-          z[jc][4 * i + 1] = q[i][0] + q[i][1];
-          z[jc][4 * i + 2] = q[i][0] - q[i][1];
-          z[jc][4 * i + 3] = q[i][1];                       // sign folded
-        }
-        if (dbw) accb[jc] += z[jc][5];
+        zq[jc][0] = rdy[jc][0], zq[jc][3] = rdy[jc][1];   // zq[3] = +dY[1], zm[..][1] = q0 - q1: signs folded
+        wino_aya_pk(rdy[jc][0], rdy[jc][1], zq[jc][1], zq[jc][2], zm[jc]);
+        if (dbw) accb[jc] += zm[jc][1][0];
       }
-      float v[16];
-      {
-        const v4f rt[4] = {rd[0] - rd[2], rd[1] + rd[2], rd[2] - rd[1], rd[1] - rd[3]};   // packed over the 4 columns
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[4 * i + 0] = rt[i][0] - rt[i][2];
-          v[4 * i + 1] = rt[i][1] + rt[i][2];
-          v[4 * i + 2] = rt[i][2] - rt[i][1];
-          v[4 * i + 3] = rt[i][1] - rt[i][3];
-        }
-      }
+      wino_btdb_pk(rlo, rhi, va, vb);
       if (gi + 1 < GN) fetch(sub * GN + gi + 1);
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi)
+      for (int xi = 0; xi < 16; ++xi) {
+        const int i = xi >> 2, c = xi & 3;
+        const float vv = c == 0 ? va[i][0] : c == 3 ? va[i][1] : c == 1 ? vb[i][0] : vb[i][1];
 #pragma unroll
-        for (int jc = 0; jc < NCO; ++jc) acc[xi][jc] = WSL_MFMA16(z[jc][xi], v[xi], acc[xi][jc]);
+        for (int jc = 0; jc < NCO; ++jc) {
+          const float zz = c == 0 ? zq[jc][i][0] : c == 3 ? zq[jc][i][1] : c == 1 ? zm[jc][i][0] : zm[jc][i][1];
+          acc[xi][jc] = WSL_MFMA16(zz, vv, acc[xi][jc]);
+        }
+      }
     }
   };
 

@@ -20,6 +20,7 @@ int wsl_debug_wino_variant(int conv_form, int wgrad_waves);   /* 1 = first Winog
 int wsl_debug_conv_variant(int v);                            /* 3 = wave-specialised persistent conv (wsl_conv3.hip) */
 int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, void* stream);          /* tools/probe_mfma4.py */
 int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* out, void* stream);      /* tools/mfma_ceiling.py */
+int wsl_debug_pk_probe(const float* in, float* out, void* stream);                            /* tools/probe_pk.py */
 int wsl_debug_lds_dma_probe(const float* g, float* out, void* stream);                      /* tools/probe_lds_dma.py */
 #ifdef __cplusplus
 }

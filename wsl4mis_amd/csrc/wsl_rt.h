@@ -114,6 +114,82 @@ __device__ __forceinline__ void xform_mask(wsl_v2f& lo, wsl_v2f& hi, uint32_t m,
   lo = (lo * es) * m01, hi = (hi * es) * m23;
 }
 
+// Packed f32 adds whose two results take their operands from DIFFERENT halves of the source register pairs (VOP3P op_sel /
+// neg_hi), so the Winograd transforms run two outputs per vector instruction with every result already in the register an
+// MFMA operand wants -- the plain vector form needs v_mov_b32 to un-interleave and loses what it saved.  Same IEEE adds as
+// the scalar form: bit-identical results.
+//   mid(P, Q) = (P.y + Q.x, Q.x - P.y)   [op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]]
+//   sd(q)     = (q.x + q.y, q.x - q.y)   [op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]]       (tools/probe_pk.py checks both)
+// The compiler has no pattern for these forms, so they are inline assembly -- and the hazard recogniser does not look
+// inside inline assembly: a vector write needs two wait states before an MFMA reads it as A / B operand, and an MFMA result
+// needs far more before a vector instruction may read it.  Hence (1) every transform is ONE asm block that ends in
+// `s_nop 1`, so whatever follows is safe, and (2) the blocks only ever read registers loaded from LDS -- transforms of MFMA
+// results (the output transforms) stay in C++, where the compiler sees the instructions and pads them itself.
+#define WSL_PK_SUB " neg_lo:[0,1] neg_hi:[0,1]\n"
+#define WSL_PK_MID " op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n"
+#define WSL_PK_SD " op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+
+// B^T d B of one 4 x 4 patch given as rows of two register pairs each ((d0, d1), (d2, d3)); results as the pairs
+// a[i] = (V[i][0], V[i][3]), b[i] = (V[i][1], V[i][2]): 16 packed adds instead of 32 scalar ones
+__device__ __forceinline__ void wino_btdb_pk(const wsl_v2f (&lo)[4], const wsl_v2f (&hi)[4], wsl_v2f (&a)[4], wsl_v2f (&b)[4]) {
+#ifdef WSL_HOST_EMUL
+  const wsl_v2f tl[4] = {lo[0] - lo[2], lo[1] + lo[2], lo[2] - lo[1], lo[1] - lo[3]};
+  const wsl_v2f th[4] = {hi[0] - hi[2], hi[1] + hi[2], hi[2] - hi[1], hi[1] - hi[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = tl[i] - th[i], b[i] = wsl_v2f{tl[i][1] + th[i][0], th[i][0] - tl[i][1]};
+#else
+  wsl_v2f t0, t1, t2, t3;   // the high halves' row combinations (dead after the block)
+  asm("v_pk_add_f32 %0, %12, %14" WSL_PK_SUB      // a[i] <- tl[i] = row combinations of the low halves
+      "v_pk_add_f32 %1, %13, %14\n"
+      "v_pk_add_f32 %2, %14, %13" WSL_PK_SUB
+      "v_pk_add_f32 %3, %13, %15" WSL_PK_SUB
+      "v_pk_add_f32 %8, %16, %18" WSL_PK_SUB      // t[i] <- th[i]
+      "v_pk_add_f32 %9, %17, %18\n"
+      "v_pk_add_f32 %10, %18, %17" WSL_PK_SUB
+      "v_pk_add_f32 %11, %17, %19" WSL_PK_SUB
+      "v_pk_add_f32 %4, %0, %8" WSL_PK_MID        // b[i] = mid(tl[i], th[i])
+      "v_pk_add_f32 %5, %1, %9" WSL_PK_MID
+      "v_pk_add_f32 %6, %2, %10" WSL_PK_MID
+      "v_pk_add_f32 %7, %3, %11" WSL_PK_MID
+      "v_pk_add_f32 %0, %0, %8" WSL_PK_SUB        // a[i] = tl[i] - th[i] (in place)
+      "v_pk_add_f32 %1, %1, %9" WSL_PK_SUB
+      "v_pk_add_f32 %2, %2, %10" WSL_PK_SUB
+      "v_pk_add_f32 %3, %3, %11" WSL_PK_SUB
+      "s_nop 1"
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(t0),
+        "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
+#endif
+}
+
+// A dY A^T of one 2 x 2 output-gradient tile given as its rows r0, r1, WITHOUT the two negations of A (folded into the
+// caller's epilogue): rows q1 = r0 + r1, q2 = r0 - r1 (q0 = r0, q3 = r1 need no instruction) and m[i] = sd(q[i]);
+// Z[4 i + {0, 3}] = q[i], Z[4 i + {1, 2}] = m[i].  6 packed adds instead of 12 scalar ones
+__device__ __forceinline__ void wino_aya_pk(wsl_v2f r0, wsl_v2f r1, wsl_v2f& q1, wsl_v2f& q2, wsl_v2f (&m)[4]) {
+#ifdef WSL_HOST_EMUL
+  q1 = r0 + r1, q2 = r0 - r1;
+  const wsl_v2f q[4] = {r0, q1, q2, r1};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) m[i] = wsl_v2f{q[i][0] + q[i][1], q[i][0] - q[i][1]};
+#else
+  asm("v_pk_add_f32 %0, %6, %7\n"
+      "v_pk_add_f32 %1, %6, %7" WSL_PK_SUB
+      "v_pk_add_f32 %2, %6, %6" WSL_PK_SD
+      "v_pk_add_f32 %5, %7, %7" WSL_PK_SD
+      "v_pk_add_f32 %3, %0, %0" WSL_PK_SD
+      "v_pk_add_f32 %4, %1, %1" WSL_PK_SD
+      "s_nop 1"
+      : "=&v"(q1), "=&v"(q2), "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3])
+      : "v"(r0), "v"(r1));
+#endif
+}
+
+// element xi = 4 i + c of a transform held as the pairs a[i] = (X[i][0], X[i][3]), b[i] = (X[i][1], X[i][2]) (xi constant after unrolling)
+__device__ __forceinline__ float wino_pick(const wsl_v2f (&a)[4], const wsl_v2f (&b)[4], int xi) {
+  const int i = xi >> 2, c = xi & 3;
+  return c == 0 ? a[i][0] : c == 3 ? a[i][1] : c == 1 ? b[i][0] : b[i][1];
+}
+
 // Sum over the 64 lanes of a wave; every lane gets the total.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
