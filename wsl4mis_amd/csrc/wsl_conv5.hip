@@ -1053,7 +1053,7 @@ struct WgWinoCfg {
                     (NCI == 1 || NCI == 2) && (NW == 4 || NW == 8), "tile shape");
 };
 
-template <int TH, int TW, int NCO, int NCI, int NW>
+template <int TH, int TW, int NCO, int NCI, int NW, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(WgWinoP p) {
   using C = WgWinoCfg<TH, TW, NCO, NCI, NW>;
   WSL_DYN_SMEM(smem);
@@ -1185,6 +1185,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
     fetch(sub * GN);
 #pragma unroll   // (fully: a rolled loop pays 24 register moves per group for the prefetched operands)
     for (int gi = 0; gi < GN; ++gi) {
+      if constexpr ((ABL & 8) != 0) {   // (ablation: operands of the first group for every group -- no further LDS reads)
+        if (gi > 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rlo[i] += 1.f, rhi[i] += 1.f;
+        }
+      }
       // Z[4 i + {0, 3}] = zq[i], Z[4 i + {1, 2}] = zm[i]; V likewise in (va, vb): packed adds (wsl_rt.h), 28 instead of 56
       wsl_v2f zq[NCO][4], zm[NCO][4], va[4], vb[4];
 #pragma unroll
@@ -1194,7 +1200,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
         if (dbw) accb[jc] += zm[jc][1][0];
       }
       wino_btdb_pk(rlo, rhi, va, vb);
-      if (gi + 1 < GN) fetch(sub * GN + gi + 1);
+      if constexpr ((ABL & 8) == 0) {
+        if (gi + 1 < GN) fetch(sub * GN + gi + 1);
+      }
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) {
         const int i = xi >> 2, c = xi & 3;
@@ -1202,20 +1210,40 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
 #pragma unroll
         for (int jc = 0; jc < NCO; ++jc) {
           const float zz = c == 0 ? zq[jc][i][0] : c == 3 ? zq[jc][i][1] : c == 1 ? zm[jc][i][0] : zm[jc][i][1];
-          acc[xi][jc] = WSL_MFMA16(zz, vv, acc[xi][jc]);
+          if constexpr ((ABL & 4) != 0) acc[xi][jc][0] += zz * vv;   // (ablation: one vector multiply-add instead of the MFMA)
+          else acc[xi][jc] = WSL_MFMA16(zz, vv, acc[xi][jc]);
         }
       }
     }
   };
 
   __syncthreads();   // BN table visible
-  if constexpr (C::NBUF == 1) {
-    // a step is ~5000 cycles of matrix work per wave; the co-resident workgroup covers this one's load latency
-    for (int item = it0; item < it1; ++item) {
+  if constexpr (C::NBUF == 1 && (ABL & 32) != 0) {
+    // (experiment: the next tile's global loads are in flight during the matrix phase, committed after it)
+    if (it0 < it1) {
       issue();
       commit(tiles, tiles + C::DY_FLOATS);
-      __syncthreads();
+    }
+    __syncthreads();
+    for (int item = it0; item < it1; ++item) {
+      const bool more = item + 1 < it1;
+      if (more) issue();
       compute(tiles, tiles + C::DY_FLOATS);
+      __syncthreads();
+      if (more) commit(tiles, tiles + C::DY_FLOATS);
+      __syncthreads();
+    }
+  } else if constexpr (C::NBUF == 1) {
+    // a step is ~5000 cycles of matrix work per wave; the co-resident workgroup covers this one's load latency
+    for (int item = it0; item < it1; ++item) {
+      // (ABL: compile-time phase ablations of the experiments build, env WSL_WGWINO_ABLATE -- 1 no matrix phase, 2 global loads +
+      //  staging only for the first tile, 4 / 8 inside the matrix phase; wrong results by design)
+      if ((ABL & 2) == 0 || item == it0) {
+        issue();
+        commit(tiles, tiles + C::DY_FLOATS);
+      }
+      __syncthreads();
+      if constexpr ((ABL & 1) == 0) compute(tiles, tiles + C::DY_FLOATS);
       __syncthreads();
     }
   } else {
@@ -1307,6 +1335,18 @@ template <int TH, int TW, int NCO, int NCI, int NW>
 static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
   using C = WgWinoCfg<TH, TW, NCO, NCI, NW>;
   auto kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW>;
+#ifdef WSL_EXPERIMENTS
+  if constexpr (NW == 4) {
+    static const int abl = WSL_TUNE("WSL_WGWINO_ABLATE", 0);   // (WSL_WGRAD_ABLATE belongs to the direct kernel and disables this one)
+    if (abl == 1) kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW, 1>;
+    if (abl == 2) kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW, 2>;
+    if (abl == 3) kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW, 3>;
+    if (abl == 32) kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW, 32>;   // in-workgroup prefetch
+    if (abl == 6) kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW, 6>;     // LDS reads + transforms, no MFMA, no global traffic
+    if (abl == 10) kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW, 10>;   // transforms + MFMA, no LDS reads, no global traffic
+    if (abl == 14) kern = wgrad_wino_kernel<TH, TW, NCO, NCI, NW, 14>;   // transforms only
+  }
+#endif
   static bool attr_done = false;
   if (!attr_done) {
     (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
