@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         wsl_v2f lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
         if (has_scale) xform_bn_leaky(lo, hi, tb[i].x, tb[i].y);
         if (has_mask) xform_mask(lo, hi, prm[i], es);
-        if (has_cm) lo = lo * cmv[i], hi = hi * cmv[i];
+        lo = lo * cmv[i], hi = hi * cmv[i];   // (1.0 without a channel mask: exact, and cheaper than selecting)
         *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
       }
     }
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
         wsl_v2f lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
         if (has_scale) xform_bn_leaky(lo, hi, tb[i].x, tb[i].y);
         if (has_mask) xform_mask(lo, hi, prm[i], es);
-        if (has_cm) lo = lo * cmv[i], hi = hi * cmv[i];
+        lo = lo * cmv[i], hi = hi * cmv[i];   // (1.0 without a channel mask: exact, and cheaper than selecting)
         *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
       }
     }
@@ -1130,10 +1130,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
 #pragma unroll
       for (int i = 0; i < C::NA; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * astride + taoff);
     }
+    // per-channel factor of this position: the channel mask (1 without one), 0 outside the image -- one multiply replaces
+    // two selects per element (the out-of-image slots read finite data at offset 0, so the product is a zero)
     if (has_cm) {
       const float* cmb = s.cmask + (int64_t)n * s.C + chb0 + (owner_a ? ga : 0);
 #pragma unroll
-      for (int i = 0; i < C::NA; ++i) prc[i] = cmb[i * C::GA];
+      for (int i = 0; i < C::NA; ++i) prc[i] = pr_aok ? cmb[i * C::GA] : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) prc[i] = pr_aok ? 1.f : 0.f;
     }
   };
   auto commit = [&](float* dy_t, float* a_t) __attribute__((always_inline)) {
@@ -1152,8 +1157,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
           xform_bn_leaky(lo, hi, t.x, t.y);
         }
         if (has_mask) xform_mask(lo, hi, prm[i], es);
-        if (has_cm) lo = lo * prc[i], hi = hi * prc[i];
-        if (!pr_aok) lo = wsl_v2f{0.f, 0.f}, hi = wsl_v2f{0.f, 0.f};
+        lo = lo * prc[i], hi = hi * prc[i];
         float* dst = a_t + i * (C::GA * C::PLA) + aloff;
         *reinterpret_cast<float2*>(dst) = make_float2(lo[0], lo[1]);
         *reinterpret_cast<float2*>(dst + 2) = make_float2(hi[0], hi[1]);
