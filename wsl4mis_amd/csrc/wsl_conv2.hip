@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
 #pragma unroll
     for (int j = 0; j < C::NT; ++j) {
       const int co = co0 + j * 16 + (lane & 15);
-      s1[j] = 0.f, s2[j] = 0.f;
+      BnBwdAcc ba;
       if (co < p.Co) {
         const float mean = p.bn.st[co], invstd = p.bn.st[p.Co + co], sc = p.bn.st[2 * p.Co + co], sh = p.bn.st[3 * p.Co + co];
 #pragma unroll
@@ -282,9 +282,10 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINW)) void c
           const int oy = y0 + mt / C::SEGS, ox = x0 + (mt % C::SEGS) * 16 + (lane >> 4) * 4;
           if (oy < H && ox < W)
             bn_bwd_acc4(p.bn, ((int64_t)n * p.Co + co) * HW + (int64_t)oy * W + ox, acc[i][j][0], acc[i][j][1], acc[i][j][2],
-                        acc[i][j][3], mean, invstd, sc, sh, s1[j], s2[j]);
+                        acc[i][j][3], mean, invstd, sc, sh, ba);
         }
       }
+      bn_bwd_fold(ba, s1[j], s2[j]);
     }
     bn_bwd_store<C::NT, CO_T>(p.bn, s1, s2, in_t, co0, p.Co, tile_id, (int)gridDim.x);
     return;
@@ -552,12 +553,13 @@ __global__ __launch_bounds__(256, (Conv2Cfg<KS, TH, TW, CO_T, KC>::MINWL)) void 
       const int co = co0 + j * 16 + (lane & 15);
       const float mean = p.bn.st[co], invstd = p.bn.st[Co + co], sc = p.bn.st[2 * Co + co], sh = p.bn.st[3 * Co + co];
       const int64_t base = ((int64_t)n * Co + co) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
-      s1[j] = 0.f, s2[j] = 0.f;
+      BnBwdAcc ba;
 #pragma unroll
       for (int i = 0; i < C::MT; ++i) {
         bn_bwd_acc4(p.bn, base + (i / C::SEGS) * W + (i % C::SEGS) * 16, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3],
-                    mean, invstd, sc, sh, s1[j], s2[j]);
+                    mean, invstd, sc, sh, ba);
       }
+      bn_bwd_fold(ba, s1[j], s2[j]);
     }
     bn_bwd_store<C::NT, CO_T>(p.bn, s1, s2, in_t, co0, Co, tile_id, nb);
     return;

@@ -374,9 +374,23 @@ struct Wino2Cfg {
 };
 
 // epilogue of both conv_wino2 kernels: output transform (register-only), bias, float4 stores, BatchNorm partials
-template <typename C, int TH, int TW, int NT>
+// positions of the lane's output float4s (and of the BatchNorm-backward epilogue's y / keep-mask reads): q = (m * NT + j) * 4
+// + {0: row 0, 1: row 0 + 4 px, 2: row 1, 3: row 1 + 4 px}
+template <typename C, int NT>
+__device__ __forceinline__ int64_t wino2_out_index(const WinoP& p, int n, int co0, int y0, int x0, int q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int a = q >> 2, m = a / NT, j = a - m * NT, r = q & 3;
+  const int tb = (wave * C::MTW + m) * 16 + 4 * (lane >> 4);
+  const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
+  return ((int64_t)n * p.Co + co0 + j * 16 + (lane & 15)) * ((int64_t)p.H * p.W) + (int64_t)(y0 + 2 * tyy + (r >> 1)) * p.W + x0 +
+         2 * txb + 4 * (r & 1);
+}
+
+// PRE: the caller has the BatchNorm-backward epilogue's y / keep-mask values in registers (loaded before its channel loop)
+template <typename C, int TH, int TW, int NT, bool PRE = false>
 __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2], float* scratch, int n, int co0, int y0, int x0,
-                                               int tile_id, int nb, int cby) {
+                                               int tile_id, int nb, int cby, const float4* ypre = nullptr,
+                                               const uint32_t* mpre = nullptr) {
   constexpr int CO_T = C::CO_T, MTW = C::MTW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = p.W, HW = p.H * p.W;
@@ -430,18 +444,26 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2]
     for (int j = 0; j < NT; ++j) {
       const int co = co0 + j * 16 + (lane & 15);
       const float mean = p.bn.st[co], invstd = p.bn.st[p.Co + co], sc = p.bn.st[2 * p.Co + co], sh = p.bn.st[3 * p.Co + co];
-      s1[j] = 0.f, s2[j] = 0.f;
+      BnBwdAcc ba;
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
         const int tb = (wave * MTW + m) * 16 + 4 * (lane >> 4);
         const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
         const int64_t base = ((int64_t)n * p.Co + co) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
         const int a = m * NT + j;
-        bn_bwd_acc4(p.bn, base, o[a][0], o[a][1], o[a][2], o[a][3], mean, invstd, sc, sh, s1[j], s2[j]);
-        bn_bwd_acc4(p.bn, base + 4, o[a][4], o[a][5], o[a][6], o[a][7], mean, invstd, sc, sh, s1[j], s2[j]);
-        bn_bwd_acc4(p.bn, base + W, o[a][8], o[a][9], o[a][10], o[a][11], mean, invstd, sc, sh, s1[j], s2[j]);
-        bn_bwd_acc4(p.bn, base + W + 4, o[a][12], o[a][13], o[a][14], o[a][15], mean, invstd, sc, sh, s1[j], s2[j]);
+        if constexpr (PRE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            bn_bwd_acc4v(p.bn, ypre[a * 4 + r], mpre[a * 4 + r], o[a][4 * r], o[a][4 * r + 1], o[a][4 * r + 2], o[a][4 * r + 3], mean,
+                         invstd, sc, sh, ba);
+        } else {
+          bn_bwd_acc4(p.bn, base, o[a][0], o[a][1], o[a][2], o[a][3], mean, invstd, sc, sh, ba);
+          bn_bwd_acc4(p.bn, base + 4, o[a][4], o[a][5], o[a][6], o[a][7], mean, invstd, sc, sh, ba);
+          bn_bwd_acc4(p.bn, base + W, o[a][8], o[a][9], o[a][10], o[a][11], mean, invstd, sc, sh, ba);
+          bn_bwd_acc4(p.bn, base + W + 4, o[a][12], o[a][13], o[a][14], o[a][15], mean, invstd, sc, sh, ba);
+        }
       }
+      bn_bwd_fold(ba, s1[j], s2[j]);
     }
     bn_bwd_store<NT, CO_T>(p.bn, s1, s2, in_t, co0, p.Co, tile_id, nb);
     return;
@@ -744,6 +766,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   };
 
   issue(0, 0);
+  // data-gradient launches with the BatchNorm-backward statistics epilogue: its y / keep-mask reads are issued HERE, a whole
+  // channel loop ahead of their use (this kernel has the 40 registers; the epilogue would otherwise sit out their latency)
+  float4 ypre[8];
+  uint32_t mpre[8];
+  const bool bn_epi = p.bn.part != nullptr;
+  if (bn_epi) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t idx = wino2_out_index<C, NT>(p, n, co0, y0, x0, q);
+      ypre[q] = *reinterpret_cast<const float4*>(p.bn.y + idx);
+      mpre[q] = p.bn.emask ? *reinterpret_cast<const uint32_t*>(p.bn.emask + idx) : 0u;
+    }
+  }
   v4f acc[16][2];   // [xi][m * NT + j]; first written by the first chunk's MFMAs
   int poff[MTW];
 #pragma unroll
@@ -810,7 +845,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   };
   chunk(0, 0, std::true_type{});
   for (int c0 = KC, bsel = 1; c0 < Ci; c0 += KC, bsel ^= 1) chunk(c0, bsel, std::false_type{});
-  wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
+  if (bn_epi) wino2_epilogue<C, TH, TW, NT, true>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
+  else wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
 }
 
 // ------------------------------------------------------------------------------------------------ filter transform
