@@ -24,9 +24,10 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$O/pmc_fetch" 
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/$O/pmc_write" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --serial-decoders --no-prof > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d "$R/$O/pmc_sq1" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --serial-decoders --no-prof > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$R/$O/pmc_sq2" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --serial-decoders --no-prof > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d "$R/$O/pmc_sq3" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --serial-decoders --no-prof > /dev/null 2>&1
 cd "$R"; rm -f "$O"/prof_*/*/*kernel_trace.csv
 python tools/pmc_traffic.py "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_traffic.json" > /dev/null 2>&1; rm -rf "$O/pmc_fetch" "$O/pmc_write"
-python tools/pmc_mfma.py "$O/pmc_sq1" "$O/pmc_sq2" > "$O/pmc_sq.md" 2>/dev/null; rm -rf "$O/pmc_sq1" "$O/pmc_sq2"
+python tools/pmc_mfma.py "$O/pmc_sq1" "$O/pmc_sq2" "$O/pmc_sq3" > "$O/pmc_sq.md" 2>/dev/null; rm -rf "$O/pmc_sq1" "$O/pmc_sq2" "$O/pmc_sq3"
 tail -3 "$O/pytest_gpu.log"; cat "$O/smoke.log"
 for f in default pce ours crf_r2 mt unet_pce forcedp serial; do python - "$O/bench_$f.json" "$f" <<'PY'
 import json, sys
