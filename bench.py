@@ -266,7 +266,7 @@ def main():
             tdoc = json.loads(raw)
             tj = tdoc["kernels"]
             keys = ("conv_wino2_kernel", "conv_wino_kernel") if name.startswith("conv_wino") else \
-                   ("conv_mfma2l_kernel", "conv_mfma2_kernel") if name.startswith("conv") else \
+                   ("conv_mfma2l_kernel", "conv_mfma2_kernel", "conv_nk16_kernel") if name.startswith("conv") else \
                    ("wgrad_wino_kernel",)
             nl = sum(tj[k]["launches_sampled"] for k in keys if k in tj)
             return {"hbm_bytes_per_launch": sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["launches_sampled"] for k in keys if k in tj) / nl,

@@ -139,7 +139,7 @@ FUSED_CASES = [
     (1, 8, 64, 16, 16, 3, False, 1),     # conv_wino2r 8 x 64 tiles (the 16-channel layers at full width)
     (2, 16, 16, 64, 32, 3, True, 1),     # conv_wino2r 16 x 16 tiles
     (2, 16, 32, 64, 32, 1, False, 1),    # direct lean kernel, 1x1 (decoder conv1x1 data gradient), 32-channel block
-    (1, 16, 64, 4, 16, 3, False, 1),     # generic direct kernel (classifier data gradient 4 -> 16)
+    (1, 16, 64, 4, 16, 3, False, 1),     # narrow-K kernel (classifier data gradient 4 -> 16)
     (2, 16, 32, 32, 64, 1, False, 2),    # 64 output channels: a 64-channel block (64 accumulators) has no epilogue -> the caller
                                          # falls back; on a 256-CU device the plan shrinks the block to 32 -> fused (2 = either)
     (2, 8, 32, 16, 16, 3, True, 0),      # first Winograd form (16-channel block below width 64): no epilogue

@@ -10,7 +10,7 @@ d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 r = d["roofline"]
 # rocprofv3 kernel names that bench.py's event families cover (the small first-conv / classifier kernels ride in the conv
 # and weight-gradient families of the library's event bracketing)
-NAMES = {"conv_mfma2l_kernel": ("conv_mfma2l_kernel", "conv_mfma2_kernel", "conv_cls_kernel"),
+NAMES = {"conv_mfma2l_kernel": ("conv_mfma2l_kernel", "conv_mfma2_kernel", "conv_cls_kernel", "conv_nk16_kernel"),
          "conv_wino2_kernel": ("conv_wino2_kernel", "conv_wino2r_kernel", "conv_wino_kernel"),
          "wgrad_wino_kernel": ("wgrad_wino_kernel",),
          "wgrad_direct_kernels": ("wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel", "wgrad_small_kernel"),

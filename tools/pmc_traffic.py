@@ -22,7 +22,7 @@ def per_kernel(d, counter):
         k = r["Kernel_Name"]
         k = k.replace("conv_wino2r_kernel", "conv_wino2_kernel")   # the raw-source (LDS-DMA) variant rides in the same family
         fam = next((f for f in ("conv_wino2_kernel", "wgrad_wino_kernel", "conv_wino_kernel", "conv_mfma2l_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel",
-                                "conv_mfma2_kernel", "wgrad_mfma2_kernel") if f in k), None)
+                                "conv_mfma2_kernel", "conv_nk16_kernel", "wgrad_mfma2_kernel") if f in k), None)
         if fam is None:
             continue
         key = (r["Dispatch_Id"], fam)

@@ -557,6 +557,9 @@ int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs
                        int H, int W, int nsplit, void* stream);
 bool conv_cls_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_bs, int H, int W, int Co, int ks,
                        const float* stat_part);                                              // wsl_conv4.hip
+bool conv_nk16_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_bs, int H, int W, int Co, int ks, int th, int tw);
+int conv_nk16_launch(const WslSrc& a, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H, int W, bool dgrad,
+                     float* stat_part, float* stat_cnt, int slots, const BnBwdEpi* bn, int* bn_done, void* stream);
 int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H, int W,
                     void* stream);
 int wino_pack(const float* w, float* u, int Co, int Ci, int dgrad, void* stream);   // wsl_conv5.hip
@@ -659,6 +662,10 @@ static int conv2d_fwd_impl(const WslSrc* a, const WslSrc* b, const float* w, con
       WSL_REQUIRE(f.wino && !conv3_enabled(), "conv2d_fwd: wmode %d needs wsl_conv2d_wino_ok() != 0 for this layer", wmode);
       return wino_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, wmode == 5, stat_part, stat_cnt, p.slots, stream, bn, bn_done);
     }
+    static const bool nk_on = (WSL_TUNE("WSL_CONV_NK16", 1) != 0);
+    if (nk_on && !conv3_enabled() && conv_nk16_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, f.th, f.tw))
+      return conv_nk16_launch(p.in.a, w, bias, y, y_bs, N, H, W, wmode == 3, stat_part, stat_cnt, p.slots, bn, bn_done,
+                              stream);   // first conv forward / classifier data gradient (wsl_conv4.hip)
     static const bool cls_on = (WSL_TUNE("WSL_CONV_CLS", 1) != 0);
     if (cls_on && wmode == 2 && conv_cls_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, stat_part))
       return conv_cls_launch(p.in.a, w, bias, y, y_bs, N, H, W, stream);   // 4-class classifier (wsl_conv4.hip)

@@ -394,6 +394,201 @@ int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* 
   return check_launch("conv_cls_kernel");
 }
 
+// ================================================================================================ narrow-K convolution
+// The first convolution (1 -> 16, forward) and the 4-class classifiers' data gradient (4 -> 16): 3x3, 16 output channels, so few
+// reduction elements (9 resp. 36) that the generic kernel's 8-channel chunks, bounds tests and staging dominate -- these launches
+// are HBM-side (one 16-channel full-resolution tensor written).  Here the whole reduction is ONE pass of v_mfma_f32_16x16x4_f32
+// operands: K = the 4 input channels of one tap (9 MFMAs per 16 pixels x 16 channels), or -- single input channel -- K = 4 taps
+// (3 MFMAs, the last group padded with zero weights).  A operand = one 4-byte LDS read of the staged halo tile per MFMA, B
+// operands = 9 / 3 registers loaded once from the packed [tap][ci][co] image the generic kernel uses.  Persistent workgroups
+// over 8 x 64-pixel tiles (the same tiles and statistics slots as the generic plan), next tile's rows prefetched into registers.
+// Epilogue as the other conv kernels: bias + BatchNorm partials (forward), or the BatchNorm-backward statistics (data gradient).
+struct NkP {
+  const float* x;
+  int64_t x_bs;
+  const float* wp;   // packed [9][CI][16]
+  const float* bias;
+  float* y;
+  int64_t y_bs;
+  int N, H, W, tiles_x, tiles_y, items;
+  float* stat_part;
+  float* stat_cnt;
+  int slots;
+  BnBwdEpi bn;
+};
+
+template <int CI>
+struct NkCfg {
+  static constexpr int TH = 8, TW = 64, PADL = 4, ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4;
+  static constexpr int PLANE = ((ROWS * ROWP - 16 + 31) / 32) * 32 + 16;   // == 16 (mod 32): the four channel planes of a read hit distinct banks
+  static constexpr int NG = CI == 4 ? 9 : 3;                               // MFMAs per 16 pixels
+  static constexpr size_t SMEM = sizeof(float) * (CI * PLANE + 8 * 16);
+  static_assert(POS <= 256 && (CI == 1 || CI == 4), "one float4 position per thread");
+};
+
+template <int CI>
+__global__ __launch_bounds__(256, 3) void conv_nk16_kernel(NkP p) {
+  using C = NkCfg<CI>;
+  WSL_DYN_SMEM(smem);
+  float* in_t = reinterpret_cast<float*>(smem);
+  float* red = in_t + CI * C::PLANE;   // 128 floats of reduction scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, W = p.W, HW = H * W;
+  const int c16 = lane & 15, k4 = lane >> 4;
+
+  // B operands: lane (j = c16, k = k4).  CI == 4: group g = tap, k = input channel.  CI == 1: tap = 4 g + k (zero past 8)
+  float bw[C::NG];
+  int aoff[C::NG];   // LDS offset of this lane's A element relative to (row, pixel) of the output
+#pragma unroll
+  for (int g = 0; g < C::NG; ++g) {
+    if (CI == 4) {
+      bw[g] = p.wp[(g * 4 + k4) * 16 + c16];
+      aoff[g] = k4 * C::PLANE + (g / 3) * C::ROWP + (g % 3);
+    } else {
+      const int tap = 4 * g + k4;
+      bw[g] = tap < 9 ? p.wp[tap * 16 + c16] : 0.f;
+      aoff[g] = tap < 9 ? (tap / 3) * C::ROWP + (tap % 3) : 0;
+    }
+  }
+  const float bias = p.bias ? p.bias[c16] : 0.f;
+
+  const int pty = tid / C::ROWP4, ptx4 = tid - pty * C::ROWP4;
+  const bool owner = tid < C::POS;
+  const int loff = pty * C::ROWP + ptx4 * 4;
+  const int it0 = (int)((int64_t)blockIdx.x * p.items / gridDim.x), it1 = (int)((int64_t)(blockIdx.x + 1) * p.items / gridDim.x);
+  float4 pre[CI];
+  bool pok = false;
+  auto tile_of = [&](int item, int& n, int& y0, int& x0) {
+    int q = item;
+    const int tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    const int ty = q % p.tiles_y;
+    n = q / p.tiles_y, y0 = ty * C::TH, x0 = tx * C::TW;
+  };
+  auto issue = [&](int item) __attribute__((always_inline)) {
+    int n, y0, x0;
+    tile_of(item, n, y0, x0);
+    const int gy = y0 + pty - 1, gx = x0 + ptx4 * 4 - C::PADL;
+    pok = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const uint32_t off = pok ? (uint32_t)(gy * W + gx) : 0u;
+    const float* xb = p.x + n * p.x_bs;
+#pragma unroll
+    for (int i = 0; i < CI; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + (int64_t)i * HW + off);
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+    if (owner) {
+#pragma unroll
+      for (int i = 0; i < CI; ++i)
+        *reinterpret_cast<float4*>(in_t + i * C::PLANE + loff) = pok ? pre[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  if (it0 < it1) issue(it0);
+  for (int item = it0; item < it1; ++item) {
+    commit();
+    __syncthreads();
+    if (item + 1 < it1) issue(item + 1);
+    int n, y0, x0;
+    tile_of(item, n, y0, x0);
+    // this wave: rows 2 * wave, 2 * wave + 1; 4 segments of 16 pixels each; lane (c16, k4) holds pixels 4 k4 .. 4 k4 + 3 of channel c16
+    v4f acc[8];
+#pragma unroll
+    for (int sg = 0; sg < 8; ++sg) {
+      acc[sg] = v4f{bias, bias, bias, bias};
+      const float* ab = in_t + (wave * 2 + (sg >> 2)) * C::ROWP + (C::PADL - 1) + 16 * (sg & 3) + c16;
+#pragma unroll
+      for (int g = 0; g < C::NG; ++g) acc[sg] = WSL_MFMA16(ab[aoff[g]], bw[g], acc[sg]);
+    }
+    // (staging the result through LDS so that every store instruction writes four 256-byte row segments instead of sixteen
+    //  64-byte pieces was measured SLOWER: 92.5 vs 75.8 us forward, 132.9 vs 115.7 data gradient)
+    float* yb = p.y + n * p.y_bs + (int64_t)c16 * HW + (int64_t)(y0 + wave * 2) * W + x0 + 4 * k4;
+#pragma unroll
+    for (int sg = 0; sg < 8; ++sg)
+      *reinterpret_cast<float4*>(yb + (sg >> 2) * W + 16 * (sg & 3)) = make_float4(acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3]);
+
+    if (p.bn.part) {   // data gradient: BatchNorm-backward statistics of the layer that consumes it
+      const float mean = p.bn.st[c16], invstd = p.bn.st[16 + c16], sc = p.bn.st[32 + c16], sh = p.bn.st[48 + c16];
+      const int64_t base = ((int64_t)n * 16 + c16) * HW + (int64_t)(y0 + wave * 2) * W + x0 + 4 * k4;
+      BnBwdAcc ba;
+#pragma unroll
+      for (int sg = 0; sg < 8; ++sg)
+        bn_bwd_acc4(p.bn, base + (sg >> 2) * W + 16 * (sg & 3), acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3], mean, invstd, sc,
+                    sh, ba);
+      float s1[1], s2[1];
+      bn_bwd_fold(ba, s1[0], s2[0]);
+      bn_bwd_store<1, 16>(p.bn, s1, s2, red, 0, 16, item, p.items);
+    } else if (p.stat_part) {   // forward: per-tile (sum, M2) per channel for the BatchNorm that follows
+      constexpr float cnt = (float)(C::TH * C::TW);
+      float* red1 = red;
+      float* red2 = red + 64;
+      float bs = 0.f;
+#pragma unroll
+      for (int sg = 0; sg < 8; ++sg) bs += (acc[sg][0] + acc[sg][1]) + (acc[sg][2] + acc[sg][3]);
+      bs += __shfl_xor(bs, 16);
+      bs += __shfl_xor(bs, 32);
+      if (lane < 16) red1[wave * 16 + lane] = bs;
+      __syncthreads();
+      const float mean_b = (red1[c16] + red1[16 + c16] + red1[32 + c16] + red1[48 + c16]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int sg = 0; sg < 8; ++sg)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = acc[sg][e] - mean_b;
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) red2[wave * 16 + lane] = q;
+      __syncthreads();
+      if (wave == 0 && lane < 16) {
+        float* dst = p.stat_part + ((int64_t)lane * ((int64_t)p.items * p.slots) + (int64_t)item * p.slots) * 2;   // [Co][slots][2]
+        dst[0] = red1[lane] + red1[16 + lane] + red1[32 + lane] + red1[48 + lane];
+        dst[1] = red2[lane] + red2[16 + lane] + red2[32 + lane] + red2[48 + lane];
+        if (lane < p.slots) p.stat_cnt[item * p.slots + lane] = lane == 0 ? cnt : 0.f;
+      }
+    }
+    __syncthreads();   // the tile and the scratch are free for the next item
+  }
+}
+
+// 3x3, Ci in {1, 4} -> 16 channels, one plain source, the generic plan's 8 x 64 tiles, aligned planes
+bool conv_nk16_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_t y_bs, int H, int W, int Co, int ks, int th, int tw) {
+  if (ks != 3 || Co != 16 || (a.C != 1 && a.C != 4) || (b && b->C > 0) || a.scale || a.emask || a.cmask) return false;
+  if (th != 8 || tw != 64 || (H % 8) || (W % 64) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.bs & 3)) return false;
+  return (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_bs & 3) == 0 && (int64_t)16 * H * W < (int64_t(1) << 31);
+}
+
+template <int CI>
+static int launch_nk16(NkP& p, bool dgrad, void* stream) {
+  using C = NkCfg<CI>;
+  auto kern = conv_nk16_kernel<CI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  int wgs = 3 * device_cu_count();
+  if (wgs > p.items) wgs = p.items;
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(dgrad ? PF_CONV_DGRAD : PF_CONV_FWD, 2.0 * px * CI * 16 * 9, 4.0 * px * (16 + CI), stream);
+  WSL_LAUNCH(kern, dim3(wgs), dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_nk16_kernel");
+}
+
+int conv_nk16_launch(const WslSrc& a, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H, int W, bool dgrad,
+                     float* stat_part, float* stat_cnt, int slots, const BnBwdEpi* bn, int* bn_done, void* stream) {
+  NkP p;
+  p.x = a.x, p.x_bs = a.bs, p.wp = wp, p.bias = bias, p.y = y, p.y_bs = y_bs;
+  p.N = N, p.H = H, p.W = W, p.tiles_x = W / 64, p.tiles_y = H / 8, p.items = N * p.tiles_x * p.tiles_y;
+  p.stat_part = stat_part, p.stat_cnt = stat_cnt, p.slots = slots;
+  const bool bn_ok = bn && bn->part;
+  if (bn_ok) p.bn = *bn;
+  if (bn_done) *bn_done = bn_ok ? 1 : 0;
+  return a.C == 4 ? launch_nk16<4>(p, dgrad, stream) : launch_nk16<1>(p, dgrad, stream);
+}
+
 // ---- machine probes (EXPERIMENTS build only; tools/mfma_ceiling.py, tools/probe_lds_dma.py, tools/probe_mfma4.py)
 #ifdef WSL_EXPERIMENTS
 // Pure MFMA stream (no memory): the practical f32 matrix ceiling of the machine at its sustained clock, per MFMA shape.

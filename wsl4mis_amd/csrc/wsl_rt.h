@@ -122,8 +122,9 @@ __device__ __forceinline__ void xform_mask(wsl_v2f& lo, wsl_v2f& hi, uint32_t m,
 //   sd(q)     = (q.x + q.y, q.x - q.y)   [op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]]       (tools/probe_pk.py checks both)
 // The compiler has no pattern for these forms, so they are inline assembly -- and the hazard recogniser does not look
 // inside inline assembly: a vector write needs two wait states before an MFMA reads it as A / B operand, and an MFMA result
-// needs far more before a vector instruction may read it.  Hence (1) every transform is ONE asm block that ends in
-// `s_nop 1`, so whatever follows is safe, and (2) the blocks only ever read registers loaded from LDS -- transforms of MFMA
+// needs far more before a vector instruction may read it (a first per-instruction version left ONE wait state between a
+// packed add and the MFMA reading it and accumulated stale operands).  Hence (1) every transform is ONE asm block that ends
+// in `s_nop 3` (four wait states: twice what was measured sufficient), so whatever follows is safe, and (2) the blocks only ever read registers loaded from LDS -- transforms of MFMA
 // results (the output transforms) stay in C++, where the compiler sees the instructions and pads them itself.
 #define WSL_PK_SUB " neg_lo:[0,1] neg_hi:[0,1]\n"
 #define WSL_PK_MID " op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n"
@@ -155,7 +156,7 @@ __device__ __forceinline__ void wino_btdb_pk(const wsl_v2f (&lo)[4], const wsl_v
       "v_pk_add_f32 %1, %1, %9" WSL_PK_SUB
       "v_pk_add_f32 %2, %2, %10" WSL_PK_SUB
       "v_pk_add_f32 %3, %3, %11" WSL_PK_SUB
-      "s_nop 1"
+      "s_nop 3"
       : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(t0),
         "=&v"(t1), "=&v"(t2), "=&v"(t3)
       : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
@@ -178,7 +179,7 @@ __device__ __forceinline__ void wino_aya_pk(wsl_v2f r0, wsl_v2f r1, wsl_v2f& q1,
       "v_pk_add_f32 %5, %7, %7" WSL_PK_SD
       "v_pk_add_f32 %3, %0, %0" WSL_PK_SD
       "v_pk_add_f32 %4, %1, %1" WSL_PK_SD
-      "s_nop 1"
+      "s_nop 3"
       : "=&v"(q1), "=&v"(q2), "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3])
       : "v"(r0), "v"(r1));
 #endif
