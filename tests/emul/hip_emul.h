@@ -115,6 +115,15 @@ static inline T wsl_emu_shfl(T v, int src_lane) {
   wsl_emu::wave_sync();
   return wsl_emu_unbits<T>(w.xa[buf][src_lane & 63]);
 }
+// 64-bit values travel as two 32-bit shuffles (what the device runtime does)
+static inline double wsl_emu_shfl(double v, int src_lane) {
+  uint64_t u;
+  memcpy(&u, &v, 8);
+  const uint32_t lo = wsl_emu_shfl<uint32_t>((uint32_t)u, src_lane), hi = wsl_emu_shfl<uint32_t>((uint32_t)(u >> 32), src_lane);
+  u = ((uint64_t)hi << 32) | lo;
+  memcpy(&v, &u, 8);
+  return v;
+}
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int = 64) { return wsl_emu_shfl(v, wsl_emu::lane() ^ mask); }
 template <typename T>

@@ -27,34 +27,38 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, con
                                                           float momentum, float* rmean, float* rvar, int64_t* nbt,
                                                           float* mean_o, float* invstd_o, float* scale_o,
                                                           float* shift_o) {
-  __shared__ double red[kThreads];
+  __shared__ double red[3 * 4];
   const int c = blockIdx.x;
-  // (loads are unconditional and the empty-slot test is a select: a branch on cnt[b] serialised one memory round trip per
-  //  iteration -- 36 us for the 8192 partials of a level-0 layer)
-  double n = 0, s = 0;
+  // ONE pass: n = sum of counts, s = sum of block sums, q = sum of (M2_b + sum_b^2 / n_b); then M2 = q - s^2 / n, the same
+  // Chan merge sum of [M2_b + n_b (mean_b - mean)^2] with the square expanded -- in fp64 the cancellation costs nothing here
+  // (q / M2 = 1 + mean^2 / var).  (Loads are unconditional and the empty-slot test is a select: a branch on cnt[b]
+  // serialised one memory round trip per iteration.)
+  double n = 0, s = 0, q = 0;
   const float* pc = part + (int64_t)c * nblk * 2;
 #pragma unroll 8
   for (int b = threadIdx.x; b < nblk; b += kThreads) {
     const float cb = cnt[b];
     const float2 v = *reinterpret_cast<const float2*>(pc + 2 * (int64_t)b);
     const bool live = cb > 0.f;   // empty slots (count 0) carry no data
+    const double nbk = live ? (double)cb : 1.0;
     n += live ? (double)cb : 0.0;
     s += live ? (double)v.x : 0.0;
+    q += live ? (double)v.y + (double)v.x * (double)v.x / nbk : 0.0;
   }
-  n = block_sum_d(n, red);
-  s = block_sum_d(s, red);
+  // fixed-order merge: lanes (xor butterfly), then the four waves
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m), s += __shfl_xor(s, m), q += __shfl_xor(q, m);
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    red[w] = n, red[4 + w] = s, red[8 + w] = q;
+  }
+  __syncthreads();
+  n = (red[0] + red[1]) + (red[2] + red[3]);
+  s = (red[4] + red[5]) + (red[6] + red[7]);
+  q = (red[8] + red[9]) + (red[10] + red[11]);
   const double mean = s / n;
-  double m2 = 0;
-#pragma unroll 8
-  for (int b = threadIdx.x; b < nblk; b += kThreads) {
-    const float cb = cnt[b];
-    const float2 v = *reinterpret_cast<const float2*>(pc + 2 * (int64_t)b);
-    const bool live = cb > 0.f;
-    const double nbk = live ? (double)cb : 1.0;
-    const double d = (double)v.x / nbk - mean;
-    m2 += live ? (double)v.y + nbk * d * d : 0.0;
-  }
-  m2 = block_sum_d(m2, red);
+  double m2 = q - s * s / n;
+  if (m2 < 0.0) m2 = 0.0;
   if (threadIdx.x == 0) {
     const double var = m2 / n;  // biased (normalisation)
     const float meanf = (float)mean;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const f
 // the convolution epilogues)
 __global__ __launch_bounds__(256) void bnact_bwd_finalize_kernel(const float* part, int nblk, int C, int64_t sb, int64_t sc,
                                                                  double count, float* dgamma, float* dbeta, float* coef) {
-  __shared__ double red[kThreads];
+  __shared__ double red[2 * 4];
   const int c = blockIdx.x;
   double s1 = 0, s2 = 0;
 #pragma unroll 4
@@ -374,8 +378,13 @@ __global__ __launch_bounds__(256) void bnact_bwd_finalize_kernel(const float* pa
     s1 += v.x;
     s2 += v.y;
   }
-  s1 = block_sum_d(s1, red);
-  s2 = block_sum_d(s2, red);
+  // fixed-order merge: lanes (xor butterfly), then the four waves
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m), s2 += __shfl_xor(s2, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s1, red[4 + (threadIdx.x >> 6)] = s2;
+  __syncthreads();
+  s1 = (red[0] + red[1]) + (red[2] + red[3]);
+  s2 = (red[4] + red[5]) + (red[6] + red[7]);
   if (threadIdx.x == 0) {
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
