@@ -9,17 +9,6 @@ namespace wsl {
 
 constexpr int kChunk = 4096;  // elements of one (n, c) plane handled by one workgroup
 
-__device__ __forceinline__ double block_sum_d(double v, double* red) {
-  __syncthreads();
-  red[threadIdx.x] = v;
-  __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  return red[0];
-}
-
 // ------------------------------------------------------------------------------------------------ BN forward stats
 // One workgroup per channel: Chan-merge the conv epilogue's per-block (sum, M2, count) partials in fp64.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, const float* cnt, int nblk, int C,
