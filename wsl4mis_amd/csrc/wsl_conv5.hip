@@ -135,7 +135,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
       const bool ina = c0 < p.a.C;
       const bool has_scale = (ina ? p.a.scale : p.b.scale) != nullptr;
       const bool has_mask = (ina ? p.a.emask : p.b.emask) != nullptr;
-      const bool has_cm = (ina ? p.a.cmask : p.b.cmask) != nullptr;
       const float es = ina ? p.a.es : p.b.es;
       // all table reads of the chunk up front (one LDS round trip instead of one per load: only two waves per SIMD hide it)
       float2 tb[C::NLD];
@@ -576,7 +575,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
       const bool ina = c0 < p.a.C;
       const bool has_scale = (ina ? p.a.scale : p.b.scale) != nullptr;
       const bool has_mask = (ina ? p.a.emask : p.b.emask) != nullptr;
-      const bool has_cm = (ina ? p.a.cmask : p.b.cmask) != nullptr;
       const float es = ina ? p.a.es : p.b.es;
       float2 tb[C::NLD];
       float cmv[C::NLD];
