@@ -706,7 +706,9 @@ struct Wino2RCfg : Wino2Cfg<TH, TW, NT> {
   static_assert(PLANE == 4 * B::POS && 8 * B::CO_T <= IN_FLOATS, "lane-contiguous tile layout");
 };
 
-template <int TH, int TW, int NT>
+// (ABL: compile-time phase ablations of the experiments build, env WSL_WINO2R_ABLATE -- 1 no MFMAs, 2 no DMA after the first
+//  chunk, 4 no epilogue, 8 no input-patch reads from LDS after the first chunk; wrong results by design; tools/abl_wino2r.sh)
+template <int TH, int TW, int NT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   using C = Wino2RCfg<TH, TW, NT>;
   constexpr int KC = C::KC, CO_T = C::CO_T, MTW = C::MTW;
@@ -791,7 +793,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   // one chunk; FIRST: the accumulators start from the MFMA's zero C operand (no 128-register clear)
   auto chunk = [&](int c0, int bsel, auto first_tag) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    if (c0 + KC < Ci) issue(c0 + KC, bsel ^ 1);   // the next chunk streams into the other buffers during this one's compute
+    if constexpr ((ABL & 2) == 0) {
+      if (c0 + KC < Ci) issue(c0 + KC, bsel ^ 1);   // the next chunk streams into the other buffers during this one's compute
+    }
     const float* in_t = in_b + bsel * C::IN_FLOATS;
     const float* w_t = w_b + bsel * C::W_FLOATS;
     wsl_v2f rlo[MTW][4], rhi[MTW][4];   // the 4 x 4 patches, one row per pair of register pairs
@@ -804,13 +808,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
           rlo[m][i] = wsl_v2f{r[0], r[1]}, rhi[m][i] = wsl_v2f{r[2], r[3]};
         }
     };
-    fetch(0);
+    if constexpr ((ABL & 8) == 0 || FIRST) {
+      fetch(0);
+    } else {   // (ablation: patch values that are not compile-time constants, no LDS read)
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rlo[m][i] = wsl_v2f{(float)lane, (float)i}, rhi[m][i] = wsl_v2f{(float)wave, (float)lane};
+    }
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
       wsl_v2f va[MTW][4], vb[MTW][4];   // V[4 i + {0, 3}] = va[i], V[4 i + {1, 2}] = vb[i]: 16 packed adds (wsl_rt.h)
 #pragma unroll
       for (int m = 0; m < MTW; ++m) wino_btdb_pk(rlo[m], rhi[m], va[m], vb[m]);
-      if (kg == 0) fetch(1);
+      if constexpr ((ABL & 8) == 0) {
+        if (kg == 0) fetch(1);
+      }
       constexpr int BD = NT == 2 ? 4 : 2, BR = BD + 1;
       float bv[BR][NT];
       auto loadb = [&](int xi, int buf) __attribute__((always_inline)) {
@@ -833,7 +846,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
           for (int j = 0; j < NT; ++j) {
             const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
             const v4f cin = (FIRST && kg == 0) ? zero4 : acc[xi][m * NT + j];
-            acc[xi][m * NT + j] = WSL_MFMA16(wino_pick(va[m], vb[m], xi), bv[xi % BR][j], cin);
+            if constexpr ((ABL & 1) != 0) acc[xi][m * NT + j][0] = cin[0] + wino_pick(va[m], vb[m], xi) * bv[xi % BR][j];
+            else acc[xi][m * NT + j] = WSL_MFMA16(wino_pick(va[m], vb[m], xi), bv[xi % BR][j], cin);
           }
         WSL_SCHED_BARRIER();
       }
@@ -843,6 +857,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   };
   chunk(0, 0, std::true_type{});
   for (int c0 = KC, bsel = 1; c0 < Ci; c0 += KC, bsel ^= 1) chunk(c0, bsel, std::false_type{});
+  if constexpr ((ABL & 4) != 0) {
+    float t = 0.f;   // (keeps every accumulator alive)
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) t += (acc[xi][a][0] + acc[xi][a][1]) + (acc[xi][a][2] + acc[xi][a][3]);
+    if (t == 123.456f) p.y[0] = t;
+    return;
+  }
   if (bn_epi) wino2_epilogue<C, TH, TW, NT, true>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
   else wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
 }
@@ -956,6 +979,18 @@ template <int TH, int TW, int NT>
 static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
   using C = Wino2RCfg<TH, TW, NT>;
   auto kern = conv_wino2r_kernel<TH, TW, NT>;
+#ifdef WSL_EXPERIMENTS
+  {
+    static const int abl = WSL_TUNE("WSL_WINO2R_ABLATE", 0);
+    if (abl == 1) kern = conv_wino2r_kernel<TH, TW, NT, 1>;
+    if (abl == 2) kern = conv_wino2r_kernel<TH, TW, NT, 2>;
+    if (abl == 4) kern = conv_wino2r_kernel<TH, TW, NT, 4>;
+    if (abl == 6) kern = conv_wino2r_kernel<TH, TW, NT, 6>;     // channel loop only, no memory traffic
+    if (abl == 7) kern = conv_wino2r_kernel<TH, TW, NT, 7>;     // ... without MFMAs
+    if (abl == 14) kern = conv_wino2r_kernel<TH, TW, NT, 14>;   // ... without operand reads (transforms + MFMAs)
+    if (abl == 3) kern = conv_wino2r_kernel<TH, TW, NT, 3>;
+  }
+#endif
   static bool attr_done = false;
   if (!attr_done) {
     (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
