@@ -142,7 +142,7 @@ FUSED_CASES = [
     (1, 16, 64, 4, 16, 3, False, 1),     # narrow-K kernel (classifier data gradient 4 -> 16)
     (2, 16, 32, 32, 64, 1, False, 2),    # 64 output channels: a 64-channel block (64 accumulators) has no epilogue -> the caller
                                          # falls back; on a 256-CU device the plan shrinks the block to 32 -> fused (2 = either)
-    (2, 8, 32, 16, 16, 3, True, 0),      # first Winograd form (16-channel block below width 64): no epilogue
+    (2, 8, 32, 16, 16, 3, True, 1),      # conv_wino2r 8 x 32 tiles x 16 channels (16-channel block below width 64)
     (1, 6, 10, 8, 8, 3, False, 0),       # odd shape, raw weights: no epilogue
 ]
 

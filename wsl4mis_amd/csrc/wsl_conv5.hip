@@ -368,7 +368,9 @@ struct Wino2Cfg {
   static constexpr int WF4 = W_FLOATS / 4, NWL = WF4 / 256;
   static constexpr int MAXC = 256;
   static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + W_FLOATS + 3 * MAXC);
-  static_assert(TILES % 64 == 0 && NA == 2 && POS <= 256 && KC % G == 0 && WF4 % 256 == 0 && TTX % 4 == 0, "tile shape");
+  static_assert(TILES % 64 == 0 && (NA == 1 || NA == 2) && POS <= 256 && KC % G == 0 && WF4 % 256 == 0 && TTX % 4 == 0, "tile shape");
+  // resident workgroups per CU the register allocator leaves room for: 64 accumulator registers (NA == 1) fit three
+  static constexpr int MINW = NA == 1 ? 3 : 2;
   static_assert(8 * CO_T <= IN_FLOATS && (TTX % 16 == 0 || MTW == 1), "reduction scratch / row groups");
 };
 
@@ -387,14 +389,14 @@ __device__ __forceinline__ int64_t wino2_out_index(const WinoP& p, int n, int co
 
 // PRE: the caller has the BatchNorm-backward epilogue's y / keep-mask values in registers (loaded before its channel loop)
 template <typename C, int TH, int TW, int NT, bool PRE = false>
-__device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2], float* scratch, int n, int co0, int y0, int x0,
+__device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C::NA], float* scratch, int n, int co0, int y0, int x0,
                                                int tile_id, int nb, int cby, const float4* ypre = nullptr,
                                                const uint32_t* mpre = nullptr) {
   constexpr int CO_T = C::CO_T, MTW = C::MTW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = p.W, HW = p.H * p.W;
   float* in_t = scratch;
-  float o[2][16];
+  float o[C::NA][16];
   float bsum[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
@@ -510,7 +512,7 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][2]
 }
 
 template <int TH, int TW, int NT>
-__global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
+__global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2_kernel(WinoP p) {
   using C = Wino2Cfg<TH, TW, NT>;
   constexpr int KC = C::KC, CO_T = C::CO_T, MTW = C::MTW;
   WSL_DYN_SMEM(smem);
@@ -607,9 +609,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p) {
       *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  v4f acc[16][2];   // [xi][m * NT + j]
+  v4f acc[16][C::NA];   // [xi][m * NT + j]
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i][0] = v4f{0.f, 0.f, 0.f, 0.f}, acc[i][1] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int a = 0; a < C::NA; ++a) acc[i][a] = v4f{0.f, 0.f, 0.f, 0.f};
   // this lane's A-operand slots: tile (wave * MTW + m) * 16 + (lane & 15), channel (lane >> 4) of a group of four
   int poff[MTW];
 #pragma unroll
@@ -709,7 +713,7 @@ struct Wino2RCfg : Wino2Cfg<TH, TW, NT> {
 // (ABL: compile-time phase ablations of the experiments build, env WSL_WINO2R_ABLATE -- 1 no MFMAs, 2 no DMA after the first
 //  chunk, 4 no epilogue, 8 no input-patch reads from LDS after the first chunk; wrong results by design; tools/abl_wino2r.sh)
 template <int TH, int TW, int NT, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
+__global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r_kernel(WinoP p) {
   using C = Wino2RCfg<TH, TW, NT>;
   constexpr int KC = C::KC, CO_T = C::CO_T, MTW = C::MTW;
   WSL_DYN_SMEM(smem);
@@ -768,18 +772,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
   issue(0, 0);
   // data-gradient launches with the BatchNorm-backward statistics epilogue: its y / keep-mask reads are issued HERE, a whole
   // channel loop ahead of their use (this kernel has the 40 registers; the epilogue would otherwise sit out their latency)
-  float4 ypre[8];
-  uint32_t mpre[8];
+  float4 ypre[4 * C::NA];
+  uint32_t mpre[4 * C::NA];
   const bool bn_epi = p.bn.part != nullptr;
   if (bn_epi) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4 * C::NA; ++q) {
       const int64_t idx = wino2_out_index<C, NT>(p, n, co0, y0, x0, q);
       ypre[q] = *reinterpret_cast<const float4*>(p.bn.y + idx);
       mpre[q] = p.bn.emask ? *reinterpret_cast<const uint32_t*>(p.bn.emask + idx) : 0u;
     }
   }
-  v4f acc[16][2];   // [xi][m * NT + j]; first written by the first chunk's MFMAs
+  v4f acc[16][C::NA];   // [xi][m * NT + j]; first written by the first chunk's MFMAs
   int poff[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
@@ -862,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2r_kernel(WinoP p) {
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-      for (int a = 0; a < 2; ++a) t += (acc[xi][a][0] + acc[xi][a][1]) + (acc[xi][a][2] + acc[xi][a][3]);
+      for (int a = 0; a < C::NA; ++a) t += (acc[xi][a][0] + acc[xi][a][1]) + (acc[xi][a][2] + acc[xi][a][3]);
     if (t == 123.456f) p.y[0] = t;
     return;
   }
@@ -951,7 +955,8 @@ static WSrc to_wsrc(const WslSrc& s) { return WSrc{s.x, s.emask, s.scale, s.shif
 bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, int* tw, int* co_t) {
   if (ks != 3 || Ci % 8 || Ci > 256 || Co % (allow16 ? 16 : 32) || H <= 0 || W <= 0) return false;
   int h = 0, w = 0;
-  if (Co == 16 && W % 64 == 0 && H % 8 == 0) h = 8, w = 64;   // 16 channels: 128 tiles per workgroup (second form)
+  static const int tile16 = WSL_TUNE("WSL_WINO16_TILE", 64);   // (experiments build: 32 = 64 tiles x 16 channels per workgroup)
+  if (Co == 16 && W % 64 == 0 && H % 8 == 0 && tile16 == 64) h = 8, w = 64;   // 16 channels: 128 tiles per workgroup (second form)
   else if (W % 32 == 0 && H % 8 == 0) h = 8, w = 32;
   else if (W % 16 == 0 && H % 16 == 0) h = 16, w = 16;
   else return false;
@@ -1064,10 +1069,12 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
   p.tiles_x = W / tw, p.tiles_y = H / th;
   const int form = wino_form();   // 1: V through LDS, 2: V in registers
   // the BatchNorm-backward statistics ride in the epilogue shared by conv_wino2 / conv_wino2r (not in the first form)
-  const bool bn_ok = bn && bn->part && (tw == 64 || (form == 2 && co_t == 32));
+  const bool narrow16 = co_t == 16 && th == 8 && tw == 32;   // 64 tiles x 16 channels: one accumulator set, 3 workgroups per CU
+  const bool bn_ok = bn && bn->part && (tw == 64 || narrow16 || (form == 2 && co_t == 32));
   if (bn_ok) p.bn = *bn;
   if (bn_done) *bn_done = bn_ok ? 1 : 0;
   if (tw == 64) return launch_wino2<8, 64, 1>(p, is_dgrad, stream);
+  if (narrow16) return launch_wino2<8, 32, 1>(p, is_dgrad, stream);
   if (form == 2 && co_t == 32) {
     if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);
     return launch_wino2<16, 16, 2>(p, is_dgrad, stream);
