@@ -417,18 +417,19 @@ struct NkP {
   BnBwdEpi bn;
 };
 
-template <int CI>
+template <int CI, int TH_ = 8, int TW_ = 64>
 struct NkCfg {
-  static constexpr int TH = 8, TW = 64, PADL = 4, ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4;
+  static constexpr int TH = TH_, TW = TW_, SEGW = TW / 16;   // (TH x TW = 512 pixels: 32 segments of 16, eight per wave, row-major)
+  static constexpr int PADL = 4, ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4;
   static constexpr int PLANE = ((ROWS * ROWP - 16 + 31) / 32) * 32 + 16;   // == 16 (mod 32): the four channel planes of a read hit distinct banks
   static constexpr int NG = CI == 4 ? 9 : 3;                               // MFMAs per 16 pixels
   static constexpr size_t SMEM = sizeof(float) * (CI * PLANE + 8 * 16);
-  static_assert(POS <= 256 && (CI == 1 || CI == 4), "one float4 position per thread");
+  static_assert(POS <= 256 && (CI == 1 || CI == 4) && TH * TW == 512, "one float4 position per thread");
 };
 
-template <int CI>
+template <int CI, int TH = 8, int TW = 64>
 __global__ __launch_bounds__(256, 3) void conv_nk16_kernel(NkP p) {
-  using C = NkCfg<CI>;
+  using C = NkCfg<CI, TH, TW>;
   WSL_DYN_SMEM(smem);
   float* in_t = reinterpret_cast<float*>(smem);
   float* red = in_t + CI * C::PLANE;   // 128 floats of reduction scratch
@@ -495,24 +496,25 @@ __global__ __launch_bounds__(256, 3) void conv_nk16_kernel(NkP p) {
 #pragma unroll
     for (int sg = 0; sg < 8; ++sg) {
       acc[sg] = v4f{bias, bias, bias, bias};
-      const float* ab = in_t + (wave * 2 + (sg >> 2)) * C::ROWP + (C::PADL - 1) + 16 * (sg & 3) + c16;
+      const float* ab = in_t + ((8 * wave + sg) / C::SEGW) * C::ROWP + (C::PADL - 1) + 16 * ((8 * wave + sg) % C::SEGW) + c16;
 #pragma unroll
       for (int g = 0; g < C::NG; ++g) acc[sg] = WSL_MFMA16(ab[aoff[g]], bw[g], acc[sg]);
     }
     // (staging the result through LDS so that every store instruction writes four 256-byte row segments instead of sixteen
     //  64-byte pieces was measured SLOWER: 92.5 vs 75.8 us forward, 132.9 vs 115.7 data gradient)
-    float* yb = p.y + n * p.y_bs + (int64_t)c16 * HW + (int64_t)(y0 + wave * 2) * W + x0 + 4 * k4;
+    float* yb = p.y + n * p.y_bs + (int64_t)c16 * HW + (int64_t)y0 * W + x0 + 4 * k4;
 #pragma unroll
     for (int sg = 0; sg < 8; ++sg)
-      *reinterpret_cast<float4*>(yb + (sg >> 2) * W + 16 * (sg & 3)) = make_float4(acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3]);
+      *reinterpret_cast<float4*>(yb + ((8 * wave + sg) / C::SEGW) * W + 16 * ((8 * wave + sg) % C::SEGW)) =
+          make_float4(acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3]);
 
     if (p.bn.part) {   // data gradient: BatchNorm-backward statistics of the layer that consumes it
       const float mean = p.bn.st[c16], invstd = p.bn.st[16 + c16], sc = p.bn.st[32 + c16], sh = p.bn.st[48 + c16];
-      const int64_t base = ((int64_t)n * 16 + c16) * HW + (int64_t)(y0 + wave * 2) * W + x0 + 4 * k4;
+      const int64_t base = ((int64_t)n * 16 + c16) * HW + (int64_t)y0 * W + x0 + 4 * k4;
       BnBwdAcc ba;
 #pragma unroll
       for (int sg = 0; sg < 8; ++sg)
-        bn_bwd_acc4(p.bn, base + (sg >> 2) * W + 16 * (sg & 3), acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3], mean, invstd, sc,
+        bn_bwd_acc4(p.bn, base + ((8 * wave + sg) / C::SEGW) * W + 16 * ((8 * wave + sg) % C::SEGW), acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3], mean, invstd, sc,
                     sh, ba);
       float s1[1], s2[1];
       bn_bwd_fold(ba, s1[0], s2[0]);
@@ -559,10 +561,11 @@ bool conv_nk16_eligible(const WslSrc& a, const WslSrc* b, const float* y, int64_
   return (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_bs & 3) == 0 && (int64_t)16 * H * W < (int64_t(1) << 31);
 }
 
-template <int CI>
+template <int CI, int TH, int TW>
 static int launch_nk16(NkP& p, bool dgrad, void* stream) {
-  using C = NkCfg<CI>;
-  auto kern = conv_nk16_kernel<CI>;
+  using C = NkCfg<CI, TH, TW>;
+  auto kern = conv_nk16_kernel<CI, TH, TW>;
+  p.tiles_x = p.W / TW, p.tiles_y = p.H / TH;
   static bool attr_done = false;
   if (!attr_done) {
     (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
@@ -586,7 +589,13 @@ int conv_nk16_launch(const WslSrc& a, const float* wp, const float* bias, float*
   const bool bn_ok = bn && bn->part;
   if (bn_ok) p.bn = *bn;
   if (bn_done) *bn_done = bn_ok ? 1 : 0;
-  return a.C == 4 ? launch_nk16<4>(p, dgrad, stream) : launch_nk16<1>(p, dgrad, stream);
+#ifdef WSL_EXPERIMENTS
+  // same number of tiles (and statistics slots) either way; 4 x 128 writes 512-byte row segments instead of 256-byte ones:
+  // 113 vs 127-136 us for the data gradient alone, no difference in the step (3862 vs 3862 slices/s) -- experiments build only
+  static const int wide = WSL_TUNE("WSL_NK16_WIDE", 0);
+  if (wide && W % 128 == 0) return a.C == 4 ? launch_nk16<4, 4, 128>(p, dgrad, stream) : launch_nk16<1, 4, 128>(p, dgrad, stream);
+#endif
+  return a.C == 4 ? launch_nk16<4, 8, 64>(p, dgrad, stream) : launch_nk16<1, 8, 64>(p, dgrad, stream);
 }
 
 // ---- machine probes (EXPERIMENTS build only; tools/mfma_ceiling.py, tools/probe_lds_dma.py, tools/probe_mfma4.py)
