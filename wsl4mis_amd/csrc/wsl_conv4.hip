@@ -427,7 +427,9 @@ struct NkCfg {
   static_assert(POS <= 256 && (CI == 1 || CI == 4) && TH * TW == 512, "one float4 position per thread");
 };
 
-template <int CI, int TH = 8, int TW = 64>
+// (NHWC: layout probe of the experiments build -- the 16 output channels of a pixel stored contiguously, [N][H][W][16]; the
+//  result is not what any consumer reads, only the store pattern is of interest: tools/microbench_nk16.py)
+template <int CI, int TH = 8, int TW = 64, bool NHWC = false>
 __global__ __launch_bounds__(256, 3) void conv_nk16_kernel(NkP p) {
   using C = NkCfg<CI, TH, TW>;
   WSL_DYN_SMEM(smem);
@@ -502,11 +504,20 @@ __global__ __launch_bounds__(256, 3) void conv_nk16_kernel(NkP p) {
     }
     // (staging the result through LDS so that every store instruction writes four 256-byte row segments instead of sixteen
     //  64-byte pieces was measured SLOWER: 92.5 vs 75.8 us forward, 132.9 vs 115.7 data gradient)
+    if constexpr (NHWC) {
+      float* yb = p.y + n * p.y_bs + ((int64_t)y0 * W + x0 + 4 * k4) * 16 + c16;
+#pragma unroll
+      for (int sg = 0; sg < 8; ++sg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          yb[((int64_t)((8 * wave + sg) / C::SEGW) * W + 16 * ((8 * wave + sg) % C::SEGW) + r) * 16] = acc[sg][r];
+    } else {
     float* yb = p.y + n * p.y_bs + (int64_t)c16 * HW + (int64_t)y0 * W + x0 + 4 * k4;
 #pragma unroll
     for (int sg = 0; sg < 8; ++sg)
       *reinterpret_cast<float4*>(yb + ((8 * wave + sg) / C::SEGW) * W + 16 * ((8 * wave + sg) % C::SEGW)) =
           make_float4(acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3]);
+    }
 
     if (p.bn.part) {   // data gradient: BatchNorm-backward statistics of the layer that consumes it
       const float mean = p.bn.st[c16], invstd = p.bn.st[16 + c16], sc = p.bn.st[32 + c16], sh = p.bn.st[48 + c16];
@@ -592,6 +603,15 @@ int conv_nk16_launch(const WslSrc& a, const float* wp, const float* bias, float*
 #ifdef WSL_EXPERIMENTS
   // same number of tiles (and statistics slots) either way; 4 x 128 writes 512-byte row segments instead of 256-byte ones:
   // 113 vs 127-136 us for the data gradient alone, no difference in the step (3862 vs 3862 slices/s) -- experiments build only
+  static const int nhwc = WSL_TUNE("WSL_NK16_NHWC", 0);
+  if (nhwc) {
+    auto kern = a.C == 4 ? conv_nk16_kernel<4, 8, 64, true> : conv_nk16_kernel<1, 8, 64, true>;
+    p.tiles_x = W / 64, p.tiles_y = H / 8;
+    int wgs = 3 * device_cu_count();
+    if (wgs > p.items) wgs = p.items;
+    WSL_LAUNCH(kern, dim3(wgs), dim3(kThreads), (a.C == 4 ? NkCfg<4>::SMEM : NkCfg<1>::SMEM), stream, p);
+    return check_launch("conv_nk16_kernel(nhwc probe)");
+  }
   static const int wide = WSL_TUNE("WSL_NK16_WIDE", 0);
   if (wide && W % 128 == 0) return a.C == 4 ? launch_nk16<4, 4, 128>(p, dgrad, stream) : launch_nk16<1, 4, 128>(p, dgrad, stream);
 #endif
