@@ -34,6 +34,8 @@ def main(argv=None):
     ap.add_argument("--loss", default="ours_proposed", choices=["ours_proposed", "pce", "pce_gatedcrf", "pce_tv", "pce_ms", "pce_entropy", "ce_dice", "mean_teacher", "ustm"])
     ap.add_argument("--num_classes", type=int, default=4)
     ap.add_argument("--max_iterations", type=int, default=60000)
+    ap.add_argument("--stop_iterations", type=int, default=0, help="stop after this many iterations while keeping the poly schedule "
+                    "of --max_iterations (short-schedule comparisons against the oracle: tools/oracle_acdc_short.py)")
     ap.add_argument("--batch_size", type=int, default=12)
     ap.add_argument("--base_lr", type=float, default=0.01)
     ap.add_argument("--patch_size", type=int, nargs=2, default=[256, 256])
@@ -74,7 +76,8 @@ def main(argv=None):
     log = [] if (args.curve_json and rank == 0) else None
     import time
     t_start = time.time()
-    while it < args.max_iterations:
+    last = args.stop_iterations if 0 < args.stop_iterations < args.max_iterations else args.max_iterations
+    while it < last:
         perm = order.permutation(len(train))
         for b in range(0, len(perm), args.batch_size):
             idx = perm[b:b + args.batch_size]
@@ -120,7 +123,7 @@ def main(argv=None):
                 eng.model.train()
             if rank == 0 and args.snapshot_path and it % args.save_every == 0:     # ..._ours_proposed.py:194-198
                 torch.save(eng.model.state_dict(), os.path.join(args.snapshot_path, "iter_" + str(it) + ".pth"))
-            if it >= args.max_iterations:
+            if it >= last:
                 break
     if log is not None:
         import json
