@@ -37,7 +37,7 @@ const char* wsl_build_info(void);   /* "gfx950 hipcc ..." or "HOST-EMULATION (te
 /* Opt-in measurement: HIP events bracket every launch of the heavy kernel families on the launch stream while
  * enabled; wsl_prof_report() waits for those events (the library's only synchronising call) and fills one row per
  * family with the launch count, summed duration and the ALGORITHMIC flops / bytes those launches covered. */
-#define WSL_PROF_FAMILIES 16
+#define WSL_PROF_FAMILIES 20
 typedef struct WslProfRow {
   char name[48];
   int64_t calls;
@@ -174,6 +174,51 @@ int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const flo
                          const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
                          float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
                          int channel_major, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ split-precision conv path
+ * (opt-in; ref semantics unchanged: networks/unet.py:13-29.)  The 3x3 convolutions on the f16 matrix cores
+ * (16x the f32 MFMA rate) with fp32-class accuracy: while an operand tile is staged it is split into
+ *     x * 2^e = hi + lo,   hi = f16(x * 2^e) rounded toward zero,  lo = f16 of the exact remainder   (21-22 significant bits)
+ * and the kernels issue three passes  hi*hi + hi*lo + lo*hi  of v_mfma_f32_16x16x32_f16 into ONE fp32 accumulator; the epilogue
+ * undoes the power-of-two scales (exact) and is otherwise the f32 kernels' (bias, BatchNorm partial statistics, BatchNorm-backward
+ * statistics).  Scales: weights per layer from max |w| (wsl_sp_pack_weights writes the bit pattern into *w_amax); gradient tensors
+ * from max |dy| as left by their producer (wsl_bnact_bwd*_amax below); activations (everything a forward convolution or the
+ * weight gradient reads through a WslSrc) a fixed 2^WSL_SP_ACT_EXP: f16 then holds |v| < 4094 -- BatchNorm-normalised values
+ * cannot reach that, and a larger value saturates instead of overflowing.  Results are independent of the scale chosen as long as
+ * nothing under- or overflows.  Eligible layers (wsl_sp_conv2d_ok): ks 3, (Ca + Cb) % 16 == 0 (Ca % 16 == 0 with two sources),
+ * Co % 16 == 0, (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0), float4-aligned tensors.
+ * An `amax` argument is the DEVICE address of one uint32: the bit pattern of a non-negative float, merged with an integer atomic
+ * max (order-independent, so results stay run-to-run reproducible); the caller zeroes it before the producer runs. */
+#define WSL_SP_ACT_EXP 4
+int wsl_sp_conv2d_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int N, int H, int W, int Co, int ks);
+/* one weight image (hi and lo halves in the kernels' operand order; the 9 taps padded to 10): 40 * Ci * Co bytes */
+size_t wsl_sp_weight_image_bytes(int Co, int Ci);
+/* w: the layer's raw weight.  dgrad 0: [Co][Ci][3][3] -> forward image.  dgrad 1: w is the FORWARD weight [Ci][Co][3][3] and Co / Ci
+ * are the data-gradient GEMM's output / input channel counts (as wsl_conv2d_pack_weights wmode_raw 1).  Two launches. */
+int wsl_sp_pack_weights(const float* w, void* image, uint32_t* w_amax, int Co, int Ci, int dgrad, void* stream);
+/* y = conv2d(cat(a, b), w) + bias on the split path.  in_amax NULL: the sources are activations (fixed scale); else the scale of
+ * the (plain) source comes from *in_amax.  stat_part / stat_cnt as wsl_conv2d_fwd ([Co][nblk][2], nblk = wsl_sp_conv2d_stat_blocks). */
+int wsl_sp_conv2d_fwd(const WslSrc* a, const WslSrc* b, const void* image, const uint32_t* w_amax, const uint32_t* in_amax,
+                      const float* bias, float* y, int64_t y_bs, int N, int H, int W, int Co, float* stat_part, float* stat_cnt,
+                      void* stream);
+int wsl_sp_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co);
+/* wsl_conv2d_dgrad_bn on the split path (image = the data-gradient image); *fused as there. */
+int wsl_sp_conv2d_dgrad_bn(const WslSrc* dy, const uint32_t* dy_amax, const void* image, const uint32_t* w_amax, float* g,
+                           int64_t g_bs, int N, int H, int W, int Co, const float* bn_y, const float* bn_st,
+                           const uint8_t* bn_emask, float bn_emask_scale, float* bn_part, int* fused, void* stream);
+/* wsl_conv2d_wgrad_partial on the split path: dy scaled from *dy_amax, the sources a / b with the activation scale. */
+size_t wsl_sp_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
+int wsl_sp_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, const uint32_t* dy_amax,
+                                float* dw, float* db, int N, int H, int W, int Co, void* ws, size_t ws_bytes,
+                                WslWgradPending* pending, void* stream);
+/* wsl_bnact_bwd / wsl_bnact_bwd_finish that also leave max |dy| in *dy_amax (NULL = the plain calls). */
+int wsl_bnact_bwd_amax(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, const uint8_t* emask, float emask_scale, float* dy, float* dgamma, float* dbeta, int N,
+                       int C, int H, int W, void* ws, size_t ws_bytes, uint32_t* dy_amax, void* stream);
+int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                              float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
+                              int channel_major, void* ws, size_t ws_bytes, uint32_t* dy_amax, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (ref: unet.py:56-57) and its transpose. */
 int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream);

@@ -51,6 +51,7 @@ struct WaveState {
   unsigned long gen = 0;
   uint32_t xa[2][64];
   uint32_t xb[2][64];
+  uint32_t xw[2][2][64][4];   // wide operands (f16 MFMA: 8 halves per lane and operand; transpose read: one pointer per lane)
 };
 
 struct State {
@@ -199,6 +200,81 @@ static inline wsl_v16f wsl_emu_mfma32(float a, float b, wsl_v16f c) {
     c[r] = acc;
   }
   return c;
+}
+
+// ---- f16 pieces of the split-precision path ------------------------------------------------------------------------------
+typedef uint32_t wsl_emu_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t wsl_emu_u2 __attribute__((ext_vector_type(2)));
+static inline float wsl_emu_h2f(uint16_t b) {
+  _Float16 h;
+  memcpy(&h, &b, 2);
+  return (float)h;
+}
+static inline uint16_t wsl_emu_f2h_rne(float f) {        // v_cvt_pk_f16_f32 (round to nearest even; overflow -> inf)
+  const _Float16 h = (_Float16)f;
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  return b;
+}
+static inline uint16_t wsl_emu_f2h_rtz(float f) {        // v_cvt_pkrtz_f16_f32 (toward zero; a finite overflow saturates at 65504)
+  const uint32_t u = wsl_emu_bits(f), sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+  if (a == 0x7f800000u) return (uint16_t)(sign | 0x7c00u);
+  if (a >= 0x477fe000u) return (uint16_t)(sign | 0x7bffu);
+  const int e = (int)(a >> 23) - 127;
+  if (e >= -14) return (uint16_t)(sign | (uint32_t)((e + 15) << 10) | ((a >> 13) & 0x3ffu));
+  const int sh = (-14 - e) + 13;
+  const uint32_t m = (a & 0x7fffffu) | 0x800000u;
+  return (uint16_t)(sign | (sh < 32 ? (m >> sh) : 0u));
+}
+// v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8 (l >> 4) + e], B[k = 8 (l >> 4) + e][j = l & 15], D col = l & 15, row = 4 (l >> 4) + r
+// (operand layout probed on the device: tools/probe_sp.hip).  Products of two halves are exact in fp32; they are summed in k order.
+static inline wsl_v4f wsl_emu_mfma16x32_f16(wsl_emu_u4 a, wsl_emu_u4 b, wsl_v4f c) {
+  auto& w = wsl_emu::wave();
+  auto& f = wsl_emu::st().fibers[wsl_emu::st().cur];
+  const int buf = f.seq & 1;
+  f.seq++;
+  const int l = wsl_emu::lane();
+  for (int q = 0; q < 4; ++q) w.xw[buf][0][l][q] = a[q], w.xw[buf][1][l][q] = b[q];
+  wsl_emu::wave_sync();
+  const int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k) {
+      const uint32_t ua = w.xw[buf][0][(k >> 3) * 16 + row][(k & 7) >> 1], ub = w.xw[buf][1][(k >> 3) * 16 + col][(k & 7) >> 1];
+      const float av = wsl_emu_h2f((uint16_t)((k & 1) ? ua >> 16 : ua)), bv = wsl_emu_h2f((uint16_t)((k & 1) ? ub >> 16 : ub));
+      acc += av * bv;
+    }
+    c[r] = acc;
+  }
+  return c;
+}
+// ds_read_b64_tr_b16 (probed on the device: tools/probe_sp.hip): inside a group of 16 lanes, lane i receives as element e the
+// (i & 3)-th half of the four contiguous halves at the address supplied by lane 4 e + (i >> 2) of the group
+static inline wsl_emu_u2 wsl_emu_ds_read_tr16(const void* p) {
+  auto& w = wsl_emu::wave();
+  auto& f = wsl_emu::st().fibers[wsl_emu::st().cur];
+  const int buf = f.seq & 1;
+  f.seq++;
+  const int l = wsl_emu::lane();
+  const uint64_t u = (uint64_t)(uintptr_t)p;
+  w.xw[buf][0][l][0] = (uint32_t)u, w.xw[buf][0][l][1] = (uint32_t)(u >> 32);
+  wsl_emu::wave_sync();
+  const int g = l & ~15, i = l & 15;
+  uint16_t h[4];
+  for (int e = 0; e < 4; ++e) {
+    const int s = g + 4 * e + (i >> 2);
+    const uint16_t* q = (const uint16_t*)(uintptr_t)(((uint64_t)w.xw[buf][0][s][1] << 32) | w.xw[buf][0][s][0]);
+    h[e] = q[i & 3];
+  }
+  return wsl_emu_u2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+}
+// order-independent maximum of non-negative floats through their bit patterns (workgroups of a launch run on several host threads)
+static inline uint32_t atomicMax(uint32_t* p, uint32_t v) {
+  uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return o;
 }
 
 template <typename T>

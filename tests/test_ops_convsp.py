@@ -1,0 +1,135 @@
+"""Split-precision conv path (f16 hi/lo operands, three MFMA passes, fp32 accumulate; include/wsl_hip.h "split-precision conv
+path") through the C ABI: forward / data gradient / weight gradient against stock torch fp32 autograd at the SAME 1e-4 criteria
+as the f32 kernels (tests/test_ops_conv.py), plus the deviation from an fp64 truth next to the f32 kernels' own.
+`be` runs every case on the host emulator (CPU) and, with -m gpu, on the MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import close, rel_err
+from test_ops_conv import virt_input
+
+TOL = 1e-4
+
+CASES = [  # N, H, W, Ca, Cb, Co, transforms on a
+    (2, 8, 32, 16, 0, 16, True),
+    (1, 16, 32, 16, 16, 32, True),
+    (1, 8, 64, 32, 0, 16, False),
+    (2, 16, 16, 16, 0, 64, True),
+    (1, 16, 16, 32, 32, 32, True),
+    (1, 8, 32, 48, 0, 64, "bn"),
+    (1, 16, 16, 64, 0, 16, False),
+    (3, 8, 32, 16, 16, 128, True),
+]
+
+
+def _amax_bits(be):
+    return be.zeros((4,), np.int64)     # 32 bytes, 16-byte aligned; the library writes / reads the first uint32
+
+
+def _set_amax(be, slot, value):
+    a = np.zeros(4, np.int64)
+    a.view(np.uint32)[0] = np.float32(value).view(np.uint32)
+    return be.arr(a)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_sp_conv_fwd_dgrad_wgrad(be, case):
+    N, H, W, Ca, Cb, Co, tr = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    xa = rng.standard_normal((N, Ca, H, W)).astype(np.float32)
+    xb = (rng.standard_normal((N, Cb, H, W)) * 3).astype(np.float32) if Cb else None
+    Ci = Ca + Cb
+    w = (rng.standard_normal((Co, Ci, 3, 3)) * 0.07).astype(np.float32)
+    bias = rng.standard_normal(Co).astype(np.float32)
+    scale = shift = emask = cmask = None
+    es = 1.0
+    if tr:
+        scale = (rng.standard_normal(Ca) * 0.5 + 1).astype(np.float32)
+        shift = (rng.standard_normal(Ca) * 0.3).astype(np.float32)
+    if tr is True:
+        emask = (rng.random((N, Ca, H, W)) > 0.3).astype(np.uint8)
+        es = float(np.float32(1 / 0.7))
+        cmask = ((rng.random((N, Ca)) > 0.5) * 2.0).astype(np.float32)
+    va = virt_input(xa, scale, shift, emask, es, cmask)
+    vin = (torch.cat([va, torch.from_numpy(xb)], 1) if Cb else va).requires_grad_()
+    wt = torch.from_numpy(w).requires_grad_()
+    bt = torch.from_numpy(bias).requires_grad_()
+    y_ref = F.conv2d(vin, wt, bt, padding=1)
+    r = (rng.standard_normal((N, Co, H, W)) * 3e-5).astype(np.float32)     # a gradient-sized tensor: exercises the dynamic scale
+    (y_ref * torch.from_numpy(r)).sum().backward()
+    y64 = F.conv2d(vin.detach().double(), wt.detach().double(), bt.detach().double(), padding=1).numpy()
+
+    d = {k: (be.arr(v) if v is not None else None) for k, v in
+         dict(xa=xa, xb=xb, w=w, bias=bias, scale=scale, shift=shift, emask=emask, cmask=cmask, r=r).items()}
+    sa = be.src(d["xa"], Ca, scale=d["scale"], shift=d["shift"], emask=d["emask"], es=es, cmask=d["cmask"])
+    sb = be.src(d["xb"], Cb) if Cb else be.src()
+    y = be.zeros((N, Co, H, W))
+    assert be.lib.wsl_sp_conv2d_ok(sa, sb, be.ptr(y), Co * H * W, N, H, W, Co, 3) == 1
+    nbytes = be.lib.wsl_sp_weight_image_bytes(Co, Ci)
+    assert nbytes == 40 * Ci * Co
+    img, wmax = be.ws(nbytes), _amax_bits(be)
+    be.call("wsl_sp_pack_weights", be.ptr(d["w"]), be.ptr(img), be.ptr(wmax), Co, Ci, 0, be.stream)
+    assert be.np(wmax).view(np.uint32)[0] == np.abs(w).max().view(np.uint32)
+    nblk = be.lib.wsl_sp_conv2d_stat_blocks(N, H, W, Ci, Co)
+    part, cnt = be.zeros((Co, nblk, 2)), be.zeros((nblk,))
+    be.call("wsl_sp_conv2d_fwd", sa, sb, be.ptr(img), be.ptr(wmax), None, be.ptr(d["bias"]), be.ptr(y), Co * H * W, N, H, W, Co,
+            be.ptr(part), be.ptr(cnt), be.stream)
+    got = be.np(y)
+    assert close(got, y_ref.detach().numpy(), TOL)
+    # distance from the fp64 truth: the split path vs stock torch fp32 (must be the same class, not 1e-4)
+    e_sp, e_f32 = rel_err(got, y64), rel_err(y_ref.detach().numpy(), y64)
+    print(f"SP-FWD {case}: split {e_sp:.2e}  torch-fp32 {e_f32:.2e} from the fp64 truth")
+    assert e_sp < 4 * max(e_f32, 2e-7)
+    # BatchNorm statistics from the epilogue partials
+    assert float(be.np(cnt).sum()) == N * H * W
+    mean, invstd, sc, sh = (be.zeros((Co,)) for _ in range(4))
+    g1, b0 = be.arr(np.ones(Co, np.float32)), be.arr(np.zeros(Co, np.float32))
+    be.call("wsl_bn_stats_finalize", be.ptr(part), be.ptr(cnt), nblk, Co, be.ptr(g1), be.ptr(b0), 1e-5, 0.1, None, None, None,
+            be.ptr(mean), be.ptr(invstd), be.ptr(sc), be.ptr(sh), be.stream)
+    yr = y_ref.detach()
+    assert rel_err(be.np(mean), yr.mean((0, 2, 3)).numpy()) < 1e-5
+    assert rel_err(be.np(invstd), (1 / torch.sqrt(yr.var((0, 2, 3), unbiased=False) + 1e-5)).numpy()) < 1e-5
+
+    # ---- data gradient: dL/d(vin) from r, scaled from max |r| as its producer would leave it
+    rmax = _set_amax(be, None, np.abs(r).max())
+    imgd, wmaxd = be.ws(be.lib.wsl_sp_weight_image_bytes(Ci, Co)), _amax_bits(be)
+    be.call("wsl_sp_pack_weights", be.ptr(d["w"]), be.ptr(imgd), be.ptr(wmaxd), Ci, Co, 1, be.stream)
+    sr = be.src(d["r"], Co)
+    dx = be.zeros((N, Ci, H, W))
+    assert be.lib.wsl_sp_conv2d_ok(sr, be.src(), be.ptr(dx), Ci * H * W, N, H, W, Ci, 3) == 1
+    be.call("wsl_sp_conv2d_fwd", sr, be.src(), be.ptr(imgd), be.ptr(wmaxd), be.ptr(rmax), None, be.ptr(dx), Ci * H * W, N, H, W, Ci,
+            None, None, be.stream)
+    assert close(be.np(dx), vin.grad.numpy(), TOL)
+    # a scale chosen 2^6 too small (an out-of-date maximum) changes nothing but the low halves that turn subnormal
+    rmax2 = _set_amax(be, None, np.abs(r).max() * 64)
+    dx2 = be.zeros((N, Ci, H, W))
+    be.call("wsl_sp_conv2d_fwd", sr, be.src(), be.ptr(imgd), be.ptr(wmaxd), be.ptr(rmax2), None, be.ptr(dx2), Ci * H * W, N, H, W, Ci,
+            None, None, be.stream)
+    assert rel_err(be.np(dx2), be.np(dx)) < 1e-6
+
+    # ---- weight / bias gradient
+    nws = be.lib.wsl_sp_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co)
+    ws, dw, db = be.ws(nws), be.zeros((Co, Ci, 3, 3)), be.zeros((Co,))
+    from wsl4mis_amd import _lib
+    pend = _lib.WslWgradPending()
+    import ctypes as C
+    be.call("wsl_sp_conv2d_wgrad_partial", sa, sb, be.ptr(d["r"]), Co * H * W, be.ptr(rmax), be.ptr(dw), be.ptr(db), N, H, W, Co,
+            be.ptr(ws), nws, C.byref(pend), be.stream)
+    be.call("wsl_wgrad_reduce_batch", C.byref(pend), 1, be.stream)
+    assert close(be.np(dw), wt.grad.numpy(), TOL)
+    assert close(be.np(db), bt.grad.numpy(), TOL)
+
+
+def test_sp_not_eligible(be):
+    x = be.zeros((1, 8, 8, 32))
+    s = be.src(x, 8)
+    assert be.lib.wsl_sp_conv2d_ok(s, be.src(), None, 0, 1, 8, 32, 16, 3) == 0        # Ci % 16
+    x2 = be.zeros((1, 16, 8, 32))
+    s2 = be.src(x2, 16)
+    assert be.lib.wsl_sp_conv2d_ok(s2, be.src(), None, 0, 1, 8, 32, 16, 1) == 0       # 1x1
+    assert be.lib.wsl_sp_conv2d_ok(s2, be.src(), None, 0, 1, 8, 32, 16, 3) == 1
+    with pytest.raises(Exception, match="eligible"):
+        be.call("wsl_sp_conv2d_fwd", s, be.src(), be.ptr(x), be.ptr(x), None, None, be.ptr(x), 16 * 8 * 32, 1, 8, 32, 16, None, None,
+                be.stream)

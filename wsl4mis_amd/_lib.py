@@ -22,7 +22,7 @@ class WslSrc(C.Structure):
                 ("shift", c_fp), ("emask", c_fp), ("emask_scale", C.c_float), ("_pad1", C.c_float), ("cmask", c_fp)]
 
 
-WSL_PROF_FAMILIES = 16
+WSL_PROF_FAMILIES = 20
 
 
 class WslProfRow(C.Structure):
@@ -91,6 +91,21 @@ _PROTOS = {
     "wsl_feat_grad_combine_bn": (i32, [PS, c_fp, i64, c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     "wsl_bnact_bwd_finish": (i32, [c_fp, i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32,
                                    c_fp, i32, i32, c_fp, sz, c_fp]),
+    # split-precision conv path (opt-in)
+    "wsl_sp_conv2d_ok": (i32, [PS, PS, c_fp, i64, i32, i32, i32, i32, i32]),
+    "wsl_sp_weight_image_bytes": (sz, [i32, i32]),
+    "wsl_sp_pack_weights": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wsl_sp_conv2d_fwd": (i32, [PS, PS, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
+    "wsl_sp_conv2d_stat_blocks": (i32, [i32, i32, i32, i32, i32]),
+    "wsl_sp_conv2d_dgrad_bn": (i32, [PS, c_fp, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp, f32, c_fp,
+                                     C.POINTER(C.c_int), c_fp]),
+    "wsl_sp_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "wsl_sp_conv2d_wgrad_partial": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, sz,
+                                          C.POINTER(WslWgradPending), c_fp]),
+    "wsl_bnact_bwd_amax": (i32, [c_fp, i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32,
+                                 c_fp, sz, c_fp, c_fp]),
+    "wsl_bnact_bwd_finish_amax": (i32, [c_fp, i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32,
+                                        c_fp, i32, i32, c_fp, sz, c_fp, c_fp]),
     "wsl_bilinear_up2_fwd": (i32, [c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),
     "wsl_bilinear_up2_bwd": (i32, [c_fp, i64, c_fp, i32, i32, i32, i32, c_fp]),
     "wsl_softmax_fwd": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),

@@ -114,7 +114,7 @@ static const char* kFamNames[WSL_PROF_FAMILIES] = {
     "conv_mfma2l_kernel(fwd)", "conv_mfma2l_kernel(dgrad)", "wgrad_wino_kernel", "wgrad_reduce_kernel", "gatedcrf_fwd_kernel",
     "other", "conv_wino2_kernel(fwd)", "conv_wino2_kernel(dgrad)", "wgrad_direct_kernels", "bnact_bwd(reduce+finalize+apply)",
     "bn_finalize_kernel", "bilinear_up2(fwd+bwd)", "pool2_fwd+feat_grad_combine", "loss_head(reduce+finalize+bwd+mix)", "sgd_kernel",
-    "masks+filter_images"};
+    "masks+filter_images", "conv_sp_kernel(fwd)", "conv_sp_kernel(dgrad)", "wgrad_sp_kernel", "spare"};
 void* prof_begin(int fam, double flops, double bytes, void* stream, double issued) {
   if (!g_prof_on) return nullptr;
   ProfRec r{fam, flops, bytes, issued < 0.0 ? flops : issued, nullptr, nullptr};

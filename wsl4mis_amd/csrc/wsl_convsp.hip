@@ -1,0 +1,811 @@
+// Split-precision convolution kernels (opt-in): the 3x3 convolutions of the UNet -- forward,
+// data gradient and weight gradient -- as DIRECT implicit GEMMs on v_mfma_f32_16x16x32_f16 (16x the f32 MFMA rate), with
+// fp32-class accuracy from a two-term operand split done while a tile is staged (wsl_rt.h: sp_split2):
+//     x * 2^e = hi + lo        acc += hi_a * lo_b;  acc += lo_a * hi_b;  acc += hi_a * hi_b      (fp32 accumulator)
+// The dropped lo * lo term is 2^-22 of the product.  Reference semantics are those of the f32 kernels
+// (ref: networks/unet.py:13-29 ConvBlock; autograd of the same).
+//
+// One LDS image serves all three kernels: CHANNEL-INNERMOST octets -- 8 channels x f16 = one 16-byte slot per (octet, pixel) --
+// because the f16 MFMA wants 8 consecutive K values per lane:
+//   * conv (K = input channels of a tap): lane (pixel m = l & 15, k-group g = l >> 4) reads ONE slot (ds_read_b128) per operand;
+//     a 16-channel chunk gives K = 32 as two taps x 16 channels (g >> 1 = which tap, g & 1 = which octet): 5 K-steps per chunk,
+//     the tenth tap is a zero block of the weight image;
+//   * weight gradient (K = pixels): the same slots read with ds_read_b64_tr_b16, which hands lane (channel, 4 pixels) the
+//     transposed 4 x 16 block -- a tap shift is a whole-slot offset, so no operand is ever misaligned.
+// Inside a plane the slots of a row are stored pixel-of-quad major (slot(c) = (c & 3) * P + (c >> 2), P = 4 or 12 mod 16): a
+// staging thread (4 pixels x 8 channels from eight float4 loads) then writes four slots that are each contiguous across lanes
+// (conflict-free ds_write_b128), and the 16 pixels of an MFMA row tile still fall into 16 different 16-byte bank groups.
+#include "wsl_rt.h"
+
+namespace wsl {
+
+struct SpSrc {           // one source, device view
+  const float* x;
+  const uint8_t* emask;
+  const float* scale;
+  const float* shift;
+  const float* cmask;
+  int64_t bs;
+  int C;
+  float es;
+};
+
+static SpSrc to_spsrc(const WslSrc& s) { return SpSrc{s.x, s.emask, s.scale, s.shift, s.cmask, s.bs, s.C, s.emask_scale}; }
+
+constexpr int kSpMaxC = 512;   // channels whose loader coefficients fit the LDS table
+
+// ------------------------------------------------------------------------------------------------ tile image + staging
+// A staged tile: ROWS x (4 * NQ) pixels x NOCT octets, hi and lo images.  Byte offset of (hl, octet o, row r, staged column c):
+//     hl * HL + o * PLANE + r * ROWB + ((c & 3) * P + (c >> 2)) * 16
+// P_ = 0: the pitch the conv kernels' row reads need (>= NQ and = 4 or 12 mod 16); the weight gradient's transpose reads take
+// compact images (P_ = NQ).
+template <int ROWS_, int NQ_, int NOCT_, int P_ = 0>
+struct SpImg {
+  static constexpr int ROWS = ROWS_, NQ = NQ_, NOCT = NOCT_;
+  static constexpr int P = P_ ? P_ : (NQ <= 12 ? 12 : (NQ <= 20 ? 20 : 28));
+  static constexpr int RS = 4 * P + 2;                              // slots per row (+2: consecutive rows rotate by two slots)
+  static constexpr int ROWB = RS * 16;
+  static constexpr int PLANE = ((ROWS * ROWB + 255) / 256) * 256;   // = 0 (mod 256): the octets of one read hit the same bank groups
+  static constexpr int HL = NOCT * PLANE;
+  static constexpr int BYTES = 2 * HL;
+  static constexpr int NTASK = ROWS * NQ * NOCT, NR = (NTASK + 255) / 256;
+  static_assert(NQ <= 28, "tile too wide");
+};
+
+template <int NR>
+struct SpTasks {            // this thread's staging tasks: (row, quad, octet) = NR rounds of 256
+  uint32_t toff[NR];        // element offset of the quad inside a channel plane (0 when outside the image)
+  int loff[NR];             // byte offset of pixel 0 of the quad inside the hi image
+  int oct[NR];
+  bool valid[NR], active[NR];
+};
+
+template <int NR>
+struct SpRegs {             // prefetched raw data of the tasks: 8 channels x 4 pixels (+ keep bytes)
+  float4 v[NR][8];
+  uint32_t m[NR][8];
+};
+
+// (y0, x0) = image coordinates of staged row 0 / staged column 0
+template <typename I>
+__device__ __forceinline__ void sp_tasks_init(SpTasks<I::NR>& t, int tid, int y0, int x0, int H, int W) {
+#pragma unroll
+  for (int r = 0; r < I::NR; ++r) {
+    const int k = tid + r * kThreads;
+    const int q = k % I::NQ, rest = k / I::NQ;
+    const int row = rest % I::ROWS, o = rest / I::ROWS;
+    const int gy = y0 + row, gx = x0 + 4 * q;
+    t.active[r] = k < I::NTASK;
+    t.valid[r] = t.active[r] && gy >= 0 && gy < H && gx >= 0 && gx < W;     // W % 4 == 0: a quad is inside or outside as a whole
+    t.toff[r] = t.valid[r] ? (uint32_t)(gy * W + gx) : 0u;
+    t.oct[r] = t.active[r] ? o : 0;
+    t.loff[r] = t.oct[r] * I::PLANE + row * I::ROWB + q * 16;
+  }
+}
+
+// loads of one channel block (8 * NOCT channels starting at channel `chb` of sample-local source planes xs / ms)
+template <typename I>
+__device__ __forceinline__ void sp_issue(const SpTasks<I::NR>& t, SpRegs<I::NR>& g, const float* xs, const uint8_t* ms, int chb,
+                                         int HW) {
+#pragma unroll
+  for (int r = 0; r < I::NR; ++r) {
+    const float* xb = xs + (int64_t)(chb + t.oct[r] * 8) * HW + t.toff[r];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g.v[r][c] = *reinterpret_cast<const float4*>(xb + (int64_t)c * HW);
+    if (ms) {
+      const uint8_t* mb = ms + (int64_t)(chb + t.oct[r] * 8) * HW + t.toff[r];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g.m[r][c] = *reinterpret_cast<const uint32_t*>(mb + (int64_t)c * HW);
+    }
+  }
+}
+
+// transform (BN + LeakyReLU, keep mask, channel multiplier -- the WslSrc loader), scale by `mul`, split, write hi / lo slots.
+// tab / cml: LDS tables {scale, shift} and channel multiplier indexed by the channel inside the concatenated input (tc0 = table
+// index of channel chb).  `zero_fill`: tasks outside the image write zero slots (once per kernel: nothing else touches them).
+template <typename I>
+__device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const float2* tab,
+                                          const float* cml, int tc0, bool has_scale, bool has_mask, bool has_cm, float es, bool has_mul,
+                                          float mul, bool zero_fill) {
+#pragma unroll
+  for (int r = 0; r < I::NR; ++r) {
+    if (t.valid[r]) {
+      wsl_v2f a[8], b[8];   // a[c] = pixels 0, 1 of channel c; b[c] = pixels 2, 3
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        a[c] = wsl_v2f{g.v[r][c].x, g.v[r][c].y}, b[c] = wsl_v2f{g.v[r][c].z, g.v[r][c].w};
+        const int ch = tc0 + t.oct[r] * 8 + c;
+        if (has_scale) {
+          const float2 cf = tab[ch];
+          xform_bn_leaky(a[c], b[c], cf.x, cf.y);
+        }
+        if (has_mask) xform_mask(a[c], b[c], g.m[r][c], es);
+        if (has_cm) {
+          const float cm = cml[ch];
+          a[c] = a[c] * cm, b[c] = b[c] * cm;
+        }
+        if (has_mul) a[c] = a[c] * mul, b[c] = b[c] * mul;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wsl_u4 hi, lo;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float x0 = j < 2 ? a[2 * p][j & 1] : b[2 * p][j & 1], x1 = j < 2 ? a[2 * p + 1][j & 1] : b[2 * p + 1][j & 1];
+          uint32_t h, l;
+          sp_split2(x0, x1, h, l);
+          hi[p] = h, lo[p] = l;
+        }
+        unsigned char* dst = img + t.loff[r] + j * (I::P * 16);
+        *reinterpret_cast<wsl_u4*>(dst) = hi;
+        *reinterpret_cast<wsl_u4*>(dst + I::HL) = lo;
+      }
+    } else if (zero_fill && t.active[r]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned char* dst = img + t.loff[r] + j * (I::P * 16);
+        *reinterpret_cast<wsl_u4*>(dst) = wsl_u4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<wsl_u4*>(dst + I::HL) = wsl_u4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+}
+
+// byte offset of staged column c inside a row
+template <typename I>
+__device__ __forceinline__ int sp_slot(int c) { return ((c & 3) * I::P + (c >> 2)) * 16; }
+
+// ------------------------------------------------------------------------------------------------ weight images
+// image (one per layer and direction), in 16-byte pieces of 8 halves:  [chunk = ci / 16][hl][kstep 0..4][g 0..3][co][8]
+//   k-group g of K-step s holds tap 2 s + (g >> 1), input channels 16 chunk + 8 (g & 1) .. + 7; tap 9 does not exist: zeros.
+__global__ __launch_bounds__(256) void sp_amax_table_kernel(PackTable t, const float* params, uint32_t* amax) {
+  __shared__ float red[4];
+  const PackEntry e = t.e[blockIdx.x];
+  const int64_t n = (int64_t)e.Co * e.Ci * e.KK;
+  const float* w = params + e.w;
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    uint32_t u;
+    memcpy(&u, &m, 4);
+    amax[blockIdx.x] = u;
+  }
+}
+
+// blockIdx.y = table entry, blockIdx.z + dir0 = 0 forward image / 1 data-gradient image.  imgf / imgd: byte bases of the two image
+// arenas; the image of entry i starts io.off[i] bytes into its arena.
+struct SpPackOffsets {
+  int64_t off[40];
+};
+__global__ __launch_bounds__(256) void sp_pack_table_kernel(PackTable t, SpPackOffsets io, const float* params, unsigned char* imgf,
+                                                            unsigned char* imgd, const uint32_t* amax, int dir0) {
+  const PackEntry e = t.e[blockIdx.y];
+  if (e.KK != 9 || (e.Ci % 16) || (e.Co % 16)) return;   // (1x1 layers, first convolution, classifiers: not on this path)
+  const int dgrad = blockIdx.z + dir0;
+  const int Co = dgrad ? e.Ci : e.Co, Ci = dgrad ? e.Co : e.Ci;   // GEMM-out / GEMM-in of this image
+  const float* w = params + e.w;
+  wsl_u4* img = reinterpret_cast<wsl_u4*>((dgrad ? imgd : imgf) + io.off[blockIdx.y]);
+  const float mul = sp_pow2(sp_exp_of(amax[blockIdx.y]));
+  const int64_t pieces = (int64_t)(Ci / 16) * 5 * 4 * Co;          // per hl
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < pieces; i += (int64_t)gridDim.x * kThreads) {
+    const int co = (int)(i % Co);
+    int64_t r = i / Co;
+    const int g = (int)(r % 4);
+    r /= 4;
+    const int s = (int)(r % 5), chunk = (int)(r / 5);
+    const int tap = 2 * s + (g >> 1), ci0 = chunk * 16 + (g & 1) * 8;
+    wsl_u4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+    if (tap < 9) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float x[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ci = ci0 + 2 * p + h;
+          x[h] = mul * (dgrad ? w[((int64_t)ci * Co + co) * 9 + (8 - tap)] : w[((int64_t)co * Ci + ci) * 9 + tap]);
+        }
+        uint32_t a, b;
+        sp_split2(x[0], x[1], a, b);
+        hi[p] = a, lo[p] = b;
+      }
+    }
+    const int64_t dst = ((((int64_t)chunk * 2 + 0) * 5 + s) * 4 + g) * Co + co;
+    img[dst] = hi;
+    img[dst + (int64_t)5 * 4 * Co] = lo;
+  }
+}
+
+int sp_pack_table(const PackTable& t, const int64_t* img_off_bytes, const float* params, void* imgf, void* imgd, uint32_t* amax,
+                  int with_dgrad, void* stream) {
+  SpPackOffsets io;
+  double bytes = 0.0;
+  for (int i = 0; i < t.n; ++i) io.off[i] = img_off_bytes[i], bytes += t.e[i].KK == 9 ? 40.0 * t.e[i].Co * t.e[i].Ci : 0.0;
+  ProfScope ps(PF_PREP, 0.0, bytes * (with_dgrad ? 2.9 : 1.9), stream);
+  WSL_LAUNCH(sp_amax_table_kernel, dim3(t.n), dim3(kThreads), 0, stream, t, params, amax);
+  WSL_LAUNCH(sp_pack_table_kernel, dim3(16, t.n, with_dgrad ? 2 : 1), dim3(kThreads), 0, stream, t, io, params,
+             static_cast<unsigned char*>(imgf), static_cast<unsigned char*>(imgd), amax, 0);
+  return check_launch("sp_pack_table_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------ conv forward / data gradient
+struct ConvSpP {
+  SpSrc a, b;
+  const wsl_u4* img;        // this layer's weight image
+  const uint32_t* w_amax;
+  const uint32_t* in_amax;  // null: activation scale 2^WSL_SP_ACT_EXP
+  const float* bias;
+  float* y;
+  int64_t y_bs;
+  int N, H, W, Ci, Co, tiles_x, tiles_y;
+  float* stat_part;
+  float* stat_cnt;
+  BnBwdEpi bn;              // data-gradient launches: BatchNorm-backward statistics of the consumer of y
+};
+
+template <int TH, int TW, int CO_T>
+struct ConvSpCfg {
+  using Img = SpImg<TH + 2, (TW + 8) / 4, 2>;
+  static constexpr int SEGS = TW / 16, MT_TOTAL = TH * SEGS, MT = MT_TOTAL / 4, NT = CO_T / 16;
+  static constexpr int B_BYTES = 2 * 5 * 4 * CO_T * 16;            // [hl][kstep][g][co][8 halves]
+  static constexpr int B_PIECES = B_BYTES / 16, NBW = (B_PIECES + 255) / 256;
+  static constexpr size_t SMEM = Img::BYTES + B_BYTES + sizeof(float) * 3 * kSpMaxC;
+  static constexpr int MINW = (MT * NT * 4 <= 32) ? 3 : 2;
+  static_assert(MT_TOTAL % 4 == 0 && MT % SEGS == 0, "tile shape");
+  static_assert(8 * CO_T * sizeof(float) <= (size_t)Img::BYTES, "epilogue scratch");
+};
+
+template <int TH, int TW, int CO_T>
+__global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_kernel(ConvSpP p) {
+  using C = ConvSpCfg<TH, TW, CO_T>;
+  using I = typename C::Img;
+  WSL_DYN_SMEM(smem);
+  unsigned char* a_img = smem;
+  unsigned char* b_img = smem + I::BYTES;
+  float2* tab = reinterpret_cast<float2*>(smem + I::BYTES + C::B_BYTES);
+  float* cm_l = reinterpret_cast<float*>(tab + kSpMaxC);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD-aware tile order (neighbouring tiles share an L2)
+  const int tile_id = bid;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = blockIdx.y * CO_T;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co, HW = H * W;
+
+  const int e_w = sp_exp_of(*p.w_amax), e_in = p.in_amax ? sp_exp_of(*p.in_amax) : WSL_SP_ACT_EXP;
+  const float in_mul = sp_pow2(e_in);
+
+  SpTasks<I::NR> tk;
+  sp_tasks_init<I>(tk, tid, y0 - 1, x0 - 4, H, W);
+  const float* xa_n = p.a.x + n * p.a.bs;
+  const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
+  const uint8_t* ma_n = p.a.emask ? p.a.emask + (int64_t)n * p.a.C * HW : nullptr;
+  const uint8_t* mb_n = (p.b.C && p.b.emask) ? p.b.emask + (int64_t)n * p.b.C * HW : nullptr;
+
+  // weight pieces of a chunk: LDS piece u = ((hl * 5 + s) * 4 + g) * CO_T + col  <-  image piece ((hl * 5 + s) * 4 + g) * Co + co0 + col
+  uint32_t woff[C::NBW];
+#pragma unroll
+  for (int i = 0; i < C::NBW; ++i) {
+    const int u = tid + i * kThreads;
+    const int col = u % CO_T, rest = u / CO_T;
+    woff[i] = u < C::B_PIECES ? (uint32_t)(rest * Co + co0 + col) : 0u;
+  }
+  const int64_t chunk_pieces = (int64_t)40 * Co;
+
+  SpRegs<I::NR> pre;
+  wsl_u4 prw[C::NBW];
+  auto issue = [&](int c0) __attribute__((always_inline)) {
+    const bool ina = c0 < p.a.C;   // uniform
+    sp_issue<I>(tk, pre, ina ? xa_n : xb_n, ina ? ma_n : mb_n, ina ? c0 : c0 - p.a.C, HW);
+    const wsl_u4* wb = p.img + (int64_t)(c0 >> 4) * chunk_pieces;
+#pragma unroll
+    for (int i = 0; i < C::NBW; ++i) prw[i] = wb[woff[i]];
+  };
+  auto commit = [&](int c0) __attribute__((always_inline)) {
+    const bool ina = c0 < p.a.C;
+    const SpSrc& s = ina ? p.a : p.b;
+    sp_commit<I>(tk, pre, a_img, tab, cm_l, c0, s.scale != nullptr, s.emask != nullptr, s.cmask != nullptr, s.es,
+                 s.scale == nullptr, in_mul, c0 == 0);
+#pragma unroll
+    for (int i = 0; i < C::NBW; ++i)
+      if ((i + 1) * kThreads <= C::B_PIECES || tid + i * kThreads < C::B_PIECES)
+        reinterpret_cast<wsl_u4*>(b_img)[tid + i * kThreads] = prw[i];
+  };
+
+  issue(0);
+  // loader tables; the operand scale of a BatchNorm source is folded into its coefficients (exact: a power of two)
+  for (int c = tid; c < Ci; c += kThreads) {
+    const bool ina = c < p.a.C;
+    const SpSrc& s = ina ? p.a : p.b;
+    const int ch = ina ? c : c - p.a.C;
+    tab[c] = s.scale ? make_float2(s.scale[ch] * in_mul, s.shift[ch] * in_mul) : make_float2(1.f, 0.f);
+    cm_l[c] = s.cmask ? s.cmask[(int64_t)n * s.C + ch] : 1.f;
+  }
+
+  v4f acc[C::MT][C::NT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  // A operand of K-step s: pixel m = lane & 15 of the row tile, octet (lane >> 4) & 1, tap 2 s + (lane >> 5)
+  int aoff[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + (lane >> 5) < 9 ? 2 * s + (lane >> 5) : 8;   // (the tenth tap meets a zero weight block)
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    aoff[s] = ((lane >> 4) & 1) * I::PLANE + ky * I::ROWB + sp_slot<I>(3 + (lane & 15) + kx);
+  }
+  const int bbase = ((lane >> 4) * CO_T + (lane & 15)) * 16;
+  __syncthreads();   // tables visible
+
+  for (int c0 = 0; c0 < Ci; c0 += 16) {
+    commit(c0);
+    __syncthreads();
+    if (c0 + 16 < Ci) issue(c0 + 16);   // in flight during the MFMA loop below
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      wsl_u4 bh[C::NT], bl[C::NT];
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) {
+        const unsigned char* q = b_img + bbase + (s * 4 * CO_T + j * 16) * 16;
+        bh[j] = *reinterpret_cast<const wsl_u4*>(q);
+        bl[j] = *reinterpret_cast<const wsl_u4*>(q + 5 * 4 * CO_T * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i) {
+        const int mt = wave * C::MT + i;
+        const unsigned char* q = a_img + aoff[s] + (mt / C::SEGS) * I::ROWB + (mt % C::SEGS) * 64;
+        const wsl_u4 ah = *reinterpret_cast<const wsl_u4*>(q), al = *reinterpret_cast<const wsl_u4*>(q + I::HL);
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+          acc[i][j] = WSL_MFMA_F16(ah, bl[j], acc[i][j]);
+          acc[i][j] = WSL_MFMA_F16(al, bh[j], acc[i][j]);
+          acc[i][j] = WSL_MFMA_F16(ah, bh[j], acc[i][j]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: undo the operand scales, bias, float4 stores, BatchNorm partial statistics (tiles and channel blocks are full)
+  const float u1 = sp_pow2(-e_w), u2 = sp_pow2(-e_in);
+  float* red = reinterpret_cast<float*>(a_img);
+  float bsum[C::NT];
+  constexpr int RPW = C::MT / C::SEGS;   // output rows per wave
+  {
+    float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
+      float* yj = yb + (int64_t)j * 16 * HW;
+      float bs = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i) {
+        v4f v = acc[i][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] * u1) * u2 + bias;
+        acc[i][j] = v;
+        *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16) = make_float4(v[0], v[1], v[2], v[3]);
+        bs += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      bsum[j] = bs;
+    }
+  }
+  if constexpr (C::MT * C::NT * 4 <= 32) if (p.bn.part) {
+    float s1[C::NT], s2[C::NT];
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int co = co0 + j * 16 + (lane & 15);
+      const float mean = p.bn.st[co], invstd = p.bn.st[Co + co], sc = p.bn.st[2 * Co + co], sh = p.bn.st[3 * Co + co];
+      const int64_t base = ((int64_t)n * Co + co) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+      BnBwdAcc ba;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i) {
+        bn_bwd_acc4(p.bn, base + (i / C::SEGS) * W + (i % C::SEGS) * 16, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3],
+                    mean, invstd, sc, sh, ba);
+      }
+      bn_bwd_fold(ba, s1[j], s2[j]);
+    }
+    bn_bwd_store<C::NT, CO_T>(p.bn, s1, s2, red, co0, Co, tile_id, nb);
+    return;
+  }
+  if (p.stat_part) {
+    float* red1 = red;
+    float* red2 = red + 4 * CO_T;
+    constexpr float cnt = (float)(TH * TW);
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int col = j * 16 + (lane & 15);
+      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][j][r] - mean_b;
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) {
+        const int col = j * 16 + lane, co = co0 + col;
+        float* dst = p.stat_part + ((int64_t)co * nb + tile_id) * 2;   // [Co][nblk][2]
+        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+      }
+      if (lane == 0 && blockIdx.y == 0) p.stat_cnt[tile_id] = cnt;
+    }
+  }
+}
+
+struct SpPlan {
+  int th, tw, co_t;
+  bool ok;
+};
+// tile shape per layer: 8 x 32 pixels (16 x 16 at the deepest level), the widest output-channel block that still leaves >= 2
+// workgroups per CU
+static SpPlan sp_plan(int N, int H, int W, int Ci, int Co) {
+  SpPlan f{0, 0, 0, false};
+  if (Ci <= 0 || Co <= 0 || (Ci % 16) || (Co % 16) || Ci > kSpMaxC) return f;
+  if (H % 8 == 0 && W % 32 == 0) f.th = 8, f.tw = 32;
+  else if (H % 16 == 0 && W % 16 == 0) f.th = 16, f.tw = 16;
+  else return f;
+  const int64_t tiles = (int64_t)N * (H / f.th) * (W / f.tw);
+  f.co_t = 16;
+  if (Co % 32 == 0) f.co_t = 32;
+  if (Co % 64 == 0 && tiles * (Co / 64) >= 2 * device_cu_count()) f.co_t = 64;
+  f.ok = true;
+  return f;
+}
+
+template <int TH, int TW, int CO_T>
+static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
+  using C = ConvSpCfg<TH, TW, CO_T>;
+  auto kern = conv_sp_kernel<TH, TW, CO_T>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
+  const double px = (double)p.N * p.H * p.W;
+  // issued = the three f16 passes over the tap-padded K (10 / 9)
+  void* tok = prof_begin(is_dgrad ? PF_SP_DGRAD : PF_SP_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
+                         2.0 * px * p.Co * p.Ci * 10 * 3);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("conv_sp_kernel");
+}
+
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+static bool sp_src_ok(const WslSrc& s) {
+  return s.x && aligned16(s.x) && !(s.bs & 3) && (!s.emask || !(reinterpret_cast<uintptr_t>(s.emask) & 3)) && (!s.scale || s.shift);
+}
+
+static int sp_conv_launch(const WslSrc& a, const WslSrc* b, const void* image, const uint32_t* w_amax, const uint32_t* in_amax,
+                          const float* bias, float* y, int64_t y_bs, int N, int H, int W, int Co, int is_dgrad, float* stat_part,
+                          float* stat_cnt, const BnBwdEpi* bn, int* bn_done, void* stream) {
+  ConvSpP p;
+  p.a = to_spsrc(a);
+  p.b = (b && b->C > 0) ? to_spsrc(*b) : SpSrc{};
+  p.img = static_cast<const wsl_u4*>(image), p.w_amax = w_amax, p.in_amax = in_amax;
+  p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
+  const SpPlan f = sp_plan(N, H, W, p.Ci, Co);
+  p.tiles_x = W / f.tw, p.tiles_y = H / f.th;
+  p.stat_part = stat_part, p.stat_cnt = stat_cnt;
+  if (bn && bn->part && f.th * f.tw * f.co_t <= 8192) p.bn = *bn;   // instantiations with <= 32 accumulator registers
+  if (bn_done) *bn_done = p.bn.part ? 1 : 0;
+#define WSL_CASE(TH_, TW_, CO_) \
+  if (f.th == TH_ && f.tw == TW_ && f.co_t == CO_) return launch_conv_sp<TH_, TW_, CO_>(p, is_dgrad, stream);
+  WSL_CASE(8, 32, 16) WSL_CASE(8, 32, 32) WSL_CASE(8, 32, 64) WSL_CASE(16, 16, 16) WSL_CASE(16, 16, 32) WSL_CASE(16, 16, 64)
+#undef WSL_CASE
+  set_error("sp_conv: no kernel for tile %dx%d co_t %d", f.th, f.tw, f.co_t);
+  return WSL_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][ci][tap] = sum_px dy[co][px] * in[ci][px + tap]:  M = 16 output channels, N = 16 input channels, K = 32 pixels of the tile.
+// Both operands come out of channel-innermost tile images through ds_read_b64_tr_b16 (lane = channel, 4 pixels per read); a tap
+// is a slot offset of the input image.  Persistent workgroups over a run of tiles, next tile prefetched into registers.
+//   CB = 32: a 32 x 32 channel block; wave w owns the (co tile w >> 1, ci tile w & 1) pair over every pixel of a tile;
+//   CB = 16: one pair; the four waves take every fourth K-step and write four partials of their own (4 * nsplit splits).
+struct WgradSpP {
+  SpSrc a, b;
+  const float* dy;
+  int64_t dy_bs;
+  const uint32_t* dy_amax;
+  float* part_dw;   // [splits][9][Co][Ci]
+  float* part_db;   // [splits][Co]
+  int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, ci_blocks;
+};
+
+template <int TH, int TW, int CB>
+struct WgradSpCfg {
+  using In = SpImg<TH + 2, (TW + 8) / 4, CB / 8, (TW + 8) / 4>;
+  using Dy = SpImg<TH, TW / 4, CB / 8, TW / 4>;
+  static constexpr int KS = TH * TW / 32, KROWS = 32 / TW;      // K-steps per tile; tile rows per K-step
+  static constexpr size_t SMEM = In::BYTES + Dy::BYTES + sizeof(float) * 3 * kSpMaxC;
+  static_assert(TW == 16 || TW == 32, "a K-step is one row of 32 pixels or two rows of 16");
+  static_assert(CB == 32 || KS % 4 == 0, "the one-pair form splits the K-steps over the four waves");
+};
+
+template <int TH, int TW, int CB>
+__global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
+  using C = WgradSpCfg<TH, TW, CB>;
+  using II = typename C::In;
+  using ID = typename C::Dy;
+  WSL_DYN_SMEM(smem);
+  unsigned char* in_img = smem;
+  unsigned char* dy_img = smem + II::BYTES;
+  float2* tab = reinterpret_cast<float2*>(smem + II::BYTES + ID::BYTES);
+  float* cm_l = reinterpret_cast<float*>(tab + kSpMaxC);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cob = blockIdx.x / p.ci_blocks, cib = blockIdx.x - cob * p.ci_blocks;
+  const int split = blockIdx.y;
+  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co, HW = H * W;
+  const int ci0 = cib * CB, co0 = cob * CB;
+  const bool ina = ci0 < p.a.C;                           // the block's input channels live in one source
+  const SpSrc& src = ina ? p.a : p.b;
+  const int chb = ina ? ci0 : ci0 - p.a.C;
+  const int e_dy = sp_exp_of(*p.dy_amax);
+  const float dy_mul = sp_pow2(e_dy), act_mul = sp_pow2(WSL_SP_ACT_EXP);
+
+  for (int c = tid; c < CB; c += kThreads) {
+    tab[c] = src.scale ? make_float2(src.scale[chb + c] * act_mul, src.shift[chb + c] * act_mul) : make_float2(1.f, 0.f);
+    cm_l[c] = 1.f;   // (per sample: refreshed with every tile below)
+  }
+
+  // operand addresses of K-step 0: supplier lane s = lane & 15 of a 16-lane group hands out pixel (s >> 2) (+ 4 for the second
+  // read) of the group's eight, channels 4 (s & 3) .. + 3 of the 16-channel tile
+  const int cot = CB == 32 ? wave >> 1 : 0, cit = CB == 32 ? wave & 1 : 0;
+  const int sup = lane & 15, grp = lane >> 4;
+  int dyo[2], ino[2][3];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int pk = 8 * grp + 4 * rd + (sup >> 2);
+    const int row = pk / TW, col = pk % TW, o = (sup & 3) >> 1, bo = (sup & 1) * 8;
+    dyo[rd] = (2 * cot + o) * ID::PLANE + row * ID::ROWB + sp_slot<ID>(col) + bo;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) ino[rd][kx] = (2 * cit + o) * II::PLANE + row * II::ROWB + sp_slot<II>(col + kx + 3) + bo;
+  }
+
+  v4f acc[9], accdb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  const bool want_db = p.part_db != nullptr && cib == 0 && cit == 0;
+  const wsl_u4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};   // f16 1.0
+
+  SpTasks<II::NR> tki;
+  SpTasks<ID::NR> tkd;
+  SpRegs<II::NR> pri;
+  SpRegs<ID::NR> prd;
+  int n = 0;
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    const int tx = t % p.tiles_x, r = t / p.tiles_x;
+    const int ty = r % p.tiles_y;
+    n = r / p.tiles_y;
+    sp_tasks_init<II>(tki, tid, ty * TH - 1, tx * TW - 4, H, W);
+    sp_tasks_init<ID>(tkd, tid, ty * TH, tx * TW, H, W);
+    sp_issue<II>(tki, pri, src.x + n * src.bs, src.emask ? src.emask + (int64_t)n * src.C * HW : nullptr, chb, HW);
+    sp_issue<ID>(tkd, prd, p.dy + n * p.dy_bs, nullptr, co0, HW);
+  };
+  int t = split;
+  if (t < p.items) issue(t);
+  __syncthreads();   // tab visible
+  while (t < p.items) {
+    if (src.cmask && tid < CB) cm_l[tid] = src.cmask[(int64_t)n * src.C + chb + tid];
+    if (src.cmask) __syncthreads();
+    sp_commit<II>(tki, pri, in_img, tab, cm_l, 0, src.scale != nullptr, src.emask != nullptr, src.cmask != nullptr, src.es,
+                  src.scale == nullptr, act_mul, true);
+    sp_commit<ID>(tkd, prd, dy_img, tab, cm_l, 0, false, false, false, 1.f, true, dy_mul, true);
+    __syncthreads();
+    const int tn = t + p.nsplit;
+    if (tn < p.items) issue(tn);   // in flight during the MFMA phase
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (CB == 16 && (ks & 3) != wave) continue;
+      const int dk = ks * C::KROWS * ID::ROWB, ik = ks * C::KROWS * II::ROWB;
+      const wsl_u2 a0 = WSL_DS_READ_TR16(dy_img + dyo[0] + dk), a1 = WSL_DS_READ_TR16(dy_img + dyo[1] + dk);
+      const wsl_u2 a2 = WSL_DS_READ_TR16(dy_img + ID::HL + dyo[0] + dk), a3 = WSL_DS_READ_TR16(dy_img + ID::HL + dyo[1] + dk);
+      const wsl_u4 ah = {a0[0], a0[1], a1[0], a1[1]}, al = {a2[0], a2[1], a3[0], a3[1]};
+      if (want_db) {
+        accdb = WSL_MFMA_F16(al, ones, accdb);
+        accdb = WSL_MFMA_F16(ah, ones, accdb);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const unsigned char* q = in_img + ik + ky * II::ROWB;
+        const wsl_u2 b0 = WSL_DS_READ_TR16(q + ino[0][kx]), b1 = WSL_DS_READ_TR16(q + ino[1][kx]);
+        const wsl_u2 b2 = WSL_DS_READ_TR16(q + II::HL + ino[0][kx]), b3 = WSL_DS_READ_TR16(q + II::HL + ino[1][kx]);
+        const wsl_u4 bh = {b0[0], b0[1], b1[0], b1[1]}, bl = {b2[0], b2[1], b3[0], b3[1]};
+        acc[tap] = WSL_MFMA_F16(ah, bl, acc[tap]);
+        acc[tap] = WSL_MFMA_F16(al, bh, acc[tap]);
+        acc[tap] = WSL_MFMA_F16(ah, bh, acc[tap]);
+      }
+    }
+    __syncthreads();
+    t = tn;
+  }
+
+  // ---- partials: D[row = co][col = ci]; lane holds rows 4 (lane >> 4) + r of column lane & 15
+  const float u1 = sp_pow2(-e_dy), u2 = sp_pow2(-WSL_SP_ACT_EXP);
+  const int sidx = CB == 32 ? split : split * 4 + wave;
+  const int64_t E = (int64_t)9 * Co * Ci;
+  float* pdw = p.part_dw + (int64_t)sidx * E;
+  const int co = co0 + cot * 16 + 4 * grp, ci = ci0 + cit * 16 + sup;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pdw[((int64_t)tap * Co + co + r) * Ci + ci] = (acc[tap][r] * u1) * u2;
+  if (want_db && sup == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p.part_db[(int64_t)sidx * Co + co + r] = accdb[r] * u1;
+  }
+}
+
+struct WgSpPlan {
+  int th, tw, cb, nsplit, splits, items, tiles_x, tiles_y, co_blocks, ci_blocks;
+  bool ok;
+};
+static WgSpPlan wgrad_sp_plan(int N, int H, int W, int Ca, int Cb, int Co) {
+  WgSpPlan g{};
+  const int Ci = Ca + Cb;
+  if (Ci <= 0 || Co <= 0 || (Ci % 16) || (Co % 16) || (Cb && (Ca % 16))) return g;
+  if (H % 4 == 0 && W % 32 == 0) g.th = 4, g.tw = 32;
+  else if (H % 8 == 0 && W % 16 == 0) g.th = 8, g.tw = 16;
+  else return g;
+  g.cb = (Co % 32 == 0 && Ci % 32 == 0 && (Cb == 0 || Ca % 32 == 0)) ? 32 : 16;
+  g.tiles_x = W / g.tw, g.tiles_y = H / g.th, g.items = N * g.tiles_x * g.tiles_y;
+  g.co_blocks = Co / g.cb, g.ci_blocks = Ci / g.cb;
+  int want = 2 * device_cu_count() / (g.co_blocks * g.ci_blocks);     // two persistent workgroups per CU
+  if (want < 1) want = 1;
+  g.nsplit = g.items < want ? g.items : want;
+  g.splits = g.cb == 32 ? g.nsplit : 4 * g.nsplit;
+  g.ok = true;
+  return g;
+}
+
+template <int TH, int TW, int CB>
+static int launch_wgrad_sp(WgradSpP& p, const WgSpPlan& g, void* stream) {
+  using C = WgradSpCfg<TH, TW, CB>;
+  auto kern = wgrad_sp_kernel<TH, TW, CB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    attr_done = true;
+  }
+  dim3 grid(g.co_blocks * g.ci_blocks, g.nsplit);
+  const double px = (double)p.N * p.H * p.W;
+  void* tok = prof_begin(PF_SP_WGRAD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream, 2.0 * px * p.Co * p.Ci * 9 * 3);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  prof_end(tok, stream);
+  return check_launch("wgrad_sp_kernel");
+}
+
+}  // namespace wsl
+
+using namespace wsl;
+
+extern "C" int wsl_sp_conv2d_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int N, int H, int W, int Co, int ks) {
+  if (!a || ks != 3 || N <= 0 || H <= 0 || W <= 0 || a->C <= 0) return 0;
+  const int Cb = (b && b->C > 0) ? b->C : 0;
+  if (Cb && (a->C % 16)) return 0;                       // a 16-channel chunk never straddles the two sources
+  if (!sp_src_ok(*a) || (Cb && !sp_src_ok(*b))) return 0;
+  if (y && (!aligned16(y) || (y_bs & 3))) return 0;
+  if ((int64_t)(a->C > Cb ? a->C : Cb) * H * W >= (int64_t(1) << 31) || (int64_t)Co * H * W >= (int64_t(1) << 31)) return 0;
+  return sp_plan(N, H, W, a->C + Cb, Co).ok ? 1 : 0;
+}
+
+extern "C" size_t wsl_sp_weight_image_bytes(int Co, int Ci) {
+  return Co > 0 && Ci > 0 && Ci % 16 == 0 ? (size_t)40 * Ci * Co : 0;
+}
+
+extern "C" int wsl_sp_pack_weights(const float* w, void* image, uint32_t* w_amax, int Co, int Ci, int dgrad, void* stream) {
+  WSL_REQUIRE(w && image && w_amax && Co > 0 && Ci > 0 && Ci % 16 == 0 && aligned16(image), "sp_pack_weights: bad args (Ci %% 16 == 0)");
+  PackTable t;
+  t.n = 1;
+  // the table entry describes the RAW tensor [e.Co][e.Ci][3][3]; in data-gradient mode the raw tensor is [Ci][Co][3][3]
+  t.e[0] = PackEntry{0, dgrad ? Ci : Co, dgrad ? Co : Ci, 9, 0};
+  SpPackOffsets io{};
+  WSL_LAUNCH(sp_amax_table_kernel, dim3(1), dim3(kThreads), 0, stream, t, w, w_amax);
+  // one image per call: route it through the slot of its direction
+  WSL_LAUNCH(sp_pack_table_kernel, dim3(16, 1, 1), dim3(kThreads), 0, stream, t, io, w, static_cast<unsigned char*>(image),
+             static_cast<unsigned char*>(image), w_amax, dgrad ? 1 : 0);
+  return check_launch("sp_pack_table_kernel");
+}
+
+extern "C" int wsl_sp_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co) {
+  const SpPlan f = sp_plan(N, H, W, Ci, Co);
+  return f.ok ? N * (H / f.th) * (W / f.tw) : 0;
+}
+
+extern "C" int wsl_sp_conv2d_fwd(const WslSrc* a, const WslSrc* b, const void* image, const uint32_t* w_amax, const uint32_t* in_amax,
+                                 const float* bias, float* y, int64_t y_bs, int N, int H, int W, int Co, float* stat_part,
+                                 float* stat_cnt, void* stream) {
+  WSL_REQUIRE(a && image && w_amax && y, "sp_conv2d_fwd: null argument");
+  WSL_REQUIRE((stat_part == nullptr) == (stat_cnt == nullptr), "sp_conv2d_fwd: stat_part and stat_cnt come together");
+  WSL_REQUIRE(y_bs >= (int64_t)Co * H * W, "sp_conv2d_fwd: y batch stride too small");
+  WSL_REQUIRE(wsl_sp_conv2d_ok(a, b, y, y_bs, N, H, W, Co, 3), "sp_conv2d_fwd: layer not eligible (wsl_sp_conv2d_ok)");
+  return sp_conv_launch(*a, b, image, w_amax, in_amax, bias, y, y_bs, N, H, W, Co, in_amax != nullptr, stat_part, stat_cnt, nullptr,
+                        nullptr, stream);
+}
+
+extern "C" int wsl_sp_conv2d_dgrad_bn(const WslSrc* dy, const uint32_t* dy_amax, const void* image, const uint32_t* w_amax, float* g,
+                                      int64_t g_bs, int N, int H, int W, int Co, const float* bn_y, const float* bn_st,
+                                      const uint8_t* bn_emask, float bn_emask_scale, float* bn_part, int* fused, void* stream) {
+  WSL_REQUIRE(dy && dy_amax && image && w_amax && g && bn_y && bn_st && bn_part && fused, "sp_conv2d_dgrad_bn: null argument");
+  WSL_REQUIRE(wsl_sp_conv2d_ok(dy, nullptr, g, g_bs, N, H, W, Co, 3), "sp_conv2d_dgrad_bn: layer not eligible (wsl_sp_conv2d_ok)");
+  BnBwdEpi e;
+  e.y = bn_y, e.st = bn_st, e.emask = bn_emask, e.es = bn_emask_scale, e.part = bn_part;
+  if (g_bs != (int64_t)Co * H * W || !aligned16(bn_y) || (bn_emask && (reinterpret_cast<uintptr_t>(bn_emask) & 3))) e.part = nullptr;
+  return sp_conv_launch(*dy, nullptr, image, w_amax, dy_amax, nullptr, g, g_bs, N, H, W, Co, 1, nullptr, nullptr, &e, fused, stream);
+}
+
+extern "C" size_t wsl_sp_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  const WgSpPlan g = wgrad_sp_plan(N, H, W, Ci, 0, Co);
+  if (!g.ok) return 0;
+  // upper bound over both channel blockings (how Ci splits over two sources may lower the block to 16): 4 partials per
+  // persistent workgroup, at most two workgroups per CU
+  const int want = 2 * device_cu_count();
+  const size_t splits = (size_t)4 * (g.items < want ? g.items : want);
+  return sizeof(float) * splits * ((size_t)9 * Co * Ci + Co);
+}
+
+extern "C" int wsl_sp_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, const uint32_t* dy_amax,
+                                           float* dw, float* db, int N, int H, int W, int Co, void* ws, size_t ws_bytes,
+                                           WslWgradPending* pending, void* stream) {
+  WSL_REQUIRE(a && dy && dy_amax && dw && ws && pending, "sp_conv2d_wgrad_partial: null argument");
+  WSL_REQUIRE(wsl_sp_conv2d_ok(a, b, nullptr, 0, N, H, W, Co, 3) && aligned16(dy) && !(dy_bs & 3) && dy_bs >= (int64_t)Co * H * W,
+              "sp_conv2d_wgrad_partial: layer not eligible (wsl_sp_conv2d_ok, float4-aligned dy)");
+  const int Cb = (b && b->C > 0) ? b->C : 0, Ci = a->C + Cb;
+  const WgSpPlan g = wgrad_sp_plan(N, H, W, a->C, Cb, Co);
+  WSL_REQUIRE(g.ok, "sp_conv2d_wgrad_partial: no tile shape for %d x %d", H, W);
+  const size_t need = sizeof(float) * (size_t)g.splits * ((size_t)9 * Co * Ci + Co);
+  if (ws_bytes < need) {
+    set_error("sp_conv2d_wgrad_partial: workspace %zu < %zu", ws_bytes, need);
+    return WSL_EWORKSPACE;
+  }
+  WgradSpP p;
+  p.a = to_spsrc(*a);
+  p.b = Cb ? to_spsrc(*b) : SpSrc{};
+  p.dy = dy, p.dy_bs = dy_bs, p.dy_amax = dy_amax;
+  p.part_dw = static_cast<float*>(ws);
+  p.part_db = db ? p.part_dw + (size_t)g.splits * 9 * Co * Ci : nullptr;
+  p.N = N, p.H = H, p.W = W, p.Ci = Ci, p.Co = Co;
+  p.tiles_x = g.tiles_x, p.tiles_y = g.tiles_y, p.items = g.items, p.nsplit = g.nsplit, p.ci_blocks = g.ci_blocks;
+  int rc = WSL_EUNSUPPORTED;
+  if (g.th == 4 && g.tw == 32 && g.cb == 32) rc = launch_wgrad_sp<4, 32, 32>(p, g, stream);
+  else if (g.th == 4 && g.tw == 32 && g.cb == 16) rc = launch_wgrad_sp<4, 32, 16>(p, g, stream);
+  else if (g.th == 8 && g.tw == 16 && g.cb == 32) rc = launch_wgrad_sp<8, 16, 32>(p, g, stream);
+  else if (g.th == 8 && g.tw == 16 && g.cb == 16) rc = launch_wgrad_sp<8, 16, 16>(p, g, stream);
+  if (rc) return rc;
+  pending->part_dw = p.part_dw, pending->part_db = p.part_db, pending->dw = dw, pending->db = db;
+  pending->Co = Co, pending->Ci = Ci, pending->KK = 9, pending->nsplit = g.splits;
+  return WSL_OK;
+}

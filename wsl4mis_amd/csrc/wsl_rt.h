@@ -3,6 +3,7 @@
 // -DWSL_HOST_EMUL) compiles the very same sources to check kernel logic on a machine without a GPU.
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/wsl_hip.h"
 #include "wsl_debug.h"
@@ -19,6 +20,10 @@ typedef wsl_v4f v4f;
 #define WSL_LDS_DMA16(gsrc, lds_wave_base) wsl_emu_lds_dma16(gsrc, lds_wave_base)
 #define WSL_WAIT_ALL()
 #define WSL_SCHED_BARRIER()
+typedef wsl_emu_u4 wsl_u4;
+typedef wsl_emu_u2 wsl_u2;
+#define WSL_MFMA_F16(a, b, c) wsl_emu_mfma16x32_f16(a, b, c)
+#define WSL_DS_READ_TR16(p) wsl_emu_ds_read_tr16(p)
 #else
 #include <hip/hip_runtime.h>
 #define WSL_LAUNCH(kern, grid, block, smem, stream, ...) \
@@ -40,6 +45,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define WSL_WAIT_ALL() __builtin_amdgcn_s_waitcnt(0)
 // keeps the instruction scheduler from moving LDS reads / MFMAs across a software-pipeline stage boundary
 #define WSL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8 (l >> 4) + e], B[k = 8 (l >> 4) + e][j = l & 15] (8 halves = 4 VGPRs each, passed as
+// four 32-bit words), D as WSL_MFMA16 (probed: tools/probe_sp.hip).  Products exact in fp32, fp32 accumulation, f16 subnormals kept.
+typedef uint32_t wsl_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t wsl_u2 __attribute__((ext_vector_type(2)));
+typedef _Float16 wsl_h8 __attribute__((ext_vector_type(8)));
+typedef short wsl_s4 __attribute__((ext_vector_type(4)));
+#define WSL_MFMA_F16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wsl_h8, (a)), __builtin_bit_cast(wsl_h8, (b)), (c), 0, 0, 0)
+// ds_read_b64_tr_b16: inside a group of 16 lanes, lane i receives as element e the (i & 3)-th half of the four contiguous halves
+// at the (8-byte aligned) LDS address supplied by lane 4 e + (i >> 2) of the group -- a 4 x 16 block of halves read row-wise,
+// delivered column-wise (probed: tools/probe_sp.hip)
+#define WSL_DS_READ_TR16(p) \
+  __builtin_bit_cast(wsl_u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wsl_s4*)(p)))
 #endif
 
 // Tuning / ablation / probe switches exist only in the EXPERIMENTS build (build.sh exp -> tools/exp/libwslhip_exp.so, and
@@ -66,7 +84,7 @@ void set_error(const char* fmt, ...);
 enum ProfFam {
   PF_CONV_FWD = 0, PF_CONV_DGRAD = 1, PF_WGRAD_WINO = 2, PF_WGRAD_REDUCE = 3, PF_GATEDCRF = 4, PF_OTHER = 5, PF_WINO_FWD = 6,
   PF_WINO_DGRAD = 7, PF_WGRAD_DIRECT = 8, PF_BN_BWD = 9, PF_BN_FINALIZE = 10, PF_BILINEAR = 11, PF_POOL_FANIN = 12,
-  PF_LOSS_HEAD = 13, PF_SGD = 14, PF_PREP = 15
+  PF_LOSS_HEAD = 13, PF_SGD = 14, PF_PREP = 15, PF_SP_FWD = 16, PF_SP_DGRAD = 17, PF_SP_WGRAD = 18, PF_SPARE = 19
 };
 void* prof_begin(int fam, double flops, double bytes, void* stream, double issued = -1.0);
 void prof_end(void* tok, void* stream);
@@ -189,6 +207,43 @@ __device__ __forceinline__ void wino_aya_pk(wsl_v2f r0, wsl_v2f r1, wsl_v2f& q1,
 __device__ __forceinline__ float wino_pick(const wsl_v2f (&a)[4], const wsl_v2f (&b)[4], int xi) {
   const int i = xi >> 2, c = xi & 3;
   return c == 0 ? a[i][0] : c == 3 ? a[i][1] : c == 1 ? b[i][0] : b[i][1];
+}
+
+// ---- split-precision operands (wsl_convsp.hip): x * 2^e = hi + lo, hi = the scaled value as f16 rounded TOWARD ZERO (a finite
+// overflow saturates at 65504 instead of turning into inf), lo = the exact remainder as f16 (round to nearest): 21-22 significant
+// bits, f16 subnormals included.  Two values per 32-bit word (element 0 in the low half).
+#ifdef WSL_HOST_EMUL
+__device__ __forceinline__ uint32_t sp_pkrtz(float x0, float x1) { return (uint32_t)wsl_emu_f2h_rtz(x0) | ((uint32_t)wsl_emu_f2h_rtz(x1) << 16); }
+__device__ __forceinline__ uint32_t sp_pkrne(float x0, float x1) { return (uint32_t)wsl_emu_f2h_rne(x0) | ((uint32_t)wsl_emu_f2h_rne(x1) << 16); }
+__device__ __forceinline__ float sp_h0(uint32_t u) { return wsl_emu_h2f((uint16_t)u); }
+__device__ __forceinline__ float sp_h1(uint32_t u) { return wsl_emu_h2f((uint16_t)(u >> 16)); }
+#else
+typedef _Float16 wsl_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sp_pkrtz(float x0, float x1) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0, x1)); }
+__device__ __forceinline__ uint32_t sp_pkrne(float x0, float x1) {
+  const wsl_h2 v = {(_Float16)x0, (_Float16)x1};      // v_cvt_pk_f16_f32
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float sp_h0(uint32_t u) { return (float)__builtin_bit_cast(wsl_h2, u)[0]; }
+__device__ __forceinline__ float sp_h1(uint32_t u) { return (float)__builtin_bit_cast(wsl_h2, u)[1]; }
+#endif
+__device__ __forceinline__ void sp_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  hi = sp_pkrtz(x0, x1);
+  lo = sp_pkrne(x0 - sp_h0(hi), x1 - sp_h1(hi));
+}
+// power-of-two operand scale from the bit pattern of max |x| (a non-negative float): max * 2^e lands in [2^14, 2^15).  The same
+// function runs where an operand is split and where the product is unscaled, so the pair always cancels exactly.
+__host__ __device__ __forceinline__ int sp_exp_of(uint32_t amax_bits) {
+  const int be = (int)((amax_bits >> 23) & 0xffu);
+  if (be == 0) return 0;                         // all-zero (or subnormal) tensor
+  const int e = 14 - (be - 127);
+  return e > 100 ? 100 : (e < -100 ? -100 : e);  // 2^e and 2^-e stay normal floats
+}
+__host__ __device__ __forceinline__ float sp_pow2(int e) {
+  const uint32_t u = (uint32_t)(e + 127) << 23;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
 }
 
 // Sum over the 64 lanes of a wave; every lane gets the total.
