@@ -187,9 +187,12 @@ int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const flo
  * cannot reach that, and a larger value saturates instead of overflowing.  Results are independent of the scale chosen as long as
  * nothing under- or overflows.  Eligible layers (wsl_sp_conv2d_ok): ks 3, (Ca + Cb) % 16 == 0 (Ca % 16 == 0 with two sources),
  * Co % 16 == 0, (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0), float4-aligned tensors.
- * An `amax` argument is the DEVICE address of one uint32: the bit pattern of a non-negative float, merged with an integer atomic
- * max (order-independent, so results stay run-to-run reproducible); the caller zeroes it before the producer runs. */
+ * A `w_amax` argument is the DEVICE address of one uint32, the bit pattern of a non-negative float; a `dy_amax` / `in_amax`
+ * argument is the device address of WSL_SP_AMAX_SLOTS such words whose maximum is the tensor's (the producer's workgroups spread
+ * their integer atomic max over the slots -- order-independent, so results stay run-to-run reproducible); the caller zeroes the
+ * words before the producer runs. */
 #define WSL_SP_ACT_EXP 4
+#define WSL_SP_AMAX_SLOTS 64
 int wsl_sp_conv2d_ok(const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int N, int H, int W, int Co, int ks);
 /* one weight image (hi and lo halves in the kernels' operand order; the 9 taps padded to 10): 40 * Ci * Co bytes */
 size_t wsl_sp_weight_image_bytes(int Co, int Ci);
@@ -356,6 +359,10 @@ typedef struct WslNetDesc {
   int32_t in_chns, n_class;
   int32_t n_dec;       /* 1 = 'unet', 2 = 'unet_cct' (main + aux decoder) */
   int32_t N, H, W;     /* H, W multiples of 16 */
+  int32_t precision;   /* 0 = fp32 kernels (default); 1 = the eligible 3x3 layers on the split-precision path (f16 hi / lo
+                          operands, three MFMA passes, fp32 accumulate -- "split-precision conv path" above); same arenas, same
+                          results to fp32 round-off, a larger workspace (wsl_net_ws_bytes knows) */
+  int32_t _pad;
 } WslNetDesc;
 
 typedef struct WslNetEntry {

@@ -7,8 +7,9 @@ from detinit import det_state, sample_index
 from wsl4mis_amd import _lib
 
 
-def net_desc(net, N, H, W, in_chns=1, n_class=4):
-    return _lib.WslNetDesc(in_chns, n_class, 2 if net == "unet_cct" else 1, N, H, W)
+def net_desc(net, N, H, W, in_chns=1, n_class=4, precision=0):
+    """precision 1: the eligible 3x3 layers on the split-precision path (f16 hi / lo operands, three MFMA passes)"""
+    return _lib.WslNetDesc(in_chns, n_class, 2 if net == "unet_cct" else 1, N, H, W, precision, 0)
 
 
 def entries(lib, d):

@@ -11,10 +11,10 @@ from netutil import check_grads, det_arenas, grad_l2, net_desc, ptr_array, stric
 TOL = 1e-4
 
 
-def run_net(be, tag, net, full=True):
+def run_net(be, tag, net, full=True, precision=0):
     g = golden(f"g2_{tag}")
     N, H, W = (int(v) for v in g["cfg"])
-    d = net_desc(net, N, H, W)
+    d = net_desc(net, N, H, W, precision=precision)
     params, bufs, nbt, ents = det_arenas(be.lib, d, 2022)
     dp, db, dn = be.arr(params), be.arr(bufs), be.arr(nbt)
     x, lab = be.arr(g["x"]), be.arr(g["label"])
@@ -100,6 +100,18 @@ def test_unet_cct_32_gpu():
 def test_unet_cct_larger_gpu(tag):
     from conftest import get_backend
     run_net(get_backend("hip"), tag, "unet_cct")
+
+
+# ---- the same fixtures on the split-precision conv path (f16 hi / lo operands, three MFMA passes, fp32 accumulate): same criteria
+def test_unet_cct_16_split_emul_and_gpu(be):
+    run_net(be, "cct16", "unet_cct", full=(be.name == "hip"), precision=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,net", [("unet32", "unet"), ("cct32", "unet_cct"), ("cct64", "unet_cct"), ("cct48x80", "unet_cct")])
+def test_net_split_gpu(tag, net):
+    from conftest import get_backend
+    run_net(get_backend("hip"), tag, net, precision=1)
 
 
 def test_layout_matches_reference_state_dict(be):

@@ -25,12 +25,13 @@ CASES = [  # N, H, W, Ca, Cb, Co, transforms on a
 
 
 def _amax_bits(be):
-    return be.zeros((4,), np.int64)     # 32 bytes, 16-byte aligned; the library writes / reads the first uint32
+    return be.zeros((4,), np.int64)     # one max |w| word (the library writes / reads the first uint32)
 
 
 def _set_amax(be, slot, value):
-    a = np.zeros(4, np.int64)
-    a.view(np.uint32)[0] = np.float32(value).view(np.uint32)
+    """a tensor's maximum as its producer leaves it: WSL_SP_AMAX_SLOTS (64) partial maxima, here one of them non-zero"""
+    a = np.zeros(32, np.int64)
+    a.view(np.uint32)[37] = np.float32(value).view(np.uint32)
     return be.arr(a)
 
 

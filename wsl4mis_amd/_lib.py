@@ -32,7 +32,7 @@ class WslProfRow(C.Structure):
 
 class WslNetDesc(C.Structure):
     _fields_ = [("in_chns", C.c_int32), ("n_class", C.c_int32), ("n_dec", C.c_int32), ("N", C.c_int32),
-                ("H", C.c_int32), ("W", C.c_int32)]
+                ("H", C.c_int32), ("W", C.c_int32), ("precision", C.c_int32), ("_pad", C.c_int32)]
 
 
 class WslWgradPending(C.Structure):

@@ -339,19 +339,39 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce4_kernel(BnBwdP p, float*
   }
 }
 
-__global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const float* coef, float* dy) {
+// max |v| over the workgroup's values into *amax: the bit patterns of non-negative floats order like the floats, and an integer
+// atomic max is order-independent -- what the split-precision consumers of dy scale their operand with (wsl_convsp.hip)
+// (one atomic per workgroup, spread over WSL_SP_AMAX_SLOTS words: see sp_amax_fold() in wsl_rt.h)
+__device__ __forceinline__ void amax_commit(float m, uint32_t* amax) {
+  __shared__ float wmax[4];
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    uint32_t u;
+    memcpy(&u, &m, 4);
+    if (u) atomicMax(amax + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & (WSL_SP_AMAX_SLOTS - 1)), u);
+  }
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const float* coef, float* dy, uint32_t* amax) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float mean = p.mean[c], invstd = p.invstd[c];
   const float sc = p.gamma[c] * invstd, sh = fmaf(-mean, sc, p.beta[c]);
   const float c1 = coef[2 * c], c2 = coef[2 * c + 1];
   const int base = blockIdx.x * kChunk;
+  float m = 0.f;
   for (int i = base + 4 * threadIdx.x; i < base + kChunk && i < p.HW; i += 4 * kThreads) {
     float d[4], xh[4];
     bn_dz4(p, n, c, i, sc, sh, mean, invstd, d, xh);
-    *reinterpret_cast<float4*>(dy + ((int64_t)n * p.C + c) * p.HW + i) =
-        make_float4(sc * (d[0] - c1 - xh[0] * c2), sc * (d[1] - c1 - xh[1] * c2), sc * (d[2] - c1 - xh[2] * c2),
-                    sc * (d[3] - c1 - xh[3] * c2));
+    const float4 v = make_float4(sc * (d[0] - c1 - xh[0] * c2), sc * (d[1] - c1 - xh[1] * c2), sc * (d[2] - c1 - xh[2] * c2),
+                                 sc * (d[3] - c1 - xh[3] * c2));
+    *reinterpret_cast<float4*>(dy + ((int64_t)n * p.C + c) * p.HW + i) = v;
+    if (amax) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  if (amax) amax_commit(m, amax);
 }
 
 // part: [nblk][C][2] (sb = C, sc = 1: the stand-alone reduction pass and the fan-in kernel) or [C][nblk][2] (sb = 1, sc = nblk:
@@ -382,17 +402,21 @@ __global__ __launch_bounds__(256) void bnact_bwd_finalize_kernel(const float* pa
   }
 }
 
-__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(BnBwdP p, const float* coef, float* dy) {
+__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(BnBwdP p, const float* coef, float* dy, uint32_t* amax) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float mean = p.mean[c], invstd = p.invstd[c];
   const float sc = p.gamma[c] * invstd, sh = fmaf(-mean, sc, p.beta[c]);
   const float c1 = coef[2 * c], c2 = coef[2 * c + 1];
   const int base = blockIdx.x * kChunk;
+  float m = 0.f;
   for (int i = base + threadIdx.x; i < base + kChunk && i < p.HW; i += kThreads) {
     float xh;
     const float d = bn_dz(p, n, c, i, sc, sh, mean, invstd, &xh);
-    dy[((int64_t)n * p.C + c) * p.HW + i] = sc * (d - c1 - xh * c2);
+    const float v = sc * (d - c1 - xh * c2);
+    dy[((int64_t)n * p.C + c) * p.HW + i] = v;
+    m = fmaxf(m, fabsf(v));
   }
+  if (amax) amax_commit(m, amax);
 }
 
 // ------------------------------------------------------------------------------------------------ bilinear x2
@@ -694,10 +718,10 @@ extern "C" size_t wsl_bnact_bwd_ws_bytes(int N, int C, int H, int W) {
   return sizeof(float) * ((size_t)N * cdiv(H * W, 256) * C * 2 + 2 * (size_t)C);
 }
 
-extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
-                             const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
-                             float* dgamma, float* dbeta, int N, int C, int H, int W, void* ws, size_t ws_bytes,
-                             void* stream) {
+extern "C" int wsl_bnact_bwd_amax(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                                  float* dgamma, float* dbeta, int N, int C, int H, int W, void* ws, size_t ws_bytes,
+                                  uint32_t* dy_amax, void* stream) {
   WSL_REQUIRE(g && y && mean && invstd && gamma && beta && dy && ws, "bnact_bwd: null argument");
   WSL_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "bnact_bwd: bad shape");
   if (ws_bytes < wsl_bnact_bwd_ws_bytes(N, C, H, W)) {
@@ -718,15 +742,23 @@ extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const
   else WSL_LAUNCH(bnact_bwd_reduce_kernel, grid, dim3(kThreads), 0, stream, p, part);
   WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, N * p.chunks, C, (int64_t)C, (int64_t)1,
              (double)N * H * W, dgamma, dbeta, coef);
-  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
-  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
+  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, dy_amax);
+  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, dy_amax);
   return check_launch("bnact_bwd");
 }
 
-extern "C" int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
-                                    const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
-                                    float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
-                                    int channel_major, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                             float* dgamma, float* dbeta, int N, int C, int H, int W, void* ws, size_t ws_bytes,
+                             void* stream) {
+  return wsl_bnact_bwd_amax(g, g_bs, y, mean, invstd, gamma, beta, emask, emask_scale, dy, dgamma, dbeta, N, C, H, W, ws, ws_bytes,
+                            nullptr, stream);
+}
+
+extern "C" int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                                         float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
+                                         int channel_major, void* ws, size_t ws_bytes, uint32_t* dy_amax, void* stream) {
   WSL_REQUIRE(g && y && mean && invstd && gamma && beta && dy && ws && part, "bnact_bwd_finish: null argument");
   WSL_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && nblk > 0, "bnact_bwd_finish: bad shape");
   WSL_REQUIRE(ws_bytes >= sizeof(float) * 2 * (size_t)C, "bnact_bwd_finish: workspace needs 2 * C floats");
@@ -740,9 +772,17 @@ extern "C" int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y
   WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, nblk, C,
              channel_major ? (int64_t)1 : (int64_t)C, channel_major ? (int64_t)nblk : (int64_t)1, (double)N * H * W, dgamma, dbeta,
              coef);
-  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
-  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy);
+  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, dy_amax);
+  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, dy_amax);
   return check_launch("bnact_bwd_finish");
+}
+
+extern "C" int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                                    float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
+                                    int channel_major, void* ws, size_t ws_bytes, void* stream) {
+  return wsl_bnact_bwd_finish_amax(g, g_bs, y, mean, invstd, gamma, beta, emask, emask_scale, dy, dgamma, dbeta, N, C, H, W, part,
+                                   nblk, channel_major, ws, ws_bytes, nullptr, stream);
 }
 
 extern "C" int wsl_feat_grad_combine_blocks(int N, int H, int W) {

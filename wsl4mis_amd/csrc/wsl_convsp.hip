@@ -158,13 +158,14 @@ __device__ __forceinline__ int sp_slot(int c) { return ((c & 3) * I::P + (c >> 2
 // ------------------------------------------------------------------------------------------------ weight images
 // image (one per layer and direction), in 16-byte pieces of 8 halves:  [chunk = ci / 16][hl][kstep 0..4][g 0..3][co][8]
 //   k-group g of K-step s holds tap 2 s + (g >> 1), input channels 16 chunk + 8 (g & 1) .. + 7; tap 9 does not exist: zeros.
+// (amax zeroed by the caller; blockIdx.y = table entry, a few workgroups per layer merged with an atomic max)
 __global__ __launch_bounds__(256) void sp_amax_table_kernel(PackTable t, const float* params, uint32_t* amax) {
   __shared__ float red[4];
-  const PackEntry e = t.e[blockIdx.x];
+  const PackEntry e = t.e[blockIdx.y];
   const int64_t n = (int64_t)e.Co * e.Ci * e.KK;
   const float* w = params + e.w;
   float m = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += kThreads) m = fmaxf(m, fabsf(w[i]));
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
   for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void sp_amax_table_kernel(PackTable t, const f
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     uint32_t u;
     memcpy(&u, &m, 4);
-    amax[blockIdx.x] = u;
+    if (u) atomicMax(amax + blockIdx.y, u);
   }
 }
 
@@ -226,7 +227,7 @@ int sp_pack_table(const PackTable& t, const int64_t* img_off_bytes, const float*
   double bytes = 0.0;
   for (int i = 0; i < t.n; ++i) io.off[i] = img_off_bytes[i], bytes += t.e[i].KK == 9 ? 40.0 * t.e[i].Co * t.e[i].Ci : 0.0;
   ProfScope ps(PF_PREP, 0.0, bytes * (with_dgrad ? 2.9 : 1.9), stream);
-  WSL_LAUNCH(sp_amax_table_kernel, dim3(t.n), dim3(kThreads), 0, stream, t, params, amax);
+  WSL_LAUNCH(sp_amax_table_kernel, dim3(16, t.n), dim3(kThreads), 0, stream, t, params, amax);   // (amax zeroed by the caller)
   WSL_LAUNCH(sp_pack_table_kernel, dim3(16, t.n, with_dgrad ? 2 : 1), dim3(kThreads), 0, stream, t, io, params,
              static_cast<unsigned char*>(imgf), static_cast<unsigned char*>(imgd), amax, 0);
   return check_launch("sp_pack_table_kernel");
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
   const int y0 = ty_i * TH, x0 = tx_i * TW;
   const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co, HW = H * W;
 
-  const int e_w = sp_exp_of(*p.w_amax), e_in = p.in_amax ? sp_exp_of(*p.in_amax) : WSL_SP_ACT_EXP;
+  const int e_w = sp_exp_of(*p.w_amax), e_in = p.in_amax ? sp_exp_of(sp_amax_fold(p.in_amax)) : WSL_SP_ACT_EXP;
   const float in_mul = sp_pow2(e_in);
 
   SpTasks<I::NR> tk;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
   const bool ina = ci0 < p.a.C;                           // the block's input channels live in one source
   const SpSrc& src = ina ? p.a : p.b;
   const int chb = ina ? ci0 : ci0 - p.a.C;
-  const int e_dy = sp_exp_of(*p.dy_amax);
+  const int e_dy = sp_exp_of(sp_amax_fold(p.dy_amax));
   const float dy_mul = sp_pow2(e_dy), act_mul = sp_pow2(WSL_SP_ACT_EXP);
 
   for (int c = tid; c < CB; c += kThreads) {
@@ -732,7 +733,11 @@ extern "C" int wsl_sp_pack_weights(const float* w, void* image, uint32_t* w_amax
   // the table entry describes the RAW tensor [e.Co][e.Ci][3][3]; in data-gradient mode the raw tensor is [Ci][Co][3][3]
   t.e[0] = PackEntry{0, dgrad ? Ci : Co, dgrad ? Co : Ci, 9, 0};
   SpPackOffsets io{};
-  WSL_LAUNCH(sp_amax_table_kernel, dim3(1), dim3(kThreads), 0, stream, t, w, w_amax);
+  if (hipMemsetAsync(w_amax, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
+    set_error("sp_pack_weights: clearing *w_amax failed");
+    return WSL_EHIP;
+  }
+  WSL_LAUNCH(sp_amax_table_kernel, dim3(16, 1), dim3(kThreads), 0, stream, t, w, w_amax);
   // one image per call: route it through the slot of its direction
   WSL_LAUNCH(sp_pack_table_kernel, dim3(16, 1, 1), dim3(kThreads), 0, stream, t, io, w, static_cast<unsigned char*>(image),
              static_cast<unsigned char*>(image), w_amax, dgrad ? 1 : 0);

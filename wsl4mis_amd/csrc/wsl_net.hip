@@ -13,11 +13,14 @@
 
 namespace wsl {
 
+int sp_pack_table(const PackTable& t, const int64_t* img_off_bytes, const float* params, void* imgf, void* imgd, uint32_t* amax,
+                  int with_dgrad, void* stream);   // wsl_convsp.hip
+
 static const int kFt[5] = {16, 32, 64, 128, 256};            // unet.py:291
 static const float kDrop[5] = {0.05f, 0.1f, 0.2f, 0.3f, 0.5f};  // unet.py:292
 static const float kEps = 1e-5f, kMom = 0.1f;
 
-struct ConvRef { int64_t w, b; int Ci, Co, ks; };
+struct ConvRef { int64_t w, b; int Ci, Co, ks; int li; };   // li: index in the pack table
 struct BnRef { int64_t gamma, beta, rmean, rvar; int nbt, C; };
 struct BlockRef { ConvRef c1, c2; BnRef b1, b2; };
 struct BlkWs { size_t y1, y2, st1, st2; };  // st*: mean | invstd | scale | shift (4*C floats)
@@ -36,6 +39,10 @@ struct Plan {
   struct Scratch { size_t tmp_g, tmp_g1, tmp_dy, tmp_du, tmp_gpool, stat_part, stat_cnt, wg_ws, bn_ws, bn_coef; } scr[2];
   size_t packf, packd;
   size_t winof, winod;   // Winograd filter images [16][Ci][Co] of the 3x3 layers, at twice the raw weight's offset
+  // split-precision path (d.precision == 1): f16 hi / lo weight images (10 floats per 9 raw weights: sp_img_off()), one max |w|
+  // slot per conv layer (pack-table order) and one max |dy| slot per BatchNorm layer
+  size_t spf, spd, sp_wmax, sp_dymax;
+  int sp;
   size_t wg_bytes, bn_bytes, total_floats;   // wg_bytes: per scratch set, room for the partials of EVERY layer of a phase
 };
 
@@ -74,7 +81,9 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   WSL_REQUIRE(d->in_chns > 0 && d->n_class > 0 && d->n_class <= 8, "net: bad channel counts");
   WSL_REQUIRE(d->N > 0 && d->H >= 16 && d->W >= 16 && d->H % 16 == 0 && d->W % 16 == 0,
               "net: N=%d H=%d W=%d (H, W must be multiples of 16)", d->N, d->H, d->W);
+  WSL_REQUIRE(d->precision == 0 || d->precision == 1, "net: precision %d (0 = f32, 1 = split f16 x 3)", d->precision);
   P.d = *d;
+  P.sp = d->precision;
   for (int l = 0; l < 5; ++l) P.H[l] = d->H >> l, P.W[l] = d->W >> l;
   int64_t po = 0, bo = 0, nbn = 0;
   plan_block(P.enc[0], d->in_chns, kFt[0], po, bo, nbn);
@@ -89,6 +98,14 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
     plan_conv(P.dec[k].out, kFt[0], d->n_class, 3, po);
   }
   P.n_param = po, P.n_buf = bo, P.n_bn = nbn;
+  {
+    int li = 0;
+    for (int l = 0; l < 5; ++l) P.enc[l].c1.li = li++, P.enc[l].c2.li = li++;
+    for (int k = 0; k < d->n_dec; ++k) {
+      for (int i = 0; i < 4; ++i) P.dec[k].c1x1[i].li = li++, P.dec[k].blk[i].c1.li = li++, P.dec[k].blk[i].c2.li = li++;
+      P.dec[k].out.li = li++;
+    }
+  }
 
   // ---- workspace
   Bump B;
@@ -105,10 +122,27 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
     w.y1 = B.take(e), w.y2 = B.take(e);
     w.st1 = B.take(4 * k.c1.Co), w.st2 = B.take(4 * k.c1.Co);
     for (const ConvRef* c : {&k.c1, &k.c2}) {
-      const size_t nb = wsl_conv2d_stat_blocks(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
+      size_t nb = wsl_conv2d_stat_blocks(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
+      size_t wgb = wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
+      // BatchNorm-backward statistics arrive as one partial per tile of whichever kernel produces the gradient: the data gradient
+      // of this layer's consumer (tile counts of the f32 and of the split plans, for either channel count) or the fan-in kernel
+      size_t nbb = nb;
+      for (int co_alt : {c->Ci, c->Co}) {
+        const size_t a = wsl_conv2d_stat_blocks(d->N, P.H[l], P.W[l], c->Co, co_alt, 3), a1 = wsl_conv2d_stat_blocks(d->N, P.H[l], P.W[l], c->Co, co_alt, 1);
+        nbb = a > nbb ? a : nbb, nbb = a1 > nbb ? a1 : nbb;
+      }
+      if (P.sp) {
+        const size_t nb2 = wsl_sp_conv2d_stat_blocks(d->N, P.H[l], P.W[l], c->Ci, c->Co);
+        const size_t wgb2 = wsl_sp_conv2d_wgrad_ws_bytes(d->N, P.H[l], P.W[l], c->Ci, c->Co);
+        nb = nb2 > nb ? nb2 : nb, wgb = wgb2 > wgb ? wgb2 : wgb, nbb = nb2 > nbb ? nb2 : nbb;
+      }
       if (nb * c->Co * 2 > max_stat) max_stat = nb * c->Co * 2;
       if (nb > max_cnt) max_cnt = nb;
-      wg_add(*wg_acc, wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3));
+      wg_add(*wg_acc, wgb);
+      const size_t fan = wsl_feat_grad_combine_blocks(d->N, P.H[l], P.W[l]);
+      nbb = fan > nbb ? fan : nbb;
+      const size_t pb = sizeof(float) * (nbb * c->Co * 2 + 2 * (size_t)c->Co);
+      if (pb > P.bn_bytes) P.bn_bytes = pb;
     }
     const size_t bb = wsl_bnact_bwd_ws_bytes(d->N, k.c1.Co, P.H[l], P.W[l]);
     if (bb > P.bn_bytes) P.bn_bytes = bb;
@@ -142,6 +176,8 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   if (d->n_dec == 1) P.scr[1] = P.scr[0];
   P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);  // packed [tap][ci][co] weight images (fwd / data-gradient)
   P.winof = B.take(2 * P.n_param), P.winod = B.take(2 * P.n_param);
+  P.spf = P.spd = P.sp_wmax = P.sp_dymax = 0;
+  if (P.sp) P.spf = B.take(P.n_param * 10 / 9 + 64), P.spd = B.take(P.n_param * 10 / 9 + 64), P.sp_wmax = B.take(64), P.sp_dymax = B.take(32 * WSL_SP_AMAX_SLOTS);   // (26 BatchNorm layers in unet_cct)
   P.total_floats = B.off;
   return WSL_OK;
 }
@@ -175,9 +211,12 @@ struct WgBatch {
 
 // weight gradient of one layer: stage 1 now (its partials get their own region of wg_ws), stage 2 with the phase's batch
 static int wgrad_layer(const Ctx& c, const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db, int H,
-                       int W, int Co, int ks) {
+                       int W, int Co, int ks, const uint32_t* dy_amax = nullptr) {
   const int N = c.P.d.N, Ci = a->C + (b ? b->C : 0);
-  const size_t need = (wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks) + 255) & ~(size_t)255;
+  const bool sp = c.P.sp && dy_amax && ks == 3 && wsl_sp_conv2d_ok(a, b, nullptr, 0, N, H, W, Co, 3) &&
+                  !(reinterpret_cast<uintptr_t>(dy) & 15) && !(dy_bs & 3);
+  const size_t need = ((sp ? wsl_sp_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co) : wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks)) + 255) &
+                      ~(size_t)255;
   WgBatch* wb = c.wb;
   if (!wb || wb->n >= 24 || wb->off + need > c.P.wg_bytes) {
     set_error("net: weight-gradient batch overflow (%d pending, %zu + %zu of %zu bytes)", wb ? wb->n : -1, wb ? wb->off : 0, need,
@@ -185,7 +224,8 @@ static int wgrad_layer(const Ctx& c, const WslSrc* a, const WslSrc* b, const flo
     return WSL_EWORKSPACE;
   }
   char* ws = reinterpret_cast<char*>(c.ws + c.S().wg_ws) + wb->off;
-  WSL_TRY(wsl_conv2d_wgrad_partial(a, b, dy, dy_bs, dw, db, N, H, W, Co, ks, ws, need, &wb->items[wb->n], c.stream));
+  if (sp) WSL_TRY(wsl_sp_conv2d_wgrad_partial(a, b, dy, dy_bs, dy_amax, dw, db, N, H, W, Co, ws, need, &wb->items[wb->n], c.stream));
+  else WSL_TRY(wsl_conv2d_wgrad_partial(a, b, dy, dy_bs, dw, db, N, H, W, Co, ks, ws, need, &wb->items[wb->n], c.stream));
   wb->n += 1, wb->off += need;
   return WSL_OK;
 }
@@ -211,11 +251,27 @@ static WslSrc act_src(const Ctx& c, size_t y, size_t st, int C, int HW, const ui
   return s;
 }
 
+// split-precision path: float offset of a layer's weight image inside its arena (16-byte aligned, images never overlap: a 3x3
+// layer's 9 Ci Co raw weights make room for its 10 Ci Co image floats); the layer's max |w| slot; a BatchNorm layer's max |dy| slot
+static size_t sp_img_off(const ConvRef& cv) { return 4 * (size_t)((10 * cv.w + 35) / 36); }
+static const uint32_t* sp_wmax(const Ctx& c, const ConvRef& cv) { return reinterpret_cast<const uint32_t*>(c.ws + c.P.sp_wmax) + cv.li; }
+static uint32_t* sp_dymax(const Ctx& c, const BnRef& bn) {
+  return c.P.sp ? reinterpret_cast<uint32_t*>(c.ws + c.P.sp_dymax) + (size_t)bn.nbt * WSL_SP_AMAX_SLOTS : nullptr;
+}
+static bool sp_takes(const Ctx& c, const ConvRef& cv, const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int H, int W,
+                     int Co) {
+  return c.P.sp && cv.ks == 3 && wsl_sp_conv2d_ok(a, b, y, y_bs, c.P.d.N, H, W, Co, 3);
+}
+
 // forward (dgrad == 0) or data-gradient (dgrad == 1) convolution of layer `cv`: the packed fast path when the shapes
 // are float4-aligned (every layer of a net whose H, W are multiples of 16), the generic kernel otherwise.
+// (in_amax: the max |x| slot of a plain gradient source -- data-gradient launches of the split path)
 static int conv_any(const Ctx& c, const ConvRef& cv, int dgrad, const WslSrc* a, const WslSrc* b, const float* bias,
-                    float* y, int64_t y_bs, int H, int W, float* stp, float* stc) {
+                    float* y, int64_t y_bs, int H, int W, float* stp, float* stc, const uint32_t* in_amax = nullptr) {
   const int N = c.P.d.N, Co = dgrad ? cv.Ci : cv.Co;
+  if ((!dgrad || in_amax) && sp_takes(c, cv, a, b, y, y_bs, H, W, Co))
+    return wsl_sp_conv2d_fwd(a, b, c.ws + (dgrad ? c.P.spd : c.P.spf) + sp_img_off(cv), sp_wmax(c, cv), dgrad ? in_amax : nullptr, bias,
+                             y, y_bs, N, H, W, Co, stp, stc, c.stream);
   if (wsl_conv2d_fast_ok(a, b, y, y_bs, W)) {
     if (wsl_conv2d_wino_ok(N, H, W, a->C, b ? b->C : 0, Co, cv.ks))
       return wsl_conv2d_fwd(a, b, c.ws + (dgrad ? c.P.winod : c.P.winof) + 2 * cv.w, bias, y, y_bs, N, H, W, Co, cv.ks,
@@ -235,10 +291,18 @@ struct GStats {
 // data-gradient convolution of layer `cv` (dy -> g, dense) that also emits the backward statistics of the BatchNorm whose raw
 // input is ws[y] (coefficients ws[st], dropout keep mask emask) when the kernel it dispatches to can (wsl_conv2d_dgrad_bn)
 static int conv_dgrad_bn(const Ctx& c, const ConvRef& cv, const float* dy, float* g, int H, int W, size_t y, size_t st,
-                         const uint8_t* emask, float es, GStats* gs) {
+                         const uint8_t* emask, float es, GStats* gs, const uint32_t* dy_amax = nullptr) {
   const int N = c.P.d.N, Cg = cv.Ci;
   const WslSrc dys = raw_src(dy, cv.Co, (int64_t)cv.Co * H * W);
   const int64_t g_bs = (int64_t)Cg * H * W;
+  if (dy_amax && sp_takes(c, cv, &dys, nullptr, g, g_bs, H, W, Cg)) {
+    int fused = 0;
+    WSL_TRY(wsl_sp_conv2d_dgrad_bn(&dys, dy_amax, c.ws + c.P.spd + sp_img_off(cv), sp_wmax(c, cv), g, g_bs, N, H, W, Cg, c.ws + y,
+                                   c.ws + st, emask, es, c.ws + c.S().bn_ws, &fused, c.stream));
+    gs->nblk = fused ? wsl_sp_conv2d_stat_blocks(N, H, W, cv.Co, Cg) : 0;
+    gs->channel_major = 1;
+    return WSL_OK;
+  }
   const float* w = c.params + cv.w;
   int wmode = 1;
   if (wsl_conv2d_fast_ok(&dys, nullptr, g, g_bs, W)) {
@@ -259,12 +323,13 @@ static int bn_bwd(const Ctx& c, const float* g, int64_t g_bs, size_t y, size_t s
   const Plan& P = c.P;
   const int C = bn.C;
   const float* s = c.ws + st;
+  // (split path: the apply pass also leaves max |dy| in the layer's slot -- the operand scale of dy's two consumers)
   if (gs.nblk)
-    return wsl_bnact_bwd_finish(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy,
-                                c.grads + bn.gamma, c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, gs.nblk, gs.channel_major,
-                                c.ws + c.S().bn_coef, 2 * sizeof(float) * (size_t)C, c.stream);
-  return wsl_bnact_bwd(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy, c.grads + bn.gamma,
-                       c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, P.bn_bytes, c.stream);
+    return wsl_bnact_bwd_finish_amax(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy,
+                                     c.grads + bn.gamma, c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, gs.nblk,
+                                     gs.channel_major, c.ws + c.S().bn_coef, 2 * sizeof(float) * (size_t)C, sp_dymax(c, bn), c.stream);
+  return wsl_bnact_bwd_amax(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy, c.grads + bn.gamma,
+                            c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, P.bn_bytes, sp_dymax(c, bn), c.stream);
 }
 
 static int pack_all(const Ctx& c, int with_dgrad) {
@@ -278,7 +343,20 @@ static int pack_all(const Ctx& c, int with_dgrad) {
     one(P.dec[k].out);
   }
   WSL_TRY(conv2_pack_table(t, c.params, c.ws + P.packf, c.ws + P.packd, with_dgrad, c.stream));
-  return wino_pack_table(t, c.params, c.ws + P.winof, c.ws + P.winod, with_dgrad, c.stream);
+  WSL_TRY(wino_pack_table(t, c.params, c.ws + P.winof, c.ws + P.winod, with_dgrad, c.stream));
+  if (P.sp) {   // f16 hi / lo images + the layers' max |w|; a training forward also clears the max |dy| slots of its backward
+    int64_t off[40];
+    for (int i = 0; i < t.n; ++i) off[i] = 4 * (int64_t)(4 * ((10 * t.e[i].w + 35) / 36));
+    // (sp_wmax and sp_dymax are adjacent workspace regions: one clear)
+    const size_t clr = with_dgrad ? (P.sp_dymax - P.sp_wmax) + 32 * WSL_SP_AMAX_SLOTS : 64;
+    if (hipMemsetAsync(c.ws + P.sp_wmax, 0, clr * sizeof(float), (hipStream_t)c.stream) != hipSuccess) {
+      set_error("net: clearing the split path's maxima failed");
+      return WSL_EHIP;
+    }
+    WSL_TRY(sp_pack_table(t, off, c.params, c.ws + P.spf, c.ws + P.spd, reinterpret_cast<uint32_t*>(c.ws + P.sp_wmax), with_dgrad,
+                          c.stream));
+  }
+  return WSL_OK;
 }
 
 // conv + (train: batch statistics -> BN coefficients | eval: running statistics)
@@ -291,7 +369,8 @@ static int conv_bn_fwd(const Ctx& c, const ConvRef& cv, const BnRef& bn, const W
   WSL_TRY(conv_any(c, cv, 0, a, b, c.params + cv.b, c.ws + y, (int64_t)C * H * W, H, W, stp, stc));
   float* s = c.ws + st;
   if (c.training) {
-    const int nblk = wsl_conv2d_stat_blocks(N, H, W, cv.Ci, C, cv.ks);
+    const int nblk = sp_takes(c, cv, a, b, c.ws + y, (int64_t)C * H * W, H, W, C) ? wsl_sp_conv2d_stat_blocks(N, H, W, cv.Ci, C)
+                                                                                 : wsl_conv2d_stat_blocks(N, H, W, cv.Ci, C, cv.ks);
     return wsl_bn_stats_finalize(stp, stc, nblk, C, c.params + bn.gamma, c.params + bn.beta, kEps, kMom,
                                  c.buffers + bn.rmean, c.buffers + bn.rvar, c.nbt ? c.nbt + bn.nbt : nullptr, s, s + C,
                                  s + 2 * C, s + 3 * C, c.stream);
@@ -321,15 +400,16 @@ static int block_bwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslS
   // BN2 + LeakyReLU (no dropout after the second activation)
   WSL_TRY(bn_bwd(c, g, g_bs, w.y2, w.st2, k.b2, nullptr, 1.f, dy, H, W, gs));
   const WslSrc mid = act_src(c, w.y1, w.st1, C, H * W, emask, es, nullptr);
-  WSL_TRY(wgrad_layer(c, &mid, nullptr, dy, CHW, c.grads + k.c2.w, c.grads + k.c2.b, H, W, C, 3));
+  WSL_TRY(wgrad_layer(c, &mid, nullptr, dy, CHW, c.grads + k.c2.w, c.grads + k.c2.b, H, W, C, 3, sp_dymax(c, k.b2)));
   // data gradient of the second convolution; its epilogue carries the statistics of BN1 + LeakyReLU + Dropout(p)
   GStats g1s;
-  WSL_TRY(conv_dgrad_bn(c, k.c2, dy, g1, H, W, w.y1, w.st1, emask, es, &g1s));
+  WSL_TRY(conv_dgrad_bn(c, k.c2, dy, g1, H, W, w.y1, w.st1, emask, es, &g1s, sp_dymax(c, k.b2)));
   WSL_TRY(bn_bwd(c, g1, CHW, w.y1, w.st1, k.b1, emask, es, dy, H, W, g1s));
-  WSL_TRY(wgrad_layer(c, a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, H, W, C, 3));
+  WSL_TRY(wgrad_layer(c, a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, H, W, C, 3, sp_dymax(c, k.b1)));
   if (dgrad_out) {
     const WslSrc dys1 = raw_src(dy, C, CHW);
-    WSL_TRY(conv_any(c, k.c1, 1, &dys1, nullptr, nullptr, dgrad_out, (int64_t)k.c1.Ci * H * W, H, W, nullptr, nullptr));
+    WSL_TRY(conv_any(c, k.c1, 1, &dys1, nullptr, nullptr, dgrad_out, (int64_t)k.c1.Ci * H * W, H, W, nullptr, nullptr,
+                     sp_dymax(c, k.b1)));
   }
   return WSL_OK;
 }

@@ -239,6 +239,17 @@ __host__ __device__ __forceinline__ int sp_exp_of(uint32_t amax_bits) {
   const int e = 14 - (be - 127);
   return e > 100 ? 100 : (e < -100 ? -100 : e);  // 2^e and 2^-e stay normal floats
 }
+// A tensor's maximum is kept as WSL_SP_AMAX_SLOTS partial maxima (a producer's workgroups spread their atomic max over the
+// slots: tens of thousands of atomics on ONE address serialise at ~12 ns each); a consumer wave folds them with one load per lane
+__device__ __forceinline__ uint32_t sp_amax_fold(const uint32_t* slots) {
+  uint32_t u = slots[threadIdx.x & (WSL_SP_AMAX_SLOTS - 1)];
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)u, k);
+    u = o > u ? o : u;
+  }
+  return u;
+}
 __host__ __device__ __forceinline__ float sp_pow2(int e) {
   const uint32_t u = (uint32_t)(e + 127) << 23;
   float f;

@@ -43,10 +43,11 @@ class TrainEngine:
 
     def __init__(self, net_type="unet_cct", in_chns=1, class_num=4, base_lr=0.01, max_iterations=60000, momentum=0.9,
                  weight_decay=1e-4, loss="ours_proposed", w_pse=0.5, crf_radius=5, crf_weight=0.1,
-                 crf_desc=None, ignore_index=4, model=None, force_dp=False):
+                 crf_desc=None, ignore_index=4, model=None, force_dp=False, conv_precision="f32"):
         if loss not in ("ours_proposed", "pce", "pce_gatedcrf", "mean_teacher", "ustm") + self.REGULARISED:
             raise NotImplementedError(f"loss composition '{loss}'")
-        self.model = model if model is not None else net_factory(net_type, in_chns, class_num)
+        # conv_precision: "f32" (default, the headline path) | "split_f16x3" (opt-in: networks/unet.py, include/wsl_hip.h)
+        self.model = model if model is not None else net_factory(net_type, in_chns, class_num, conv_precision=conv_precision)
         if self.model is None:
             raise _lib.WslError(f"unknown net_type {net_type}")
         self.model.train()
@@ -79,7 +80,7 @@ class TrainEngine:
         if loss in ("mean_teacher", "ustm"):
             if self.dual:
                 raise _lib.WslError(f"'{loss}' is defined for the single-decoder unet")
-            self.teacher = net_factory(net_type, in_chns, class_num)
+            self.teacher = net_factory(net_type, in_chns, class_num, conv_precision=self.model.conv_precision)
             self.teacher.train()                          # the reference never puts the EMA model in eval()
             with torch.no_grad():
                 self.teacher._param_arena.copy_(self.model._param_arena)

@@ -24,6 +24,7 @@ _DROP = (0.05, 0.1, 0.2, 0.3, 0.5)
 class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x, *params):
+        x = rt.f32c(x, "input")     # the kernels address x as dense NCHW: keep the tensor the forward actually read
         outs = mod._run_forward(x, keep_for_backward=True)
         ctx.mod, ctx.x, ctx.token = mod, x, mod._fwd_token
         return outs if len(outs) > 1 else outs[0]
@@ -43,10 +44,16 @@ class _NetFn(torch.autograd.Function):
 
 class _HipUNet(nn.Module):
     _n_dec = 1
+    PRECISIONS = {"f32": 0, "split_f16x3": 1}
 
-    def __init__(self, in_chns, class_num):
+    def __init__(self, in_chns, class_num, conv_precision="f32"):
         super().__init__()
         self.in_chns, self.class_num = int(in_chns), int(class_num)
+        # "split_f16x3" (opt-in): the 3x3 layers with >= 16 channels on both sides run on the f16 matrix cores with f16 hi / lo
+        # operands, three MFMA passes and fp32 accumulation (include/wsl_hip.h, "split-precision conv path"); "f32" is the default
+        if conv_precision not in self.PRECISIONS:
+            raise ValueError(f"conv_precision {conv_precision!r}: one of {sorted(self.PRECISIONS)}")
+        self.conv_precision = conv_precision
         dev = rt.device()
         d0 = self._desc(1, 16, 16)
         L = rt.L()
@@ -76,7 +83,7 @@ class _HipUNet(nn.Module):
 
     # ------------------------------------------------------------------ structure
     def _desc(self, N, H, W):
-        return _lib.WslNetDesc(self.in_chns, self.class_num, self._n_dec, N, H, W)
+        return _lib.WslNetDesc(self.in_chns, self.class_num, self._n_dec, N, H, W, self.PRECISIONS[self.conv_precision], 0)
 
     def _build_tree(self):
         """Container modules named after the reference's attribute path, so state_dict() keys are identical."""
@@ -242,8 +249,8 @@ class UNet(_HipUNet):
     """ref: networks/unet.py:286-303 (in_chns, class_num) -> logits [N, class_num, H, W]."""
     _n_dec = 1
 
-    def __init__(self, in_chns, class_num):
-        super().__init__(in_chns, class_num)
+    def __init__(self, in_chns, class_num, conv_precision="f32"):
+        super().__init__(in_chns, class_num, conv_precision)
 
 
 class UNet_CCT(_HipUNet):
@@ -251,13 +258,14 @@ class UNet_CCT(_HipUNet):
     F.dropout2d(feature, 0.5) of all five encoder features, in train AND eval mode."""
     _n_dec = 2
 
-    def __init__(self, in_chns, class_num):
-        super().__init__(in_chns, class_num)
+    def __init__(self, in_chns, class_num, conv_precision="f32"):
+        super().__init__(in_chns, class_num, conv_precision)
 
 
 class _UpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x1, x2, *params):
+        x1, x2 = rt.f32c(x1, "x1"), rt.f32c(x2, "x2")     # the dense tensors the kernels read are the ones saved (ADVICE r2)
         out = mod._run_forward(x1, x2, keep=True)
         ctx.mod, ctx.token = mod, mod._fwd_token
         ctx.save_for_backward(x1, x2)
@@ -352,8 +360,20 @@ class UpBlock(nn.Module):
         """inject the nn.Dropout keep mask [N, Co, 2h, 2w] uint8 of the next forward(s) (parity tests); None = draw"""
         self._forced_mask = emask
 
+    def _ensure_arena(self):
+        """Re-attach parameters that were re-allocated behind the module (p.data = ..., .double().float(), ...)."""
+        base = self._param_arena.data_ptr()
+        for prm, off, k, shape in self._plist:
+            if prm.data_ptr() != base + 4 * off:
+                if prm.device != self._param_arena.device or prm.dtype != torch.float32:
+                    raise _lib.WslError("UpBlock parameters were moved off the GPU / cast away from float32")
+                with torch.no_grad():
+                    self._param_arena[off:off + k].copy_(prm.data.reshape(-1))
+                    prm.data = self._param_arena[off:off + k].view(shape)
+
     def _run_forward(self, x1, x2, keep=False):
         x1, x2 = rt.f32c(x1, "x1"), rt.f32c(x2, "x2")
+        self._ensure_arena()
         N, c1, h, w = x1.shape
         if c1 != self.c1 or tuple(x2.shape) != (N, self.c2, 2 * h, 2 * w):
             raise _lib.WslError(f"UpBlock: x1 {tuple(x1.shape)} / x2 {tuple(x2.shape)} do not fit ({self.c1}, {self.c2})")
@@ -380,8 +400,9 @@ class UpBlock(nn.Module):
     def _run_backward(self, x1, x2, gout, need):
         d, ws, nws, em = self._saved
         g = rt.f32c(gout, "grad_output")
-        dx1 = torch.empty_like(x1) if need[0] else None
-        dx2 = torch.empty_like(x2) if need[1] else None
+        x1, x2 = rt.f32c(x1, "x1"), rt.f32c(x2, "x2")
+        dx1 = torch.empty(x1.shape, dtype=torch.float32, device=x1.device) if need[0] else None     # dense, whatever x's strides
+        dx2 = torch.empty(x2.shape, dtype=torch.float32, device=x2.device) if need[1] else None
         rt.call("wsl_upblock_t_backward", C.byref(d), rt.ptr(self._param_arena), rt.ptr(x1), rt.ptr(x2), rt.ptr(em), rt.ptr(g),
                 rt.ptr(self._grad_arena), rt.ptr(dx1), rt.ptr(dx2), rt.ptr(ws), nws, rt.stream())
         flat = self._grad_arena.clone()
@@ -390,4 +411,7 @@ class UpBlock(nn.Module):
     def forward(self, x1, x2):
         if self.training and torch.is_grad_enabled():
             return _UpFn.apply(self, x1, x2, *[p for p, _, _, _ in self._plist])
+        if torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad or any(p.requires_grad for p, _, _, _ in self._plist)):
+            raise NotImplementedError("UpBlock: gradients in eval mode are not built (the backward kernels replay the training-mode "
+                                      "BatchNorm); call .train() or wrap the forward in torch.no_grad()")
         return self._run_forward(x1, x2)
