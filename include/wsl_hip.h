@@ -186,7 +186,7 @@ int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const flo
  * weight gradient reads through a WslSrc) a fixed 2^WSL_SP_ACT_EXP: f16 then holds |v| < 4094 -- BatchNorm-normalised values
  * cannot reach that, and a larger value saturates instead of overflowing.  Results are independent of the scale chosen as long as
  * nothing under- or overflows.  Eligible layers (wsl_sp_conv2d_ok): ks 3, (Ca + Cb) % 16 == 0 (Ca % 16 == 0 with two sources),
- * Co % 16 == 0, (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0), float4-aligned tensors.
+ * Co % 16 == 0, H % 8 == 0 and W % 16 == 0, float4-aligned tensors.
  * A `w_amax` argument is the DEVICE address of one uint32, the bit pattern of a non-negative float; a `dy_amax` / `in_amax`
  * argument is the device address of WSL_SP_AMAX_SLOTS such words whose maximum is the tensor's (the producer's workgroups spread
  * their integer atomic max over the slots -- order-independent, so results stay run-to-run reproducible); the caller zeroes the

@@ -10,7 +10,12 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from wsl4mis_amd import _lib  # noqa: E402
+if "--exp" in sys.argv:          # the experiments build: WSL_SP_ABLATE and friends apply
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import explib  # noqa: E402
+    _lib = explib.use()
+else:
+    from wsl4mis_amd import _lib  # noqa: E402
 
 L = _lib.lib()
 dev = torch.device("cuda:0")
@@ -20,6 +25,8 @@ ENC = [(16, 16, 256), (16, 32, 128), (32, 32, 128), (32, 64, 64), (64, 64, 64), 
        (256, 256, 16)]
 DEC = [(256, 128, 32), (128, 64, 64), (64, 32, 128), (32, 16, 256)]
 SHAPES = ENC + (DEC if "--dec" in sys.argv else [])
+if "--few" in sys.argv:
+    SHAPES = [(16, 16, 256), (32, 16, 256), (64, 64, 64), (128, 128, 32)]
 only_sp = "--only-sp" in sys.argv
 
 

@@ -341,18 +341,22 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce4_kernel(BnBwdP p, float*
 
 // max |v| over the workgroup's values into *amax: the bit patterns of non-negative floats order like the floats, and an integer
 // atomic max is order-independent -- what the split-precision consumers of dy scale their operand with (wsl_convsp.hip)
-// (one atomic per workgroup, spread over WSL_SP_AMAX_SLOTS words: see sp_amax_fold() in wsl_rt.h)
+// (one candidate per wave, spread over WSL_SP_AMAX_SLOTS words -- sp_amax_fold() in wsl_rt.h; a wave only issues the atomic when
+//  its maximum beats what the slot already holds, which a relaxed L2 load tells it: a running maximum is raised O(log n) times,
+//  so the atomics of a launch stay in the hundreds.  No LDS, no barrier.)
 __device__ __forceinline__ void amax_commit(float m, uint32_t* amax) {
-  __shared__ float wmax[4];
 #pragma unroll
   for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  if ((threadIdx.x & 63) == 0) {
     uint32_t u;
     memcpy(&u, &m, 4);
-    if (u) atomicMax(amax + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & (WSL_SP_AMAX_SLOTS - 1)), u);
+    uint32_t* slot = amax + ((blockIdx.x * 4 + (threadIdx.x >> 6) + 5 * blockIdx.y + 11 * blockIdx.z) & (WSL_SP_AMAX_SLOTS - 1));
+#ifdef WSL_HOST_EMUL
+    const uint32_t cur = __atomic_load_n(slot, __ATOMIC_RELAXED);
+#else
+    const uint32_t cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    if (u > cur) atomicMax(slot, u);
   }
 }
 

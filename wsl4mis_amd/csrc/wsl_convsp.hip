@@ -61,9 +61,10 @@ struct SpTasks {            // this thread's staging tasks: (row, quad, octet) =
 };
 
 template <int NR>
-struct SpRegs {             // prefetched raw data of the tasks: 8 channels x 4 pixels (+ keep bytes)
-  float4 v[NR][8];
+struct SpRegs {             // prefetched raw data of the tasks: 8 channels x 4 pixels (+ keep bytes), and whether the quad was inside
+  float4 v[NR][8];          // the image of the tile it was requested for (the task table may already describe the next tile)
   uint32_t m[NR][8];
+  bool valid[NR];
 };
 
 // (y0, x0) = image coordinates of staged row 0 / staged column 0
@@ -89,6 +90,7 @@ __device__ __forceinline__ void sp_issue(const SpTasks<I::NR>& t, SpRegs<I::NR>&
                                          int HW) {
 #pragma unroll
   for (int r = 0; r < I::NR; ++r) {
+    g.valid[r] = t.valid[r];
     const float* xb = xs + (int64_t)(chb + t.oct[r] * 8) * HW + t.toff[r];
 #pragma unroll
     for (int c = 0; c < 8; ++c) g.v[r][c] = *reinterpret_cast<const float4*>(xb + (int64_t)c * HW);
@@ -101,15 +103,15 @@ __device__ __forceinline__ void sp_issue(const SpTasks<I::NR>& t, SpRegs<I::NR>&
 }
 
 // transform (BN + LeakyReLU, keep mask, channel multiplier -- the WslSrc loader), scale by `mul`, split, write hi / lo slots.
-// tab / cml: LDS tables {scale, shift} and channel multiplier indexed by the channel inside the concatenated input (tc0 = table
-// index of channel chb).  `zero_fill`: tasks outside the image write zero slots (once per kernel: nothing else touches them).
+// tab: LDS table {scale, shift}, cml: this sample's channel multipliers (global memory), both indexed by the channel inside the
+// concatenated input (tc0 = index of channel chb).  `zero_fill`: tasks outside the image write zero slots.
 template <typename I>
 __device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const float2* tab,
                                           const float* cml, int tc0, bool has_scale, bool has_mask, bool has_cm, float es, bool has_mul,
                                           float mul, bool zero_fill) {
 #pragma unroll
   for (int r = 0; r < I::NR; ++r) {
-    if (t.valid[r]) {
+    if (g.valid[r]) {
       wsl_v2f a[8], b[8];   // a[c] = pixels 0, 1 of channel c; b[c] = pixels 2, 3
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -234,6 +236,12 @@ int sp_pack_table(const PackTable& t, const int64_t* img_off_bytes, const float*
 }
 
 // ------------------------------------------------------------------------------------------------ conv forward / data gradient
+// Persistent workgroups: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and, inside a tile, the 16-channel
+// chunks of the input; the raw data of the NEXT (tile, chunk) is requested before the MFMA loop of the current one, so loads are
+// in flight during the matrix work, the epilogue's stores and the statistics -- the full-resolution layers are HBM-bound by a wide
+// margin (16 -> 16 @ 256 x 256: 107 us of traffic at 5 TB/s against 40 us of matrix + staging work) and a workgroup that loads,
+// waits, computes and stores in sequence leaves the memory system idle most of its life.  BRES: the weight image of the block fits
+// LDS for all chunks (Ci * CO_T <= 1024: the two full-resolution levels) and is staged once per workgroup.
 struct ConvSpP {
   SpSrc a, b;
   const wsl_u4* img;        // this layer's weight image
@@ -242,55 +250,44 @@ struct ConvSpP {
   const float* bias;
   float* y;
   int64_t y_bs;
-  int N, H, W, Ci, Co, tiles_x, tiles_y;
+  int N, H, W, Ci, Co, tiles_x, tiles_y, ntiles;
   float* stat_part;
   float* stat_cnt;
   BnBwdEpi bn;              // data-gradient launches: BatchNorm-backward statistics of the consumer of y
+  int ablate;               // EXPERIMENTS build (env WSL_SP_ABLATE; results are WRONG by design): 1 no MFMA, 2 no transform / split /
+                            // LDS writes after the first commit, 4 no output stores, 8 no global loads after the first request
 };
 
 template <int TH, int TW, int CO_T>
 struct ConvSpCfg {
   using Img = SpImg<TH + 2, (TW + 8) / 4, 2>;
   static constexpr int SEGS = TW / 16, MT_TOTAL = TH * SEGS, MT = MT_TOTAL / 4, NT = CO_T / 16;
-  static constexpr int B_BYTES = 2 * 5 * 4 * CO_T * 16;            // [hl][kstep][g][co][8 halves]
+  static constexpr int B_BYTES = 2 * 5 * 4 * CO_T * 16;            // one chunk: [hl][kstep][g][co][8 halves]
   static constexpr int B_PIECES = B_BYTES / 16, NBW = (B_PIECES + 255) / 256;
-  static constexpr size_t SMEM = Img::BYTES + B_BYTES + sizeof(float) * 3 * kSpMaxC;
-  static constexpr int MINW = (MT * NT * 4 <= 32) ? 3 : 2;
+  static constexpr int RED_BYTES = 8 * CO_T * 4;
+  // waves per SIMD the register allocator must leave room for (a tighter cap spills the staging state into scratch)
+  static constexpr int MINW = NT == 1 ? 3 : 2;
+  static size_t smem(int Ci, bool bres) { return Img::BYTES + (size_t)(bres ? Ci / 16 : 1) * B_BYTES + RED_BYTES + 8 * (size_t)Ci; }
   static_assert(MT_TOTAL % 4 == 0 && MT % SEGS == 0, "tile shape");
-  static_assert(8 * CO_T * sizeof(float) <= (size_t)Img::BYTES, "epilogue scratch");
 };
 
-template <int TH, int TW, int CO_T>
+template <int TH, int TW, int CO_T, bool BRES>
 __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_kernel(ConvSpP p) {
   using C = ConvSpCfg<TH, TW, CO_T>;
   using I = typename C::Img;
   WSL_DYN_SMEM(smem);
+  const int Ci = p.Ci, Co = p.Co, H = p.H, W = p.W, HW = H * W;
   unsigned char* a_img = smem;
   unsigned char* b_img = smem + I::BYTES;
-  float2* tab = reinterpret_cast<float2*>(smem + I::BYTES + C::B_BYTES);
-  float* cm_l = reinterpret_cast<float*>(tab + kSpMaxC);
+  float* red = reinterpret_cast<float*>(b_img + (size_t)(BRES ? Ci / 16 : 1) * C::B_BYTES);
+  float2* tab = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(red) + C::RED_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
-  const int nb = gridDim.x;
-  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD-aware tile order (neighbouring tiles share an L2)
-  const int tile_id = bid;
-  const int tx_i = bid % p.tiles_x;
-  bid /= p.tiles_x;
-  const int ty_i = bid % p.tiles_y;
-  const int n = bid / p.tiles_y;
   const int co0 = blockIdx.y * CO_T;
-  const int y0 = ty_i * TH, x0 = tx_i * TW;
-  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co, HW = H * W;
+  const int nb = p.ntiles;
 
   const int e_w = sp_exp_of(*p.w_amax), e_in = p.in_amax ? sp_exp_of(sp_amax_fold(p.in_amax)) : WSL_SP_ACT_EXP;
   const float in_mul = sp_pow2(e_in);
-
-  SpTasks<I::NR> tk;
-  sp_tasks_init<I>(tk, tid, y0 - 1, x0 - 4, H, W);
-  const float* xa_n = p.a.x + n * p.a.bs;
-  const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
-  const uint8_t* ma_n = p.a.emask ? p.a.emask + (int64_t)n * p.a.C * HW : nullptr;
-  const uint8_t* mb_n = (p.b.C && p.b.emask) ? p.b.emask + (int64_t)n * p.b.C * HW : nullptr;
+  const float u1 = sp_pow2(-e_w), u2 = sp_pow2(-e_in);
 
   // weight pieces of a chunk: LDS piece u = ((hl * 5 + s) * 4 + g) * CO_T + col  <-  image piece ((hl * 5 + s) * 4 + g) * Co + co0 + col
   uint32_t woff[C::NBW];
@@ -301,42 +298,22 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
     woff[i] = u < C::B_PIECES ? (uint32_t)(rest * Co + co0 + col) : 0u;
   }
   const int64_t chunk_pieces = (int64_t)40 * Co;
-
-  SpRegs<I::NR> pre;
-  wsl_u4 prw[C::NBW];
-  auto issue = [&](int c0) __attribute__((always_inline)) {
-    const bool ina = c0 < p.a.C;   // uniform
-    sp_issue<I>(tk, pre, ina ? xa_n : xb_n, ina ? ma_n : mb_n, ina ? c0 : c0 - p.a.C, HW);
-    const wsl_u4* wb = p.img + (int64_t)(c0 >> 4) * chunk_pieces;
+  if constexpr (BRES) {   // every chunk's weights, once
+    for (int ch = 0; ch < Ci / 16; ++ch) {
+      const wsl_u4* wb = p.img + (int64_t)ch * chunk_pieces;
 #pragma unroll
-    for (int i = 0; i < C::NBW; ++i) prw[i] = wb[woff[i]];
-  };
-  auto commit = [&](int c0) __attribute__((always_inline)) {
-    const bool ina = c0 < p.a.C;
-    const SpSrc& s = ina ? p.a : p.b;
-    sp_commit<I>(tk, pre, a_img, tab, cm_l, c0, s.scale != nullptr, s.emask != nullptr, s.cmask != nullptr, s.es,
-                 s.scale == nullptr, in_mul, c0 == 0);
-#pragma unroll
-    for (int i = 0; i < C::NBW; ++i)
-      if ((i + 1) * kThreads <= C::B_PIECES || tid + i * kThreads < C::B_PIECES)
-        reinterpret_cast<wsl_u4*>(b_img)[tid + i * kThreads] = prw[i];
-  };
-
-  issue(0);
-  // loader tables; the operand scale of a BatchNorm source is folded into its coefficients (exact: a power of two)
+      for (int i = 0; i < C::NBW; ++i)
+        if ((i + 1) * kThreads <= C::B_PIECES || tid + i * kThreads < C::B_PIECES)
+          reinterpret_cast<wsl_u4*>(b_img + (size_t)ch * C::B_BYTES)[tid + i * kThreads] = wb[woff[i]];
+    }
+  }
+  // loader table; the operand scale of a BatchNorm source is folded into its coefficients (exact: a power of two)
   for (int c = tid; c < Ci; c += kThreads) {
     const bool ina = c < p.a.C;
     const SpSrc& s = ina ? p.a : p.b;
     const int ch = ina ? c : c - p.a.C;
     tab[c] = s.scale ? make_float2(s.scale[ch] * in_mul, s.shift[ch] * in_mul) : make_float2(1.f, 0.f);
-    cm_l[c] = s.cmask ? s.cmask[(int64_t)n * s.C + ch] : 1.f;
   }
-
-  v4f acc[C::MT][C::NT];
-#pragma unroll
-  for (int i = 0; i < C::MT; ++i)
-#pragma unroll
-    for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
   // A operand of K-step s: pixel m = lane & 15 of the row tile, octet (lane >> 4) & 1, tap 2 s + (lane >> 5)
   int aoff[5];
@@ -347,18 +324,78 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
     aoff[s] = ((lane >> 4) & 1) * I::PLANE + ky * I::ROWB + sp_slot<I>(3 + (lane & 15) + kx);
   }
   const int bbase = ((lane >> 4) * CO_T + (lane & 15)) * 16;
-  __syncthreads();   // tables visible
 
-  for (int c0 = 0; c0 < Ci; c0 += 16) {
-    commit(c0);
+  SpTasks<I::NR> tk;
+  SpRegs<I::NR> pre;
+  // Tile order: workgroup b runs on XCD b % 8 (observed dispatch; speed only) -- give every XCD one contiguous eighth of the tiles and
+  // let its workgroups walk it side by side, so the halo lines two neighbouring tiles share meet in ONE L2 instead of being fetched
+  // over the fabric by three (measured: the loads alone of 16 -> 16 @ 256 x 256 took 118 us with tiles dealt round-robin)
+  const bool xcd = (nb & 7) == 0 && (gridDim.x & 7) == 0;
+  const int tstep = xcd ? gridDim.x >> 3 : gridDim.x;
+  const int tend = xcd ? ((int)(blockIdx.x & 7) + 1) * (nb >> 3) : nb;
+  // (tile, chunk) whose raw data sits in `pre`
+  int nt = xcd ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x, nc0 = 0, n_n = 0;
+  const int t_first = nt;
+  auto issue = [&]() __attribute__((always_inline)) {
+    if (nc0 == 0) {   // first chunk of a tile: its coordinates
+      const int tx = nt % p.tiles_x, r = nt / p.tiles_x;
+      const int ty = r % p.tiles_y;
+      n_n = r / p.tiles_y;
+      sp_tasks_init<I>(tk, tid, ty * TH - 1, tx * TW - 4, H, W);
+    }
+    const bool ina = nc0 < p.a.C;   // uniform
+    const SpSrc& s = ina ? p.a : p.b;
+    const int chb = ina ? nc0 : nc0 - p.a.C;
+    sp_issue<I>(tk, pre, s.x + n_n * s.bs, s.emask ? s.emask + (int64_t)n_n * s.C * HW : nullptr, chb, HW);
+  };
+
+  // streamed weights: one chunk's block goes straight into LDS (global_load_lds: lane-linear pieces, no registers, no ds_write);
+  // requested when the MFMA loop that read the previous block is over, awaited behind the next tile image's staging arithmetic
+  auto dma_weights = [&](int c0) __attribute__((always_inline)) {
+    const wsl_u4* wb = p.img + (int64_t)(c0 >> 4) * chunk_pieces;
+#pragma unroll
+    for (int i = 0; i < C::NBW; ++i)
+      if ((i + 1) * kThreads <= C::B_PIECES || (i * kThreads + wave * 64) < C::B_PIECES)   // whole waves (B_PIECES % 64 == 0)
+        WSL_LDS_DMA16(wb + woff[i], b_img + (size_t)(i * kThreads + wave * 64) * 16);
+  };
+
+  v4f acc[C::MT][C::NT];
+  if (nt < tend) {
+    issue();
+    if constexpr (!BRES) dma_weights(0);
+  }
+  __syncthreads();   // table (and resident weights) visible
+
+  while (nt < tend) {
+    const int t = nt, c0 = nc0, n = n_n;
+    {   // ---- raw data -> hi / lo images
+      const bool ina = c0 < p.a.C;
+      const SpSrc& s = ina ? p.a : p.b;
+      const float* cmn = s.cmask ? s.cmask + (int64_t)n * s.C - (ina ? 0 : p.a.C) : nullptr;   // indexed by the table channel
+      if (!WSL_ABLATED(p, 2) || (t == t_first && c0 == 0))
+        sp_commit<I>(tk, pre, a_img, tab, cmn, c0, s.scale != nullptr, s.emask != nullptr, s.cmask != nullptr, s.es,
+                     s.scale == nullptr, in_mul, true);
+      if constexpr (!BRES) WSL_WAIT_ALL();   // this chunk's weight block has landed
+    }
     __syncthreads();
-    if (c0 + 16 < Ci) issue(c0 + 16);   // in flight during the MFMA loop below
+    // ---- request the next (tile, chunk)
+    if (c0 + 16 < Ci) nc0 = c0 + 16;
+    else nc0 = 0, nt = t + tstep;
+    if (nt < tend && !WSL_ABLATED(p, 8)) issue();   // in flight during the MFMA loop, the epilogue's stores and the statistics
+    if (c0 == 0) {
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned char* b_c = b_img + (BRES ? (size_t)(c0 >> 4) * C::B_BYTES : 0);
+    if (!WSL_ABLATED(p, 1))
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       wsl_u4 bh[C::NT], bl[C::NT];
 #pragma unroll
       for (int j = 0; j < C::NT; ++j) {
-        const unsigned char* q = b_img + bbase + (s * 4 * CO_T + j * 16) * 16;
+        const unsigned char* q = b_c + bbase + (s * 4 * CO_T + j * 16) * 16;
         bh[j] = *reinterpret_cast<const wsl_u4*>(q);
         bl[j] = *reinterpret_cast<const wsl_u4*>(q + 5 * 4 * CO_T * 16);
       }
@@ -375,90 +412,94 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
         }
       }
     }
-    __syncthreads();
-  }
-
-  // ---- epilogue: undo the operand scales, bias, float4 stores, BatchNorm partial statistics (tiles and channel blocks are full)
-  const float u1 = sp_pow2(-e_w), u2 = sp_pow2(-e_in);
-  float* red = reinterpret_cast<float*>(a_img);
-  float bsum[C::NT];
-  constexpr int RPW = C::MT / C::SEGS;   // output rows per wave
-  {
-    float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+    if (c0 + 16 >= Ci) {
+      // ---- epilogue of tile t: undo the operand scales, bias, float4 stores, statistics (tiles and channel blocks are full)
+      const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TW;
+      float bsum[C::NT];
+      constexpr int RPW = C::MT / C::SEGS;   // output rows per wave
+      {
+        float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
 #pragma unroll
-    for (int j = 0; j < C::NT; ++j) {
-      const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
-      float* yj = yb + (int64_t)j * 16 * HW;
-      float bs = 0.f;
+        for (int j = 0; j < C::NT; ++j) {
+          const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
+          float* yj = yb + (int64_t)j * 16 * HW;
+          float bs = 0.f;
 #pragma unroll
-      for (int i = 0; i < C::MT; ++i) {
-        v4f v = acc[i][j];
+          for (int i = 0; i < C::MT; ++i) {
+            v4f v = acc[i][j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (v[r] * u1) * u2 + bias;
-        acc[i][j] = v;
-        *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16) = make_float4(v[0], v[1], v[2], v[3]);
-        bs += (v[0] + v[1]) + (v[2] + v[3]);
-      }
-      bsum[j] = bs;
-    }
-  }
-  if constexpr (C::MT * C::NT * 4 <= 32) if (p.bn.part) {
-    float s1[C::NT], s2[C::NT];
-#pragma unroll
-    for (int j = 0; j < C::NT; ++j) {
-      const int co = co0 + j * 16 + (lane & 15);
-      const float mean = p.bn.st[co], invstd = p.bn.st[Co + co], sc = p.bn.st[2 * Co + co], sh = p.bn.st[3 * Co + co];
-      const int64_t base = ((int64_t)n * Co + co) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
-      BnBwdAcc ba;
-#pragma unroll
-      for (int i = 0; i < C::MT; ++i) {
-        bn_bwd_acc4(p.bn, base + (i / C::SEGS) * W + (i % C::SEGS) * 16, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3],
-                    mean, invstd, sc, sh, ba);
-      }
-      bn_bwd_fold(ba, s1[j], s2[j]);
-    }
-    bn_bwd_store<C::NT, CO_T>(p.bn, s1, s2, red, co0, Co, tile_id, nb);
-    return;
-  }
-  if (p.stat_part) {
-    float* red1 = red;
-    float* red2 = red + 4 * CO_T;
-    constexpr float cnt = (float)(TH * TW);
-#pragma unroll
-    for (int j = 0; j < C::NT; ++j) {
-      float s = bsum[j];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < C::NT; ++j) {
-      const int col = j * 16 + (lane & 15);
-      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < C::MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = acc[i][j][r] - mean_b;
-          q = fmaf(d, d, q);
+            for (int r = 0; r < 4; ++r) v[r] = (v[r] * u1) * u2 + bias;
+            acc[i][j] = v;
+            if (!WSL_ABLATED(p, 4) || v[0] == 123.456f)
+              *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            bs += (v[0] + v[1]) + (v[2] + v[3]);
+          }
+          bsum[j] = bs;
         }
-      q += __shfl_xor(q, 16);
-      q += __shfl_xor(q, 32);
-      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
-    }
-    __syncthreads();
-    if (wave == 0 && lane < 16) {
-#pragma unroll
-      for (int j = 0; j < C::NT; ++j) {
-        const int col = j * 16 + lane, co = co0 + col;
-        float* dst = p.stat_part + ((int64_t)co * nb + tile_id) * 2;   // [Co][nblk][2]
-        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
-        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
       }
-      if (lane == 0 && blockIdx.y == 0) p.stat_cnt[tile_id] = cnt;
+      bool bn_done = false;
+      if constexpr (C::MT * C::NT * 4 <= 32) if (p.bn.part) {
+        float s1[C::NT], s2[C::NT];
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+          const int co = co0 + j * 16 + (lane & 15);
+          const float mean = p.bn.st[co], invstd = p.bn.st[Co + co], sc = p.bn.st[2 * Co + co], sh = p.bn.st[3 * Co + co];
+          const int64_t base = ((int64_t)n * Co + co) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+          BnBwdAcc ba;
+#pragma unroll
+          for (int i = 0; i < C::MT; ++i) {
+            bn_bwd_acc4(p.bn, base + (i / C::SEGS) * W + (i % C::SEGS) * 16, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3],
+                        mean, invstd, sc, sh, ba);
+          }
+          bn_bwd_fold(ba, s1[j], s2[j]);
+        }
+        bn_bwd_store<C::NT, CO_T>(p.bn, s1, s2, red, co0, Co, t, nb);
+        bn_done = true;
+      }
+      if (!bn_done && p.stat_part) {
+        float* red1 = red;
+        float* red2 = red + 4 * CO_T;
+        constexpr float cnt = (float)(TH * TW);
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+          float s = bsum[j];
+          s += __shfl_xor(s, 16);
+          s += __shfl_xor(s, 32);
+          if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+          const int col = j * 16 + (lane & 15);
+          const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
+          float q = 0.f;
+#pragma unroll
+          for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = acc[i][j][r] - mean_b;
+              q = fmaf(d, d, q);
+            }
+          q += __shfl_xor(q, 16);
+          q += __shfl_xor(q, 32);
+          if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 16) {
+#pragma unroll
+          for (int j = 0; j < C::NT; ++j) {
+            const int col = j * 16 + lane, co = co0 + col;
+            float* dst = p.stat_part + ((int64_t)co * nb + t) * 2;   // [Co][nblk][2]
+            dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
+            dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
+          }
+          if (lane == 0 && blockIdx.y == 0) p.stat_cnt[t] = cnt;
+        }
+      }
     }
+    __syncthreads();   // the images (and `red`) are free again
+    if constexpr (!BRES) if (nt < tend) dma_weights(nc0);
   }
 }
 
@@ -466,37 +507,47 @@ struct SpPlan {
   int th, tw, co_t;
   bool ok;
 };
-// tile shape per layer: 8 x 32 pixels (16 x 16 at the deepest level), the widest output-channel block that still leaves >= 2
+// tile shape per layer: 8 x 32 pixels (8 x 16 below 32 columns), the widest output-channel block that still leaves >= 2
 // workgroups per CU
 static SpPlan sp_plan(int N, int H, int W, int Ci, int Co) {
   SpPlan f{0, 0, 0, false};
   if (Ci <= 0 || Co <= 0 || (Ci % 16) || (Co % 16) || Ci > kSpMaxC) return f;
   if (H % 8 == 0 && W % 32 == 0) f.th = 8, f.tw = 32;
-  else if (H % 16 == 0 && W % 16 == 0) f.th = 16, f.tw = 16;
+  else if (H % 8 == 0 && W % 16 == 0) f.th = 8, f.tw = 16;
   else return f;
   const int64_t tiles = (int64_t)N * (H / f.th) * (W / f.tw);
   f.co_t = 16;
   if (Co % 32 == 0) f.co_t = 32;
-  if (Co % 64 == 0 && tiles * (Co / 64) >= 2 * device_cu_count()) f.co_t = 64;
+  if (Co % 64 == 0 && f.tw == 32 && tiles * (Co / 64) >= 2 * device_cu_count()) f.co_t = 64;   // (8 x 16 x 64 spills)
   f.ok = true;
   return f;
 }
 
-template <int TH, int TW, int CO_T>
+template <int TH, int TW, int CO_T, bool BRES>
 static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
   using C = ConvSpCfg<TH, TW, CO_T>;
-  auto kern = conv_sp_kernel<TH, TW, CO_T>;
+  auto kern = conv_sp_kernel<TH, TW, CO_T, BRES>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::smem(BRES ? 1024 / CO_T : kSpMaxC, BRES));
     attr_done = true;
   }
-  dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
+  const size_t smem = C::smem(p.Ci, BRES);
+  // persistent: as many workgroups as stay resident (registers: MINW per SIMD; LDS), spread over the output-channel blocks
+  int per_cu = (int)((size_t)160 * 1024 / smem);
+  if (per_cu > C::MINW) per_cu = C::MINW;
+  if (per_cu < 1) per_cu = 1;
+  const int co_blocks = p.Co / CO_T;
+  int gx = per_cu * device_cu_count() / co_blocks;
+  if (gx < 1) gx = 1;
+  if (gx > p.ntiles) gx = p.ntiles;
+  if (gx >= 8) gx &= ~7;   // the XCD-wise tile walk wants a multiple of eight
+  dim3 grid(gx, co_blocks);
   const double px = (double)p.N * p.H * p.W;
   // issued = the three f16 passes over the tap-padded K (10 / 9)
   void* tok = prof_begin(is_dgrad ? PF_SP_DGRAD : PF_SP_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
                          2.0 * px * p.Co * p.Ci * 10 * 3);
-  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
+  WSL_LAUNCH(kern, grid, dim3(kThreads), smem, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_sp_kernel");
 }
@@ -516,13 +567,17 @@ static int sp_conv_launch(const WslSrc& a, const WslSrc* b, const void* image, c
   p.img = static_cast<const wsl_u4*>(image), p.w_amax = w_amax, p.in_amax = in_amax;
   p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   const SpPlan f = sp_plan(N, H, W, p.Ci, Co);
-  p.tiles_x = W / f.tw, p.tiles_y = H / f.th;
+  p.tiles_x = W / f.tw, p.tiles_y = H / f.th, p.ntiles = N * p.tiles_x * p.tiles_y;
+  static const int ablate = WSL_TUNE("WSL_SP_ABLATE", 0);
+  p.ablate = ablate;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
   if (bn && bn->part && f.th * f.tw * f.co_t <= 8192) p.bn = *bn;   // instantiations with <= 32 accumulator registers
   if (bn_done) *bn_done = p.bn.part ? 1 : 0;
-#define WSL_CASE(TH_, TW_, CO_) \
-  if (f.th == TH_ && f.tw == TW_ && f.co_t == CO_) return launch_conv_sp<TH_, TW_, CO_>(p, is_dgrad, stream);
-  WSL_CASE(8, 32, 16) WSL_CASE(8, 32, 32) WSL_CASE(8, 32, 64) WSL_CASE(16, 16, 16) WSL_CASE(16, 16, 32) WSL_CASE(16, 16, 64)
+  const bool bres = p.Ci * f.co_t <= 1024;   // the block's weight image of every chunk stays in LDS (<= 40 KB)
+#define WSL_CASE(TH_, TW_, CO_)                                                    \
+  if (f.th == TH_ && f.tw == TW_ && f.co_t == CO_)                                 \
+    return bres ? launch_conv_sp<TH_, TW_, CO_, true>(p, is_dgrad, stream) : launch_conv_sp<TH_, TW_, CO_, false>(p, is_dgrad, stream);
+  WSL_CASE(8, 32, 16) WSL_CASE(8, 32, 32) WSL_CASE(8, 32, 64) WSL_CASE(8, 16, 16) WSL_CASE(8, 16, 32)
 #undef WSL_CASE
   set_error("sp_conv: no kernel for tile %dx%d co_t %d", f.th, f.tw, f.co_t);
   return WSL_EUNSUPPORTED;
@@ -614,39 +669,81 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
     sp_issue<II>(tki, pri, src.x + n * src.bs, src.emask ? src.emask + (int64_t)n * src.C * HW : nullptr, chb, HW);
     sp_issue<ID>(tkd, prd, p.dy + n * p.dy_bs, nullptr, co0, HW);
   };
-  int t = split;
-  if (t < p.items) issue(t);
+  // every split owns one contiguous run of tiles: neighbouring tiles share their halo lines, and walked back to back by one
+  // workgroup those lines are still in its CU's L1 / its XCD's L2 (dealt round-robin, three XCDs fetch them over the fabric)
+  const int run = (p.items + p.nsplit - 1) / p.nsplit;
+  int t = split * run;
+  const int t_end = (t + run < p.items) ? t + run : p.items;
+  if (t < t_end) issue(t);
   __syncthreads();   // tab visible
-  while (t < p.items) {
+  while (t < t_end) {
     if (src.cmask && tid < CB) cm_l[tid] = src.cmask[(int64_t)n * src.C + chb + tid];
     if (src.cmask) __syncthreads();
     sp_commit<II>(tki, pri, in_img, tab, cm_l, 0, src.scale != nullptr, src.emask != nullptr, src.cmask != nullptr, src.es,
                   src.scale == nullptr, act_mul, true);
     sp_commit<ID>(tkd, prd, dy_img, tab, cm_l, 0, false, false, false, 1.f, true, dy_mul, true);
     __syncthreads();
-    const int tn = t + p.nsplit;
-    if (tn < p.items) issue(tn);   // in flight during the MFMA phase
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      if (CB == 16 && (ks & 3) != wave) continue;
-      const int dk = ks * C::KROWS * ID::ROWB, ik = ks * C::KROWS * II::ROWB;
+    const int tn = t + 1;
+    if (tn < t_end) issue(tn);   // in flight during the MFMA phase
+    auto read_a = [&](int ks, wsl_u4& ah, wsl_u4& al) __attribute__((always_inline)) {
+      const int dk = ks * C::KROWS * ID::ROWB;
       const wsl_u2 a0 = WSL_DS_READ_TR16(dy_img + dyo[0] + dk), a1 = WSL_DS_READ_TR16(dy_img + dyo[1] + dk);
       const wsl_u2 a2 = WSL_DS_READ_TR16(dy_img + ID::HL + dyo[0] + dk), a3 = WSL_DS_READ_TR16(dy_img + ID::HL + dyo[1] + dk);
-      const wsl_u4 ah = {a0[0], a0[1], a1[0], a1[1]}, al = {a2[0], a2[1], a3[0], a3[1]};
-      if (want_db) {
-        accdb = WSL_MFMA_F16(al, ones, accdb);
-        accdb = WSL_MFMA_F16(ah, ones, accdb);
-      }
+      ah = wsl_u4{a0[0], a0[1], a1[0], a1[1]}, al = wsl_u4{a2[0], a2[1], a3[0], a3[1]};
+    };
+    auto read_b = [&](int row_off, int kx, wsl_u4& bh, wsl_u4& bl) __attribute__((always_inline)) {
+      const unsigned char* q = in_img + row_off;
+      const wsl_u2 b0 = WSL_DS_READ_TR16(q + ino[0][kx]), b1 = WSL_DS_READ_TR16(q + ino[1][kx]);
+      const wsl_u2 b2 = WSL_DS_READ_TR16(q + II::HL + ino[0][kx]), b3 = WSL_DS_READ_TR16(q + II::HL + ino[1][kx]);
+      bh = wsl_u4{b0[0], b0[1], b1[0], b1[1]}, bl = wsl_u4{b2[0], b2[1], b3[0], b3[1]};
+    };
+    if constexpr (CB == 32 && TW == 32) {
+      // a K-step is one tile row: walk the INPUT rows r = 0 .. TH + 1 of the halo image; the three column-shifted operands of row r
+      // serve output rows r, r - 1, r - 2 (taps ky = 0, 1, 2), whose dy operands stay in registers for three input rows --
+      // 12 + 4 transpose reads per 27 MFMAs instead of 36 + 4
+      wsl_u4 ah[3], al[3];   // dy operands of output rows r, r - 1, r - 2 (slot y % 3)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
-        const unsigned char* q = in_img + ik + ky * II::ROWB;
-        const wsl_u2 b0 = WSL_DS_READ_TR16(q + ino[0][kx]), b1 = WSL_DS_READ_TR16(q + ino[1][kx]);
-        const wsl_u2 b2 = WSL_DS_READ_TR16(q + II::HL + ino[0][kx]), b3 = WSL_DS_READ_TR16(q + II::HL + ino[1][kx]);
-        const wsl_u4 bh = {b0[0], b0[1], b1[0], b1[1]}, bl = {b2[0], b2[1], b3[0], b3[1]};
-        acc[tap] = WSL_MFMA_F16(ah, bl, acc[tap]);
-        acc[tap] = WSL_MFMA_F16(al, bh, acc[tap]);
-        acc[tap] = WSL_MFMA_F16(ah, bh, acc[tap]);
+      for (int r = 0; r < TH + 2; ++r) {
+        if (r < TH) {
+          read_a(r, ah[r % 3], al[r % 3]);
+          if (want_db) {
+            accdb = WSL_MFMA_F16(al[r % 3], ones, accdb);
+            accdb = WSL_MFMA_F16(ah[r % 3], ones, accdb);
+          }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          wsl_u4 bh, bl;
+          read_b(r * II::ROWB, kx, bh, bl);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int y = r - ky;
+            if (y >= 0 && y < TH) {
+              acc[ky * 3 + kx] = WSL_MFMA_F16(ah[y % 3], bl, acc[ky * 3 + kx]);
+              acc[ky * 3 + kx] = WSL_MFMA_F16(al[y % 3], bh, acc[ky * 3 + kx]);
+              acc[ky * 3 + kx] = WSL_MFMA_F16(ah[y % 3], bh, acc[ky * 3 + kx]);
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        if (CB == 16 && (ks & 3) != wave) continue;
+        wsl_u4 ah, al;
+        read_a(ks, ah, al);
+        if (want_db) {
+          accdb = WSL_MFMA_F16(al, ones, accdb);
+          accdb = WSL_MFMA_F16(ah, ones, accdb);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          wsl_u4 bh, bl;
+          read_b(ks * C::KROWS * II::ROWB + (tap / 3) * II::ROWB, tap % 3, bh, bl);
+          acc[tap] = WSL_MFMA_F16(ah, bl, acc[tap]);
+          acc[tap] = WSL_MFMA_F16(al, bh, acc[tap]);
+          acc[tap] = WSL_MFMA_F16(ah, bh, acc[tap]);
+        }
       }
     }
     __syncthreads();

@@ -213,8 +213,10 @@ struct WgBatch {
 static int wgrad_layer(const Ctx& c, const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db, int H,
                        int W, int Co, int ks, const uint32_t* dy_amax = nullptr) {
   const int N = c.P.d.N, Ci = a->C + (b ? b->C : 0);
+  // (the split weight gradient is taken where it wins: 32-channel blocks on both sides.  On the 16-channel full-resolution layers
+  // the f32 Winograd kernel is the faster one -- profiles/r3_sweep_layers_sp.md -- and just as much an fp32 result.)
   const bool sp = c.P.sp && dy_amax && ks == 3 && wsl_sp_conv2d_ok(a, b, nullptr, 0, N, H, W, Co, 3) &&
-                  !(reinterpret_cast<uintptr_t>(dy) & 15) && !(dy_bs & 3);
+                  !(reinterpret_cast<uintptr_t>(dy) & 15) && !(dy_bs & 3) && Co % 32 == 0 && a->C % 32 == 0 && (!b || b->C % 32 == 0);
   const size_t need = ((sp ? wsl_sp_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co) : wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, ks)) + 255) &
                       ~(size_t)255;
   WgBatch* wb = c.wb;
