@@ -47,6 +47,22 @@ def close(a, b, tol=1e-4):
 
 
 _RATES = []
+_SUMMARY = []
+
+
+def summary_line(text):
+    """A measured margin that should reach the terminal even under `pytest -q` (the driver's record keeps the tail of the
+    output): printed by pytest_terminal_summary below."""
+    _SUMMARY.append(str(text))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if _RATES or _SUMMARY:
+        terminalreporter.write_sep("-", "measured margins (label-map mismatches in pixels; error budgets)")
+        for r in _RATES:
+            terminalreporter.write_line(f"LABELMAP {r['test']}: {r['mismatched_px']} of {r['pixels']} px differ (allowed {r['allowed_px']})")
+        for t in _SUMMARY:
+            terminalreporter.write_line(t)
 
 
 def labelmap_mismatch(name, got, ref, allow_px):

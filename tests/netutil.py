@@ -115,3 +115,51 @@ class KinkMargins:
 
     def __exit__(self, *exc):
         self._F.batch_norm, self._F.max_pool2d = self._bn, self._mp
+
+
+class DecisionReplay:
+    """Context manager around ORACLE forwards (oracle.torch_ref calls F.leaky_relu once per BatchNorm layer and F.max_pool2d(x, 2)
+    once per encoder level, in state_dict order).  record=True: keeps the oracle's own decisions (`signs`: bool [N,C,H,W] per
+    BatchNorm layer, `args`: uint8 [N,C,H/2,W/2] first-maximum position per pooling).  Otherwise the given decisions REPLACE the
+    oracle's: LeakyReLU becomes  where(sign, z, 0.01 z)  and the pooling a gather -- the forward then is the piecewise-linear
+    function another implementation evaluated, and its autograd gradient is what that implementation's backward must reproduce
+    element by element."""
+
+    def __init__(self, signs=None, args=None, record=False):
+        self.signs, self.args, self.record = (signs or []), (args or []), record
+        self._i = self._j = 0
+
+    @staticmethod
+    def _windows(x):
+        N, C, H, W = x.shape
+        return x.reshape(N, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H // 2, W // 2, 4)
+
+    def __enter__(self):
+        import torch
+        import torch.nn.functional as F
+        self._F, self._lr, self._mp = F, F.leaky_relu, F.max_pool2d
+
+        def lr(z, slope=0.01, *a, **kw):
+            if self.record:
+                self.signs.append(z > 0)
+                return self._lr(z, slope, *a, **kw)
+            m = self.signs[self._i]
+            self._i += 1
+            return torch.where(m.to(torch.bool), z, z * slope)
+
+        def mp(x, k, *a, **kw):
+            if k != 2:
+                return self._mp(x, k, *a, **kw)
+            v = self._windows(x)
+            if self.record:
+                self.args.append(torch.argmax(v, dim=-1).to(torch.uint8))     # first index on ties, like the strict '>' scan
+                return self._mp(x, k, *a, **kw)
+            idx = self.args[self._j]
+            self._j += 1
+            return torch.gather(v, -1, idx.long().unsqueeze(-1)).squeeze(-1)
+        F.leaky_relu, F.max_pool2d = lr, mp
+        return self
+
+    def __exit__(self, *exc):
+        self._F.leaky_relu, self._F.max_pool2d = self._lr, self._mp
+        return False

@@ -22,6 +22,15 @@ CASES = [  # N, H, W, Ca, Cb, Co, transforms on a
     (1, 16, 16, 64, 0, 16, False),
     (3, 8, 32, 16, 16, 128, True),
 ]
+# sizes at which the GPU launches take the shapes of the full-size step: 64-channel output blocks with streamed weight blocks,
+# several tiles per persistent workgroup, weight-gradient runs of several tiles per split (the emulator reaches the same code with
+# its single "CU"; it runs the small cases only for time)
+BIG = [
+    (32, 64, 64, 64, 0, 64, "bn"),
+    (32, 32, 64, 32, 32, 64, True),
+    (48, 32, 32, 128, 0, 128, "bn"),
+    (8, 128, 128, 32, 0, 32, True),
+]
 
 
 def _amax_bits(be):
@@ -35,10 +44,18 @@ def _set_amax(be, slot, value):
     return be.arr(a)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", BIG)
+def test_sp_conv_big_gpu(case):
+    from conftest import get_backend
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    test_sp_conv_fwd_dgrad_wgrad(get_backend("hip"), case)
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_sp_conv_fwd_dgrad_wgrad(be, case):
     N, H, W, Ca, Cb, Co, tr = case
-    rng = np.random.default_rng(1000 + CASES.index(case))     # (hash() of a tuple holding a str changes from process to process)
+    rng = np.random.default_rng(1000 + (CASES + BIG).index(case))     # (hash() of a tuple holding a str changes from process to process)
     xa = rng.standard_normal((N, Ca, H, W)).astype(np.float32)
     xb = (rng.standard_normal((N, Cb, H, W)) * 3).astype(np.float32) if Cb else None
     Ci = Ca + Cb

@@ -102,12 +102,34 @@ __device__ __forceinline__ void sp_issue(const SpTasks<I::NR>& t, SpRegs<I::NR>&
   }
 }
 
-// transform (BN + LeakyReLU, keep mask, channel multiplier -- the WslSrc loader), scale by `mul`, split, write hi / lo slots.
-// tab: LDS table {scale, shift}, cml: this sample's channel multipliers (global memory), both indexed by the channel inside the
-// concatenated input (tc0 = index of channel chb).  `zero_fill`: tasks outside the image write zero slots.
+// the {scale, shift} pairs of the tasks' octets: channels chb + 8 oct .. + 7 of one source (arrays 16-byte aligned: sp_src_ok),
+// fetched as two float4 pairs per task
+template <int NR>
+struct SpCoef {
+  float4 s[NR][2], h[NR][2];
+};
 template <typename I>
-__device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const float2* tab,
-                                          const float* cml, int tc0, bool has_scale, bool has_mask, bool has_cm, float es, bool has_mul,
+__device__ __forceinline__ void sp_coef_issue(const SpTasks<I::NR>& t, SpCoef<I::NR>& k, const float* scale, const float* shift, int chb) {
+#pragma unroll
+  for (int r = 0; r < I::NR; ++r) {
+    const float4* ps = reinterpret_cast<const float4*>(scale + chb + t.oct[r] * 8);
+    const float4* ph = reinterpret_cast<const float4*>(shift + chb + t.oct[r] * 8);
+    k.s[r][0] = ps[0], k.s[r][1] = ps[1], k.h[r][0] = ph[0], k.h[r][1] = ph[1];
+  }
+}
+__device__ __forceinline__ float sp_f4(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// transform (BN + LeakyReLU, keep mask, channel multiplier -- the WslSrc loader), scale by `mul`, split, write hi / lo slots.
+// cf: the thread's OWN BatchNorm coefficients {scale, shift} of the eight channels of each task, in REGISTERS, times cmul (the
+// operand scale of a BatchNorm source is folded into its coefficients: exact, a power of two) -- a
+// staging thread works on the same octet in every tile, so they are fetched from global memory (L1) once per kernel (weight
+// gradient) or per channel chunk (conv), never from an LDS table: table reads inside the staging code returned wrong pairs on
+// MI355X whenever a second workgroup shared the CU (profiles/r3_sp_hunt.md).  cml: this sample's channel multipliers (global
+// memory), indexed by the channel inside the concatenated input (tc0 = index of channel chb).  `zero_fill`: tasks outside the
+// image write zero slots.
+template <typename I>
+__device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const SpCoef<I::NR>& cf,
+                                          float cmul, const float* cml, int tc0, bool has_scale, bool has_mask, bool has_cm, float es, bool has_mul,
                                           float mul, bool zero_fill) {
 #pragma unroll
   for (int r = 0; r < I::NR; ++r) {
@@ -118,8 +140,7 @@ __device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<
         a[c] = wsl_v2f{g.v[r][c].x, g.v[r][c].y}, b[c] = wsl_v2f{g.v[r][c].z, g.v[r][c].w};
         const int ch = tc0 + t.oct[r] * 8 + c;
         if (has_scale) {
-          const float2 cf = tab[ch];
-          xform_bn_leaky(a[c], b[c], cf.x, cf.y);
+          xform_bn_leaky(a[c], b[c], sp_f4(cf.s[r][c >> 2], c & 3) * cmul, sp_f4(cf.h[r][c >> 2], c & 3) * cmul);
         }
         if (has_mask) xform_mask(a[c], b[c], g.m[r][c], es);
         if (has_cm) {
@@ -267,8 +288,8 @@ struct ConvSpCfg {
   static constexpr int RED_BYTES = 8 * CO_T * 4;
   // waves per SIMD the register allocator must leave room for (a tighter cap spills the staging state into scratch)
   static constexpr int MINW = NT == 1 ? 3 : 2;
-  static size_t smem(int Ci, bool bres) { return Img::BYTES + (size_t)(bres ? Ci / 16 : 1) * B_BYTES + RED_BYTES + 8 * (size_t)Ci; }
-  static_assert(MT_TOTAL % 4 == 0 && MT % SEGS == 0, "tile shape");
+  static size_t smem(int Ci, bool bres) { return Img::BYTES + (size_t)(bres ? Ci / 16 : 1) * B_BYTES + RED_BYTES; }
+  static_assert(MT_TOTAL % 4 == 0 && MT % SEGS == 0 && MT % 2 == 0, "tile shape");
 };
 
 template <int TH, int TW, int CO_T, bool BRES>
@@ -280,8 +301,7 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
   unsigned char* a_img = smem;
   unsigned char* b_img = smem + I::BYTES;
   float* red = reinterpret_cast<float*>(b_img + (size_t)(BRES ? Ci / 16 : 1) * C::B_BYTES);
-  float2* tab = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(red) + C::RED_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WSL_WAVE_UNIFORM(tid >> 6);
   const int co0 = blockIdx.y * CO_T;
   const int nb = p.ntiles;
 
@@ -307,14 +327,6 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
           reinterpret_cast<wsl_u4*>(b_img + (size_t)ch * C::B_BYTES)[tid + i * kThreads] = wb[woff[i]];
     }
   }
-  // loader table; the operand scale of a BatchNorm source is folded into its coefficients (exact: a power of two)
-  for (int c = tid; c < Ci; c += kThreads) {
-    const bool ina = c < p.a.C;
-    const SpSrc& s = ina ? p.a : p.b;
-    const int ch = ina ? c : c - p.a.C;
-    tab[c] = s.scale ? make_float2(s.scale[ch] * in_mul, s.shift[ch] * in_mul) : make_float2(1.f, 0.f);
-  }
-
   // A operand of K-step s: pixel m = lane & 15 of the row tile, octet (lane >> 4) & 1, tap 2 s + (lane >> 5)
   int aoff[5];
 #pragma unroll
@@ -364,18 +376,23 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
     issue();
     if constexpr (!BRES) dma_weights(0);
   }
-  __syncthreads();   // table (and resident weights) visible
+  __syncthreads();   // resident weights visible
 
   while (nt < tend) {
     const int t = nt, c0 = nc0, n = n_n;
     {   // ---- raw data -> hi / lo images
       const bool ina = c0 < p.a.C;
       const SpSrc& s = ina ? p.a : p.b;
+      // this chunk's BatchNorm coefficients: an L1 hit, requested here rather than with the tile data so that its 16 registers
+      // are not live across the MFMA loop
+      SpCoef<I::NR> coef;
+      if (s.scale) sp_coef_issue<I>(tk, coef, s.scale, s.shift, ina ? c0 : c0 - p.a.C);
+      WSL_WAIT_ALL();   // every requested load has landed
       const float* cmn = s.cmask ? s.cmask + (int64_t)n * s.C - (ina ? 0 : p.a.C) : nullptr;   // indexed by the table channel
       if (!WSL_ABLATED(p, 2) || (t == t_first && c0 == 0))
-        sp_commit<I>(tk, pre, a_img, tab, cmn, c0, s.scale != nullptr, s.emask != nullptr, s.cmask != nullptr, s.es,
+        sp_commit<I>(tk, pre, a_img, coef, in_mul, cmn, c0, s.scale != nullptr, s.emask != nullptr, s.cmask != nullptr, s.es,
                      s.scale == nullptr, in_mul, true);
-      if constexpr (!BRES) WSL_WAIT_ALL();   // this chunk's weight block has landed
+      WSL_WAIT_ALL();   // this chunk's streamed weight block has landed; every LDS store of this wave is complete
     }
     __syncthreads();
     // ---- request the next (tile, chunk)
@@ -399,20 +416,41 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
         bh[j] = *reinterpret_cast<const wsl_u4*>(q);
         bl[j] = *reinterpret_cast<const wsl_u4*>(q + 5 * 4 * CO_T * 16);
       }
+      // pairs of row tiles: four operand reads, one full LDS wait (WSL_LDS_READ_FENCE: counted waits are not safe here), 6 NT MFMAs
 #pragma unroll
-      for (int i = 0; i < C::MT; ++i) {
-        const int mt = wave * C::MT + i;
-        const unsigned char* q = a_img + aoff[s] + (mt / C::SEGS) * I::ROWB + (mt % C::SEGS) * 64;
-        const wsl_u4 ah = *reinterpret_cast<const wsl_u4*>(q), al = *reinterpret_cast<const wsl_u4*>(q + I::HL);
+      for (int i0 = 0; i0 < C::MT; i0 += 2) {
+        wsl_u4 ah[2], al[2];
 #pragma unroll
-        for (int j = 0; j < C::NT; ++j) {
-          acc[i][j] = WSL_MFMA_F16(ah, bl[j], acc[i][j]);
-          acc[i][j] = WSL_MFMA_F16(al, bh[j], acc[i][j]);
-          acc[i][j] = WSL_MFMA_F16(ah, bh[j], acc[i][j]);
+        for (int d = 0; d < 2; ++d) {
+          const int mt = wave * C::MT + i0 + d;
+          const unsigned char* q = a_img + aoff[s] + (mt / C::SEGS) * I::ROWB + (mt % C::SEGS) * 64;
+          ah[d] = *reinterpret_cast<const wsl_u4*>(q), al[d] = *reinterpret_cast<const wsl_u4*>(q + I::HL);
         }
+        WSL_LDS_READ_FENCE4(ah[0], al[0], ah[1], al[1]);
+        if (i0 == 0) {
+#pragma unroll
+          for (int j = 0; j < C::NT; ++j) WSL_LDS_READ_FENCE2(bh[j], bl[j]);
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int i = i0 + d;
+#pragma unroll
+          for (int j = 0; j < C::NT; ++j) {
+            WSL_MFMA_F16_INPLACE(ah[d], bl[j], acc[i][j]);
+            WSL_MFMA_F16_INPLACE(al[d], bh[j], acc[i][j]);
+            WSL_MFMA_F16_INPLACE(ah[d], bh[j], acc[i][j]);
+          }
+        }
+        WSL_MFMA_SRC_RELEASE4(ah[0], al[0], ah[1], al[1]);
       }
+#pragma unroll
+      for (int j = 0; j < C::NT; ++j) WSL_MFMA_SRC_RELEASE2(bh[j], bl[j]);
     }
     if (c0 + 16 >= Ci) {
+#pragma unroll
+      for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) WSL_MFMA_DRAIN(acc[i][j]);
       // ---- epilogue of tile t: undo the operand scales, bias, float4 stores, statistics (tiles and channel blocks are full)
       const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y;
       const int y0 = ty * TH, x0 = tx * TW;
@@ -529,13 +567,15 @@ static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
   auto kern = conv_sp_kernel<TH, TW, CO_T, BRES>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)WSL_SET_MAX_DYN_SMEM(kern, C::smem(BRES ? 1024 / CO_T : kSpMaxC, BRES));
+    (void)WSL_SET_MAX_DYN_SMEM(kern, C::smem(BRES ? 1024 / CO_T : kSpMaxC, BRES) + 4096);
     attr_done = true;
   }
   const size_t smem = C::smem(p.Ci, BRES);
   // persistent: as many workgroups as stay resident (registers: MINW per SIMD; LDS), spread over the output-channel blocks
   int per_cu = (int)((size_t)160 * 1024 / smem);
   if (per_cu > C::MINW) per_cu = C::MINW;
+  static const int percu_env = WSL_TUNE("WSL_SP_PERCU", 0);   // (experiments build)
+  if (percu_env > 0) per_cu = percu_env;
   if (per_cu < 1) per_cu = 1;
   const int co_blocks = p.Co / CO_T;
   int gx = per_cu * device_cu_count() / co_blocks;
@@ -555,7 +595,8 @@ static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 static bool sp_src_ok(const WslSrc& s) {
-  return s.x && aligned16(s.x) && !(s.bs & 3) && (!s.emask || !(reinterpret_cast<uintptr_t>(s.emask) & 3)) && (!s.scale || s.shift);
+  return s.x && aligned16(s.x) && !(s.bs & 3) && (!s.emask || !(reinterpret_cast<uintptr_t>(s.emask) & 3)) &&
+         (!s.scale || (s.shift && aligned16(s.scale) && aligned16(s.shift)));   // coefficient octets are fetched as float4 pairs
 }
 
 static int sp_conv_launch(const WslSrc& a, const WslSrc* b, const void* image, const uint32_t* w_amax, const uint32_t* in_amax,
@@ -604,7 +645,7 @@ struct WgradSpCfg {
   using In = SpImg<TH + 2, (TW + 8) / 4, CB / 8, (TW + 8) / 4>;
   using Dy = SpImg<TH, TW / 4, CB / 8, TW / 4>;
   static constexpr int KS = TH * TW / 32, KROWS = 32 / TW;      // K-steps per tile; tile rows per K-step
-  static constexpr size_t SMEM = In::BYTES + Dy::BYTES + sizeof(float) * 3 * kSpMaxC;
+  static constexpr size_t SMEM = In::BYTES + Dy::BYTES;
   static_assert(TW == 16 || TW == 32, "a K-step is one row of 32 pixels or two rows of 16");
   static_assert(CB == 32 || KS % 4 == 0, "the one-pair form splits the K-steps over the four waves");
 };
@@ -617,9 +658,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
   WSL_DYN_SMEM(smem);
   unsigned char* in_img = smem;
   unsigned char* dy_img = smem + II::BYTES;
-  float2* tab = reinterpret_cast<float2*>(smem + II::BYTES + ID::BYTES);
-  float* cm_l = reinterpret_cast<float*>(tab + kSpMaxC);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WSL_WAVE_UNIFORM(tid >> 6);
   const int cob = blockIdx.x / p.ci_blocks, cib = blockIdx.x - cob * p.ci_blocks;
   const int split = blockIdx.y;
   const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co, HW = H * W;
@@ -629,11 +668,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
   const int chb = ina ? ci0 : ci0 - p.a.C;
   const int e_dy = sp_exp_of(sp_amax_fold(p.dy_amax));
   const float dy_mul = sp_pow2(e_dy), act_mul = sp_pow2(WSL_SP_ACT_EXP);
-
-  for (int c = tid; c < CB; c += kThreads) {
-    tab[c] = src.scale ? make_float2(src.scale[chb + c] * act_mul, src.shift[chb + c] * act_mul) : make_float2(1.f, 0.f);
-    cm_l[c] = 1.f;   // (per sample: refreshed with every tile below)
-  }
 
   // operand addresses of K-step 0: supplier lane s = lane & 15 of a 16-lane group hands out pixel (s >> 2) (+ 4 for the second
   // read) of the group's eight, channels 4 (s & 3) .. + 3 of the 16-channel tile
@@ -675,13 +709,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
   int t = split * run;
   const int t_end = (t + run < p.items) ? t + run : p.items;
   if (t < t_end) issue(t);
-  __syncthreads();   // tab visible
+  // a thread stages the same octet of every tile: its eight BatchNorm coefficient pairs stay in registers for the whole kernel
+  SpCoef<II::NR> cfr;
+  if (src.scale && t < t_end) sp_coef_issue<II>(tki, cfr, src.scale, src.shift, chb);
   while (t < t_end) {
-    if (src.cmask && tid < CB) cm_l[tid] = src.cmask[(int64_t)n * src.C + chb + tid];
-    if (src.cmask) __syncthreads();
-    sp_commit<II>(tki, pri, in_img, tab, cm_l, 0, src.scale != nullptr, src.emask != nullptr, src.cmask != nullptr, src.es,
-                  src.scale == nullptr, act_mul, true);
-    sp_commit<ID>(tkd, prd, dy_img, tab, cm_l, 0, false, false, false, 1.f, true, dy_mul, true);
+    WSL_WAIT_ALL();   // every requested load has landed (as in conv_sp_kernel)
+    sp_commit<II>(tki, pri, in_img, cfr, act_mul, src.cmask ? src.cmask + (int64_t)n * src.C + chb : nullptr, 0, src.scale != nullptr,
+                  src.emask != nullptr, src.cmask != nullptr, src.es, src.scale == nullptr, act_mul, true);
+    sp_commit<ID>(tkd, prd, dy_img, SpCoef<ID::NR>{}, 1.f, nullptr, 0, false, false, false, 1.f, true, dy_mul, true);
+    WSL_WAIT_ALL();
     __syncthreads();
     const int tn = t + 1;
     if (tn < t_end) issue(tn);   // in flight during the MFMA phase
@@ -690,12 +726,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
       const wsl_u2 a0 = WSL_DS_READ_TR16(dy_img + dyo[0] + dk), a1 = WSL_DS_READ_TR16(dy_img + dyo[1] + dk);
       const wsl_u2 a2 = WSL_DS_READ_TR16(dy_img + ID::HL + dyo[0] + dk), a3 = WSL_DS_READ_TR16(dy_img + ID::HL + dyo[1] + dk);
       ah = wsl_u4{a0[0], a0[1], a1[0], a1[1]}, al = wsl_u4{a2[0], a2[1], a3[0], a3[1]};
+      WSL_LDS_READ_FENCE2(ah, al);   // (counted LDS waits are not safe for these reads: wsl_rt.h)
     };
     auto read_b = [&](int row_off, int kx, wsl_u4& bh, wsl_u4& bl) __attribute__((always_inline)) {
       const unsigned char* q = in_img + row_off;
       const wsl_u2 b0 = WSL_DS_READ_TR16(q + ino[0][kx]), b1 = WSL_DS_READ_TR16(q + ino[1][kx]);
       const wsl_u2 b2 = WSL_DS_READ_TR16(q + II::HL + ino[0][kx]), b3 = WSL_DS_READ_TR16(q + II::HL + ino[1][kx]);
       bh = wsl_u4{b0[0], b0[1], b1[0], b1[1]}, bl = wsl_u4{b2[0], b2[1], b3[0], b3[1]};
+      WSL_LDS_READ_FENCE2(bh, bl);
     };
     if constexpr (CB == 32 && TW == 32) {
       // a K-step is one tile row: walk the INPUT rows r = 0 .. TH + 1 of the halo image; the three column-shifted operands of row r
@@ -707,8 +745,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
         if (r < TH) {
           read_a(r, ah[r % 3], al[r % 3]);
           if (want_db) {
-            accdb = WSL_MFMA_F16(al[r % 3], ones, accdb);
-            accdb = WSL_MFMA_F16(ah[r % 3], ones, accdb);
+            WSL_MFMA_F16_INPLACE_V(al[r % 3], ones, accdb);
+            WSL_MFMA_F16_INPLACE_V(ah[r % 3], ones, accdb);
           }
         }
 #pragma unroll
@@ -719,12 +757,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
           for (int ky = 0; ky < 3; ++ky) {
             const int y = r - ky;
             if (y >= 0 && y < TH) {
-              acc[ky * 3 + kx] = WSL_MFMA_F16(ah[y % 3], bl, acc[ky * 3 + kx]);
-              acc[ky * 3 + kx] = WSL_MFMA_F16(al[y % 3], bh, acc[ky * 3 + kx]);
-              acc[ky * 3 + kx] = WSL_MFMA_F16(ah[y % 3], bh, acc[ky * 3 + kx]);
+              WSL_MFMA_F16_INPLACE(ah[y % 3], bl, acc[ky * 3 + kx]);
+              WSL_MFMA_F16_INPLACE(al[y % 3], bh, acc[ky * 3 + kx]);
+              WSL_MFMA_F16_INPLACE(ah[y % 3], bh, acc[ky * 3 + kx]);
             }
           }
+          WSL_MFMA_SRC_RELEASE2(bh, bl);
         }
+        if (r >= 2) WSL_MFMA_SRC_RELEASE2(ah[(r - 2) % 3], al[(r - 2) % 3]);   // output row r - 2 is complete: its slot is re-read next
       }
     } else {
 #pragma unroll
@@ -733,23 +773,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
         wsl_u4 ah, al;
         read_a(ks, ah, al);
         if (want_db) {
-          accdb = WSL_MFMA_F16(al, ones, accdb);
-          accdb = WSL_MFMA_F16(ah, ones, accdb);
+          WSL_MFMA_F16_INPLACE_V(al, ones, accdb);
+          WSL_MFMA_F16_INPLACE_V(ah, ones, accdb);
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           wsl_u4 bh, bl;
           read_b(ks * C::KROWS * II::ROWB + (tap / 3) * II::ROWB, tap % 3, bh, bl);
-          acc[tap] = WSL_MFMA_F16(ah, bl, acc[tap]);
-          acc[tap] = WSL_MFMA_F16(al, bh, acc[tap]);
-          acc[tap] = WSL_MFMA_F16(ah, bh, acc[tap]);
+          WSL_MFMA_F16_INPLACE(ah, bl, acc[tap]);
+          WSL_MFMA_F16_INPLACE(al, bh, acc[tap]);
+          WSL_MFMA_F16_INPLACE(ah, bh, acc[tap]);
+          WSL_MFMA_SRC_RELEASE2(bh, bl);
         }
+        WSL_MFMA_SRC_RELEASE2(ah, al);
       }
     }
     __syncthreads();
     t = tn;
   }
 
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) WSL_MFMA_DRAIN(acc[tap]);
+  WSL_MFMA_DRAIN(accdb);
   // ---- partials: D[row = co][col = ci]; lane holds rows 4 (lane >> 4) + r of column lane & 15
   const float u1 = sp_pow2(-e_dy), u2 = sp_pow2(-WSL_SP_ACT_EXP);
   const int sidx = CB == 32 ? split : split * 4 + wave;
@@ -911,3 +956,4 @@ extern "C" int wsl_sp_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, con
   pending->Co = Co, pending->Ci = Ci, pending->KK = 9, pending->nsplit = g.splits;
   return WSL_OK;
 }
+

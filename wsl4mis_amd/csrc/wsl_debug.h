@@ -13,6 +13,17 @@ int wsl_debug_conv_plan(int th, int tw, int co_t);
  * layers with Co % 16 == 0; -1 restores the default. */
 int wsl_debug_conv_wino(int on);
 
+/* The discrete decisions of the training forward held in a network workspace (wsl_net_forward(training = 1) ran on `ws`), as the
+ * kernels take them -- the full-size gradient-parity test replays them in the oracle, so that two fp32 implementations are compared
+ * on the SAME piecewise-linear function instead of on whichever side of a LeakyReLU kink round-off put them.
+ *   which 0: index = BatchNorm layer in state_dict order (0 .. 25 for unet_cct): out uint8 [N, C, H, W], 1 where the LeakyReLU
+ *            argument  fma(y, scale, shift)  is > 0 (the loader's expression, bit for bit), else 0;
+ *   which 1: index = encoder level l = 1 .. 4: out uint8 [N, C, H/2, W/2] of level l - 1's feature, the position 0 .. 3 (row-major
+ *            in the 2 x 2 window) the max-pool takes (first maximum, strict >: the forward kernel's scan). */
+struct WslNetDesc;
+int wsl_debug_net_decisions(const struct WslNetDesc* d, const void* ws, size_t ws_bytes, int which, int index, unsigned char* out,
+                            void* stream);
+
 /* Only in the EXPERIMENTS build (-DWSL_EXPERIMENTS: `build.sh exp` -> tools/exp/libwslhip_exp.so, and the host emulator):
  * measured-slower kernel families kept for A/B timing, ablation switches (env WSL_CONV_ABLATE / WSL_WGRAD_ABLATE: they skip
  * work, results are WRONG by design), ~20 env tuning knobs (WSL_TUNE in wsl_rt.h) and three machine probes. */

@@ -669,6 +669,64 @@ extern "C" int wsl_net_backward(const WslNetDesc* d, const float* params, const 
   return WSL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ test hook: the forward's decisions
+namespace wsl {
+__global__ __launch_bounds__(256) void dbg_sign_kernel(const float* y, const float* sc, const float* sh, unsigned char* out, int C, int HW) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float a = sc[c], b = sh[c];
+  const int64_t base = ((int64_t)n * C + c) * HW;
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < HW; i += gridDim.x * kThreads) out[base + i] = fmaf(y[base + i], a, b) > 0.f ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void dbg_argmax_kernel(const float* y, const float* sc, const float* sh, unsigned char* out, int C, int H,
+                                                         int W) {
+  const int c = blockIdx.y, n = blockIdx.z, Ho = H / 2, Wo = W / 2;
+  const float a = sc[c], b = sh[c];
+  const float* p = y + ((int64_t)n * C + c) * H * W;
+  for (int o = blockIdx.x * kThreads + threadIdx.x; o < Ho * Wo; o += gridDim.x * kThreads) {
+    const int oy = o / Wo, ox = o - oy * Wo;
+    float best = 0.f;
+    int arg = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = leaky(fmaf(p[(int64_t)(2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)], a, b));
+      if (k == 0 || v > best) best = v, arg = k;
+    }
+    out[((int64_t)n * C + c) * Ho * Wo + o] = (unsigned char)arg;
+  }
+}
+}  // namespace wsl
+
+extern "C" int wsl_debug_net_decisions(const WslNetDesc* d, const void* ws, size_t ws_bytes, int which, int index, unsigned char* out,
+                                       void* stream) {
+  Plan P;
+  WSL_TRY(make_plan(d, P));
+  WSL_REQUIRE(ws && out && ws_bytes >= P.total_floats * sizeof(float), "debug_net_decisions: bad workspace");
+  const float* w = static_cast<const float*>(ws);
+  size_t y = 0, st = 0;
+  int C = 0, l = 0;
+  if (which == 0) {
+    WSL_REQUIRE(index >= 0 && index < (int)P.n_bn, "debug_net_decisions: BatchNorm layer %d of %d", index, (int)P.n_bn);
+    bool found = false;
+    auto look = [&](const BlockRef& k, const BlkWs& bw, int lev) {
+      if (k.b1.nbt == index) y = bw.y1, st = bw.st1, C = k.b1.C, l = lev, found = true;
+      if (k.b2.nbt == index) y = bw.y2, st = bw.st2, C = k.b2.C, l = lev, found = true;
+    };
+    for (int lev = 0; lev < 5; ++lev) look(P.enc[lev], P.wenc[lev], lev);
+    for (int k = 0; k < d->n_dec; ++k)
+      for (int i = 0; i < 4; ++i) look(P.dec[k].blk[i], P.wdec[k].blk[i], 3 - i);
+    WSL_REQUIRE(found, "debug_net_decisions: layer not found");
+    const int HW = P.H[l] * P.W[l];
+    WSL_LAUNCH(dbg_sign_kernel, dim3(cdiv(HW, 4 * kThreads), C, d->N), dim3(kThreads), 0, stream, w + y, w + st + 2 * C, w + st + 3 * C, out,
+               C, HW);
+    return check_launch("dbg_sign_kernel");
+  }
+  WSL_REQUIRE(which == 1 && index >= 1 && index <= 4, "debug_net_decisions: which %d index %d", which, index);
+  l = index - 1, C = kFt[l];
+  WSL_LAUNCH(dbg_argmax_kernel, dim3(cdiv(P.H[l] * P.W[l] / 4, 4 * kThreads), C, d->N), dim3(kThreads), 0, stream, w + P.wenc[l].y2,
+             w + P.wenc[l].st2 + 2 * C, w + P.wenc[l].st2 + 3 * C, out, C, P.H[l], P.W[l]);
+  return check_launch("dbg_argmax_kernel");
+}
+
 // ================================================================================================ UpBlock, transposed-conv branch
 // UpBlock(in_channels1, in_channels2, out_channels, dropout_p, bilinear=False).forward(x1, x2)  (ref: networks/unet.py:47-68):
 //     x1 = ConvTranspose2d(C1, C2, kernel_size=2, stride=2)(x1);  x = cat([x2, x1], 1);  return ConvBlock(2 C2, Co, p)(x)
