@@ -49,6 +49,9 @@ def main(argv=None):
     ap.add_argument("--log_every", type=int, default=20)
     ap.add_argument("--quiet", action="store_true", help="no per-iteration lines (validation lines stay)")
     ap.add_argument("--curve_json", default=None, help="write the loss / validation curve here (rank 0)")
+    ap.add_argument("--oracle_stream", action="store_true", help="draw the nn.Dropout masks on the CPU generator in the order "
+                    "tools/oracle_acdc_short.py draws them (with --resume of its initial state and the same --seed, the two arms then "
+                    "run the SAME trajectory up to fp32 round-off: profiles/r3_acdc_short_schedule.md)")
     ap.add_argument("--resume", default=None, help="a state_dict .pth (the reference's or ours: same keys) to start from")
     args = ap.parse_args(argv)
 
@@ -84,7 +87,14 @@ def main(argv=None):
             if len(idx) < 2:                            # BatchNorm needs more than one slice
                 continue
             image, label = aug([train[int(i)] for i in idx])
+            if args.oracle_stream:
+                from wsl4mis_amd.networks.unet import _DROP, _FT
+                n, (ph, pw) = len(idx), args.patch_size
+                em = [(torch.rand((n, _FT[l], ph >> l, pw >> l)) >= _DROP[l]).to(torch.uint8).cuda() for l in range(5)]
+                eng.model.set_dropout_masks(em, None)
             eng.step(image, label, random.random() + 1e-10)
+            if args.oracle_stream:
+                eng.model.set_dropout_masks(None, None)
             it += 1
             if rank == 0 and (it % args.log_every == 0 or it == 1):
                 o = eng.losses()

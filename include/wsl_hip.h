@@ -214,7 +214,9 @@ size_t wsl_sp_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
 int wsl_sp_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, const uint32_t* dy_amax,
                                 float* dw, float* db, int N, int H, int W, int Co, void* ws, size_t ws_bytes,
                                 WslWgradPending* pending, void* stream);
-/* wsl_bnact_bwd / wsl_bnact_bwd_finish that also leave max |dy| in *dy_amax (NULL = the plain calls). */
+/* wsl_bnact_bwd / wsl_bnact_bwd_finish that also leave max |dy| in dy_amax[0 .. WSL_SP_AMAX_SLOTS) (NULL = the plain calls; every
+ * slot is written, none needs clearing).  Workspace of the finish form: wsl_bnact_bwd_finish_ws_bytes(..., dy_amax != NULL). */
+size_t wsl_bnact_bwd_finish_ws_bytes(int N, int C, int H, int W, int with_amax);
 int wsl_bnact_bwd_amax(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, const uint8_t* emask, float emask_scale, float* dy, float* dgamma, float* dbeta, int N,
                        int C, int H, int W, void* ws, size_t ws_bytes, uint32_t* dy_amax, void* stream);

@@ -38,6 +38,13 @@ def test_bnact_bwd(be, shape, drop):
     assert close(be.np(dy), yt.grad.numpy(), TOL)
     assert close(be.np(dgam), gt.grad.numpy(), TOL)
     assert close(be.np(dbet), bt.grad.numpy(), TOL)
+    # the same pass leaving max |dy| for the split-precision consumers: the largest of the 64 slots is the bit pattern of the maximum
+    # of the dy it wrote (every slot written: the garbage put there first must be gone), dy itself unchanged
+    dy2, slots = be.zeros(shape), be.arr(np.full(64, 0x7f7fffff, np.uint32).view(np.float32))
+    be.call("wsl_bnact_bwd_amax", be.ptr(d[0]), C * H * W, *[be.ptr(a) for a in d[1:]], be.ptr(dm) if drop else None, es,
+            be.ptr(dy2), be.ptr(dgam), be.ptr(dbet), N, C, H, W, be.ptr(ws), nws, be.ptr(slots), be.stream)
+    assert np.array_equal(be.np(dy2), be.np(dy))
+    assert be.np(slots).view(np.uint32).max() == np.abs(be.np(dy)).max().view(np.uint32)
 
 
 def test_pool_and_routing_golden(be):
@@ -228,3 +235,12 @@ def test_fan_in_with_bn_backward_statistics_equals_the_two_pass_form(be, shape, 
     assert np.array_equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert rel_err(b, a) < 2e-6
+    # stage 2 that also leaves max |dy| (larger workspace: one partial maximum per workgroup)
+    nfw = be.lib.wsl_bnact_bwd_finish_ws_bytes(N, C, H, W, 1)
+    assert nfw > 8 * C == be.lib.wsl_bnact_bwd_finish_ws_bytes(N, C, H, W, 0)
+    dy2, wsf, slots = be.zeros(shape), be.ws(nfw), be.arr(np.full(64, 0x7f7fffff, np.uint32).view(np.float32))
+    bn[9] = be.ptr(dy2)
+    be.call("wsl_bnact_bwd_finish_amax", *bn, be.ptr(ws), be.lib.wsl_feat_grad_combine_blocks(N, H, W), 0, be.ptr(wsf), nfw,
+            be.ptr(slots), be.stream)
+    assert np.array_equal(be.np(dy2), outs[1][1])
+    assert be.np(slots).view(np.uint32).max() == np.abs(outs[1][1]).max().view(np.uint32)

@@ -9,7 +9,7 @@ import sys
 
 
 def family(k):
-    for f in ("conv_wino2r_kernel", "conv_wino2_kernel", "wgrad_wino_kernel", "conv_wino_kernel", "conv_mfma2l_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "conv_cls_kernel", "conv_nk16_kernel", "wgrad_small_kernel",
+    for f in ("conv_sp_kernel", "wgrad_sp_kernel", "conv_wino2r_kernel", "conv_wino2_kernel", "wgrad_wino_kernel", "conv_wino_kernel", "conv_mfma2l_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "conv_cls_kernel", "conv_nk16_kernel", "wgrad_small_kernel",
               "conv_mfma2_kernel", "bnact_bwd_apply", "bnact_bwd_reduce", "gatedcrf_fwd", "feat_grad_combine", "bilinear_up2"):
         if f in k:
             return f

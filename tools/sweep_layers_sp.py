@@ -16,6 +16,8 @@ if "--exp" in sys.argv:          # the experiments build: WSL_SP_ABLATE and frie
     _lib = explib.use()
 else:
     from wsl4mis_amd import _lib  # noqa: E402
+    if os.environ.get("WSL_LIB"):          # any other build of the library (A / B timing)
+        _lib.LIB_PATH = os.environ["WSL_LIB"]
 
 L = _lib.lib()
 dev = torch.device("cuda:0")

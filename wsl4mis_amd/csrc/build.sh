@@ -11,8 +11,6 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 srcs=(wsl_api wsl_conv wsl_conv2 wsl_conv3 wsl_conv4 wsl_conv5 wsl_convsp wsl_bn wsl_convt wsl_loss wsl_optim wsl_net wsl_data)
-# extra flags for wsl_convsp.hip only (A / B builds of the hazard spacing: e.g. WSL_SP_FLAGS='-DWSL_SP_RELEASE_ASM="\"s_nop 0\""')
-SP_FLAGS="${WSL_SP_FLAGS:-}"
 mkdir -p "$here/build"
 objs=()
 pids=()
@@ -25,7 +23,6 @@ for s in "${srcs[@]}"; do
     # the Winograd kernels are bound by their vector-instruction count: the SLP vectoriser packs the output transforms into
     # v_pk_add_f32 and then pays more v_mov_b32 to un-interleave the results than it saved (-8 % vector instructions without)
     [ "$s" = "wsl_conv5" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
-    [ "$s" = "wsl_convsp" ] && extra="$SP_FLAGS"
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra -c "$here/$s.hip" -o "$o" &
     pids+=($!)
   fi
@@ -46,7 +43,6 @@ if [ "${1:-}" = "exp" ] || [ "${2:-}" = "exp" ]; then
     if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$here/wsl_debug.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
       extra=""
       [ "$s" = "wsl_conv5" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
-      [ "$s" = "wsl_convsp" ] && extra="$SP_FLAGS"
       "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DWSL_EXPERIMENTS $extra -c "$here/$s.hip" -o "$o" &
       pids+=($!)
     fi

@@ -339,28 +339,46 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce4_kernel(BnBwdP p, float*
   }
 }
 
-// max |v| over the workgroup's values into *amax: the bit patterns of non-negative floats order like the floats, and an integer
-// atomic max is order-independent -- what the split-precision consumers of dy scale their operand with (wsl_convsp.hip)
-// (one candidate per wave, spread over WSL_SP_AMAX_SLOTS words -- sp_amax_fold() in wsl_rt.h; a wave only issues the atomic when
-//  its maximum beats what the slot already holds, which a relaxed L2 load tells it: a running maximum is raised O(log n) times,
-//  so the atomics of a launch stay in the hundreds.  No LDS, no barrier.)
-__device__ __forceinline__ void amax_commit(float m, uint32_t* amax) {
+// max |dy| for the split-precision consumers of dy (wsl_convsp.hip scales its f16 operands from it): every workgroup of the apply
+// pass leaves ONE partial maximum (bit pattern of a non-negative float: orders like the float) in a scratch array, and a 64-block
+// fold kernel reduces them into the tensor's WSL_SP_AMAX_SLOTS slots.  No atomics: tens of thousands of short-lived workgroups
+// raising 64 words with atomicMax cost 70 us per launch (bnact_bwd_apply4: 126 us against 56 without the maximum, 19 % of the
+// split step -- profiles/r3_rocprofv3_kernel_stats_split_first.csv), with or without a pre-check load of the slot.
+__device__ __forceinline__ void amax_block_store(float m, uint32_t* pmax) {
+  __shared__ float mred[4];
 #pragma unroll
   for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(mred[0], mred[1]), fmaxf(mred[2], mred[3]));
     uint32_t u;
     memcpy(&u, &m, 4);
-    uint32_t* slot = amax + ((blockIdx.x * 4 + (threadIdx.x >> 6) + 5 * blockIdx.y + 11 * blockIdx.z) & (WSL_SP_AMAX_SLOTS - 1));
-#ifdef WSL_HOST_EMUL
-    const uint32_t cur = __atomic_load_n(slot, __ATOMIC_RELAXED);
-#else
-    const uint32_t cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-    if (u > cur) atomicMax(slot, u);
+    pmax[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = u;
+  }
+}
+// grid WSL_SP_AMAX_SLOTS: block b folds partials b, b + 64, ... into slots[b] (a plain store: the slots need no clearing)
+__global__ __launch_bounds__(256) void amax_fold_kernel(const uint32_t* pmax, int n, uint32_t* slots) {
+  __shared__ uint32_t ured[4];
+  uint32_t u = 0u;
+  for (int i = blockIdx.x + WSL_SP_AMAX_SLOTS * threadIdx.x; i < n; i += WSL_SP_AMAX_SLOTS * kThreads) {
+    const uint32_t v = pmax[i];
+    u = v > u ? v : u;
+  }
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)u, k);
+    u = o > u ? o : u;
+  }
+  if ((threadIdx.x & 63) == 0) ured[threadIdx.x >> 6] = u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = ured[0] > ured[1] ? ured[0] : ured[1], b = ured[2] > ured[3] ? ured[2] : ured[3];
+    slots[blockIdx.x] = a > b ? a : b;
   }
 }
 
-__global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const float* coef, float* dy, uint32_t* amax) {
+__global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const float* coef, float* dy, uint32_t* pmax) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float mean = p.mean[c], invstd = p.invstd[c];
   const float sc = p.gamma[c] * invstd, sh = fmaf(-mean, sc, p.beta[c]);
@@ -373,9 +391,9 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const f
     const float4 v = make_float4(sc * (d[0] - c1 - xh[0] * c2), sc * (d[1] - c1 - xh[1] * c2), sc * (d[2] - c1 - xh[2] * c2),
                                  sc * (d[3] - c1 - xh[3] * c2));
     *reinterpret_cast<float4*>(dy + ((int64_t)n * p.C + c) * p.HW + i) = v;
-    if (amax) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (pmax) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
-  if (amax) amax_commit(m, amax);
+  if (pmax) amax_block_store(m, pmax);   // (pmax is a kernel argument: uniform)
 }
 
 // part: [nblk][C][2] (sb = C, sc = 1: the stand-alone reduction pass and the fan-in kernel) or [C][nblk][2] (sb = 1, sc = nblk:
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_finalize_kernel(const float* pa
   }
 }
 
-__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(BnBwdP p, const float* coef, float* dy, uint32_t* amax) {
+__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(BnBwdP p, const float* coef, float* dy, uint32_t* pmax) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float mean = p.mean[c], invstd = p.invstd[c];
   const float sc = p.gamma[c] * invstd, sh = fmaf(-mean, sc, p.beta[c]);
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(BnBwdP p, const fl
     dy[((int64_t)n * p.C + c) * p.HW + i] = v;
     m = fmaxf(m, fabsf(v));
   }
-  if (amax) amax_commit(m, amax);
+  if (pmax) amax_block_store(m, pmax);   // (pmax is a kernel argument: uniform)
 }
 
 // ------------------------------------------------------------------------------------------------ bilinear x2
@@ -746,8 +764,11 @@ extern "C" int wsl_bnact_bwd_amax(const float* g, int64_t g_bs, const float* y, 
   else WSL_LAUNCH(bnact_bwd_reduce_kernel, grid, dim3(kThreads), 0, stream, p, part);
   WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, N * p.chunks, C, (int64_t)C, (int64_t)1,
              (double)N * H * W, dgamma, dbeta, coef);
-  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, dy_amax);
-  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, dy_amax);
+  // (the partial sums were consumed by the finalize kernel: their area now takes the apply pass' partial maxima)
+  uint32_t* pmax = dy_amax ? reinterpret_cast<uint32_t*>(part) : nullptr;
+  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
+  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
+  if (dy_amax) WSL_LAUNCH(amax_fold_kernel, dim3(WSL_SP_AMAX_SLOTS), dim3(kThreads), 0, stream, pmax, N * p.chunks * C, dy_amax);
   return check_launch("bnact_bwd");
 }
 
@@ -759,13 +780,19 @@ extern "C" int wsl_bnact_bwd(const float* g, int64_t g_bs, const float* y, const
                             nullptr, stream);
 }
 
+extern "C" size_t wsl_bnact_bwd_finish_ws_bytes(int N, int C, int H, int W, int with_amax) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return sizeof(float) * (2 * (size_t)C + (with_amax ? (size_t)N * cdiv(H * W, kChunk) * C : 0));
+}
+
 extern "C" int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
                                          const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
                                          float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
                                          int channel_major, void* ws, size_t ws_bytes, uint32_t* dy_amax, void* stream) {
   WSL_REQUIRE(g && y && mean && invstd && gamma && beta && dy && ws && part, "bnact_bwd_finish: null argument");
   WSL_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && nblk > 0, "bnact_bwd_finish: bad shape");
-  WSL_REQUIRE(ws_bytes >= sizeof(float) * 2 * (size_t)C, "bnact_bwd_finish: workspace needs 2 * C floats");
+  WSL_REQUIRE(ws_bytes >= wsl_bnact_bwd_finish_ws_bytes(N, C, H, W, dy_amax != nullptr),
+              "bnact_bwd_finish: workspace too small (wsl_bnact_bwd_finish_ws_bytes)");
   BnBwdP p{g, g_bs, y, mean, invstd, gamma, beta, emask, emask_scale, C, H * W, cdiv(H * W, kChunk)};
   ProfScope ps(PF_BN_BWD, 0.0, (double)N * C * H * W * (12.0 + (emask ? 1.0 : 0.0)), stream);     // the apply pass alone
   float* coef = static_cast<float*>(ws);
@@ -776,8 +803,10 @@ extern "C" int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const flo
   WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, nblk, C,
              channel_major ? (int64_t)1 : (int64_t)C, channel_major ? (int64_t)nblk : (int64_t)1, (double)N * H * W, dgamma, dbeta,
              coef);
-  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, dy_amax);
-  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, dy_amax);
+  uint32_t* pmax = dy_amax ? reinterpret_cast<uint32_t*>(coef + 2 * (size_t)C) : nullptr;
+  if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
+  else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
+  if (dy_amax) WSL_LAUNCH(amax_fold_kernel, dim3(WSL_SP_AMAX_SLOTS), dim3(kThreads), 0, stream, pmax, N * p.chunks * C, dy_amax);
   return check_launch("bnact_bwd_finish");
 }
 

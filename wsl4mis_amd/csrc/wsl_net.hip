@@ -43,7 +43,7 @@ struct Plan {
   // slot per conv layer (pack-table order) and one max |dy| slot per BatchNorm layer
   size_t spf, spd, sp_wmax, sp_dymax;
   int sp;
-  size_t wg_bytes, bn_bytes, total_floats;   // wg_bytes: per scratch set, room for the partials of EVERY layer of a phase
+  size_t wg_bytes, bn_bytes, bn_coef_bytes, total_floats;   // wg_bytes: per scratch set, room for the partials of EVERY layer of a phase
 };
 
 struct Bump {
@@ -166,12 +166,18 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   }
   P.wg_bytes = wg_enc > wg_dec ? wg_enc : wg_dec;
   const size_t big = N * kFt[0] * P.H[0] * P.W[0];  // largest activation (level 0; every deeper level is <= half)
+  // stage 2 of the BatchNorm backward from a producer's partial sums: coefficients + (split path) one partial maximum per workgroup
+  P.bn_coef_bytes = 0;
+  for (int l = 0; l < 5; ++l) {
+    const size_t b = wsl_bnact_bwd_finish_ws_bytes(d->N, kFt[l], P.H[l], P.W[l], 1);
+    if (b > P.bn_coef_bytes) P.bn_coef_bytes = b;
+  }
   for (int k = 0; k < d->n_dec; ++k) {
     Plan::Scratch& S = P.scr[k];
     S.tmp_g = B.take(big), S.tmp_g1 = B.take(big), S.tmp_dy = B.take(big);
     S.tmp_du = B.take(big / 4), S.tmp_gpool = B.take(big / 4);
     S.stat_part = B.take(max_stat), S.stat_cnt = B.take(max_cnt);
-    S.wg_ws = B.take((P.wg_bytes + 3) / 4), S.bn_ws = B.take((P.bn_bytes + 3) / 4), S.bn_coef = B.take(2 * kFt[4]);
+    S.wg_ws = B.take((P.wg_bytes + 3) / 4), S.bn_ws = B.take((P.bn_bytes + 3) / 4), S.bn_coef = B.take((P.bn_coef_bytes + 3) / 4);
   }
   if (d->n_dec == 1) P.scr[1] = P.scr[0];
   P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);  // packed [tap][ci][co] weight images (fwd / data-gradient)
@@ -329,7 +335,7 @@ static int bn_bwd(const Ctx& c, const float* g, int64_t g_bs, size_t y, size_t s
   if (gs.nblk)
     return wsl_bnact_bwd_finish_amax(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy,
                                      c.grads + bn.gamma, c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, gs.nblk,
-                                     gs.channel_major, c.ws + c.S().bn_coef, 2 * sizeof(float) * (size_t)C, sp_dymax(c, bn), c.stream);
+                                     gs.channel_major, c.ws + c.S().bn_coef, P.bn_coef_bytes, sp_dymax(c, bn), c.stream);
   return wsl_bnact_bwd_amax(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy, c.grads + bn.gamma,
                             c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, P.bn_bytes, sp_dymax(c, bn), c.stream);
 }
@@ -779,6 +785,7 @@ static int make_up_plan(const WslUpBlockDesc* d, UpPlan& U) {
   S.tmp_du = 0, S.tmp_gpool = 0;
   S.stat_part = B.take(max_stat), S.stat_cnt = B.take(max_cnt);
   S.wg_ws = B.take((P.wg_bytes + 3) / 4), S.bn_ws = B.take((P.bn_bytes + 3) / 4), S.bn_coef = B.take(2 * (size_t)d->Co + 64);
+  P.bn_coef_bytes = sizeof(float) * (2 * (size_t)d->Co + 64);
   P.scr[1] = P.scr[0];
   P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);
   P.winof = B.take(2 * P.n_param), P.winod = B.take(2 * P.n_param);
