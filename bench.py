@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--net", default="unet_cct", choices=["unet_cct", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--pmc-refresh", action="store_true", help="N=1: before the timed run, collect roofline.traffic IN THIS RUN -- two "
+                    "rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domain) of this same command at "
+                    "--steps 2 --warmup 1, aggregated by tools/pmc_traffic.py (adds about a minute)")
     ap.add_argument("--prof-timed", action="store_true",
                     help="also record per-launch events in the (overlapped) timed region -> roofline.timed_region_overlapped")
     ap.add_argument("--serial-decoders", action="store_true",
@@ -255,6 +258,30 @@ def main():
                                          "algo_GBps": round(r.bytes / (r.ms * 1e-3) / 1e9, 1)}
         return rows, fams
 
+    fresh_traffic = [None]
+
+    def pmc_refresh():
+        """two counter passes of this command in child processes (the GPU is still untouched by this process)"""
+        import shutil
+        import subprocess
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_traffic as agg
+        tmp = tempfile.mkdtemp(prefix="wsl_pmc_", dir="/tmp")
+        child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-prof",
+                 "--serial-decoders", "--conv-precision", args.conv_precision, "--loss", args.loss, "--net", args.net, "--batch", str(args.batch),
+                 "--size", str(args.size), "--crf-radius", str(args.crf_radius)]
+        try:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, ctr), "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=600, check=True)
+            fresh_traffic[0] = agg.aggregate(os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"))
+        except (OSError, subprocess.SubprocessError, AssertionError) as e:
+            print(f"[bench] --pmc-refresh failed ({e}); falling back to the committed record", file=sys.stderr)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     def pmc_traffic(name, grp, calls):
         """HBM bytes per launch of the dominant kernel family from the newest committed rocprofv3 PMC record
         (FETCH_SIZE / WRITE_SIZE in separate runs of this same command -- tools/pmc_traffic.py); the record's file name,
@@ -262,21 +289,28 @@ def main():
         import glob
         import hashlib
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=os.path.basename)          # r1z < r2a < ...: the newest round's record
-        if not cands:
+        if not cands and fresh_traffic[0] is None:
             return None
-        tfile = cands[-1]
+        tfile = cands[-1] if cands else "(none)"
         try:
-            raw = open(tfile, "rb").read()
-            tdoc = json.loads(raw)
+            if fresh_traffic[0] is not None:
+                tdoc = fresh_traffic[0]
+                raw = json.dumps(tdoc, sort_keys=True).encode()
+            else:
+                raw = open(tfile, "rb").read()
+                tdoc = json.loads(raw)
             tj = tdoc["kernels"]
-            keys = ("conv_wino2_kernel", "conv_wino_kernel") if name.startswith("conv_wino") else \
+            keys = ("conv_sp_kernel",) if name.startswith("conv_sp") else ("wgrad_sp_kernel",) if name.startswith("wgrad_sp") else \
+                   ("conv_wino2_kernel", "conv_wino_kernel") if name.startswith("conv_wino") else \
                    ("conv_mfma2l_kernel", "conv_mfma2_kernel", "conv_nk16_kernel") if name.startswith("conv") else \
                    ("wgrad_wino_kernel",)
             nl = sum(tj[k]["launches_sampled"] for k in keys if k in tj)
             return {"hbm_bytes_per_launch": sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["launches_sampled"] for k in keys if k in tj) / nl,
                     "algorithmic_bytes_per_launch": sum(r.bytes for r in grp) / calls,
-                    "source": f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md; a committed "
-                              "record of an earlier run of this command, not collected in this run)",
+                    "source": ("collected in THIS run (--pmc-refresh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes, FETCH_SIZE x2 per "
+                               "MI355X_MICROARCH.md)") if fresh_traffic[0] is not None else
+                              (f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md; a committed "
+                               "record of an earlier run of this command, not collected in this run)"),
                     "source_sha256": hashlib.sha256(raw).hexdigest(),
                     "source_collected_utc": tdoc.get("collected_utc")}
         except (OSError, KeyError, ValueError, ZeroDivisionError):
@@ -349,6 +383,8 @@ def main():
                                  "all_hbm_kernels_ms_per_step": round(sum(v["ms_per_step"] for v in hbm.values()), 3)}}
 
     roof, fams = None, {}
+    if args.pmc_refresh and world == 1 and not args.no_prof:
+        pmc_refresh()                  # (after the timed region: the child processes share this GPU)
     if not args.no_prof:
         timed = None
         if prof_timed:

@@ -33,7 +33,7 @@ def shard_inputs(rank, kind, S=32, N=2, seed=None):
     return {"x": x, "lab": lab, "em": em, "cm": cm, "em_t": em_t, "noise": noise, "beta": 0.41}
 
 
-def run_kind(rank, world, outdir, kind):
+def run_kind(rank, world, outdir, kind, dev=None):
     """pce_gatedcrf (unet_cct, headline composition) / mean_teacher (config 4: the teacher forward and the gradient
     all-reduce in the same step) through the engine's data-parallel route"""
     from detinit import det_state
@@ -48,16 +48,18 @@ def run_kind(rank, world, outdir, kind):
         dist.broadcast(m._param_arena, src=0)          # rank 1 was given OTHER weights: what the engine does at construction
         dist.broadcast(m._buf_arena, src=0)
     d = shard_inputs(rank, kind)
+    if dev is not None:                                 # both ranks on ONE MI355X (gloo carries the collectives through the host)
+        d = {k: ([t.to(dev) for t in v] if isinstance(v, list) else (v.to(dev) if torch.is_tensor(v) else v)) for k, v in d.items()}
     eng.it = 4500                                       # mean teacher: a non-trivial consistency weight and EMA alpha
     eng.model.set_dropout_masks(d["em"], d["cm"] if net == "unet_cct" else None)
     if eng.teacher is not None:
         eng.teacher.set_dropout_masks(d["em_t"], None)
     eng.forward_backward(d["x"], d["lab"], d["beta"], noise=d["noise"] if kind == "mean_teacher" else None)
-    out = {"loss": np.float32(eng.losses()["loss"]), "grads": (eng.model.flat_grads() / world).numpy().copy()}
+    out = {"loss": np.float32(eng.losses()["loss"]), "grads": (eng.model.flat_grads() / world).cpu().numpy().copy()}
     eng.optimizer_step()
-    out["params_after"] = eng.model.flat_params().numpy().copy()
+    out["params_after"] = eng.model.flat_params().cpu().numpy().copy()
     if eng.teacher is not None:
-        out["teacher_after"] = eng.teacher.flat_params().numpy().copy()
+        out["teacher_after"] = eng.teacher.flat_params().cpu().numpy().copy()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
 
 
@@ -67,9 +69,13 @@ def main():
     torch.set_num_threads(1)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     from wsl4mis_amd import _lib
-    _lib.use_library_for_tests(C.CDLL(os.path.join(ROOT, "tests", "emul", "libwslhip_emul.so")))
+    gpu = len(sys.argv) > 6 and sys.argv[6] == "gpu"    # the real library, both ranks on cuda:0
+    if gpu:
+        torch.cuda.set_device(0)
+    else:
+        _lib.use_library_for_tests(C.CDLL(os.path.join(ROOT, "tests", "emul", "libwslhip_emul.so")))
     if kind != "ours_proposed":
-        run_kind(rank, world, outdir, kind)
+        run_kind(rank, world, outdir, kind, torch.device("cuda", 0) if gpu else None)
         dist.destroy_process_group()
         return
     from detinit import det_state, sample_index

@@ -43,8 +43,22 @@ def test_two_rank_gloo_matches_ddp_fixture(tmp_path):
     assert np.array_equal(r0["params_after"], r1["params_after"])   # replicas stay bit-identical after the step
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind", ["pce_gatedcrf", "mean_teacher"])
+def test_two_rank_gloo_on_one_gpu_match_the_oracle(tmp_path, kind):
+    """the data-parallel route with world_size 2 on the REAL library -- two processes sharing cuda:0, gloo
+    carrying the broadcasts and the bucketed gradient all-reduce (RCCL cannot put two ranks on one device; the driver's 8-GPU
+    run covers that transport) -- against the oracle's per-shard computation averaged, replicas bit-identical."""
+    _two_rank_against_the_oracle(tmp_path, kind, gpu=True)
+
+
 @pytest.mark.parametrize("kind", ["pce_gatedcrf", "mean_teacher"])
 def test_two_rank_gloo_other_compositions_match_the_oracle(tmp_path, kind):
+    _two_rank_against_the_oracle(tmp_path, kind, gpu=False)
+
+
+def _two_rank_against_the_oracle(tmp_path, kind, gpu):
     """The headline composition (unet_cct pCE + GatedCRF) and BASELINE.json config 4 (mean teacher: teacher forward + gradient
     all-reduce in one step) through the data-parallel route on two gloo ranks: the averaged gradient, the SGD step and the
     EMA teacher equal the oracle's per-shard computation averaged (DDP-equivalent semantics), and the replicas
@@ -53,11 +67,12 @@ def test_two_rank_gloo_other_compositions_match_the_oracle(tmp_path, kind):
     from detinit import det_state
     from oracle import torch_ref as R
     import dp_worker
-    get_backend("emul")
+    if not gpu:
+        get_backend("emul")
     port = str(free_port())
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", port, str(tmp_path), kind],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", port, str(tmp_path), kind] +
+                              (["gpu"] if gpu else []), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=1500)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     r0, r1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))

@@ -327,3 +327,95 @@ def test_full_batch_gradients_strict_with_replayed_decisions(full, mode):
         # the emulator run only checks this test's plumbing: at 2 x 16 x 16 the deepest BatchNorm normalises TWO values per channel
         # (1 x 1 pixels x 2 samples), whose gradient amplifies fp32 round-off by orders of magnitude in any implementation
         assert tot <= 2.0 * float(np.linalg.norm(gc - gt) / np.linalg.norm(gt)) + 1e-6, tot
+
+
+REG_KINDS = ("pce_tv", "pce_ms", "pce_entropy", "mean_teacher")
+
+
+def test_full_resolution_regulariser_compositions_against_the_oracle(mode):
+    """the single-branch compositions (pCE + TV / Mumford-Shah / entropy minimisation, and the mean-teacher step
+    with its softmax-MSE consistency -- SURVEY 8d config 4) at the benchmark RESOLUTION against the fp32 oracle: every loss term to
+    1e-4 and the whole parameter gradient to the deviation two fp32 implementations show on the dual-branch compositions (a few
+    1e-3, kink flips included; the strict element-wise checks are the kink-clear small fixtures of test_python_api.py).  Batch 8
+    instead of 64: the oracle's four backward passes then cost half a minute of host time instead of four."""
+    import math
+    import time
+    from conftest import summary_line
+    from oracle import torch_ref as R
+    from wsl4mis_amd import runtime
+    from wsl4mis_amd.engine import TrainEngine
+    from wsl4mis_amd.synthetic import batch
+    dev = runtime.device()
+    n, S, it0 = (8, 256, 30000) if mode == "hip" else (2, 16, 30000)
+    x, lab = batch(n, S, S, 77, dev)
+    gen = torch.Generator().manual_seed(5)
+    em = [[(torch.rand((n, 16 << l, S >> l, S >> l), generator=gen) >= R.DROP[l]).to(torch.uint8) for l in range(5)] for _ in range(2)]
+    noise = torch.clamp(torch.randn((n, 1, S, S), generator=gen) * 0.1, -0.2, 0.2)
+    torch.manual_seed(7)
+    engs = {k: TrainEngine("unet", 1, 4, base_lr=0.01, loss=k) for k in REG_KINDS}
+    sd0 = {k: v.detach().cpu().clone() for k, v in engs["pce_tv"].model.state_dict().items()}
+    sdt = {k: v.detach().cpu().clone() for k, v in engs["mean_teacher"].teacher.state_dict().items()}
+    for k in sdt:                                   # a teacher that differs from the student
+        if sdt[k].is_floating_point() and sdt[k].ndim == 4:
+            sdt[k] = sdt[k] * 1.05
+    pk = [k for k in sd0 if R.is_param(k)]
+    hip = {}
+    for kind, eng in engs.items():
+        eng.model.load_state_dict(sd0)
+        eng.model.set_dropout_masks([m.to(dev) for m in em[0]])
+        if kind == "mean_teacher":
+            eng.teacher.load_state_dict(sdt)
+            eng.teacher.set_dropout_masks([m.to(dev) for m in em[1]])
+            eng.it = it0
+            eng.forward_backward(x, lab, 0.5, noise.to(dev))
+        else:
+            eng.forward_backward(x, lab, 0.5)
+        hip[kind] = (eng.losses(), eng.model.flat_grads().cpu().numpy().astype(np.float64))
+    del engs
+    # ---- the oracle, fp32 on the host cores
+    t0 = time.time()
+    xc, labc = x.cpu(), lab.cpu()
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for k in pk:
+        sd[k].requires_grad_(True)
+    z = R.net_forward(sd, xc, "unet", em[0], None, True)
+    with torch.no_grad():
+        zt = R.net_forward({k: v.clone() for k, v in sdt.items()}, xc + noise, "unet", em[1], None, True)
+    s = torch.softmax(z, 1)
+    ce = R.ce_ignore(z, labc)
+    rows = []
+    for kind in REG_KINDS:
+        if kind == "pce_tv":
+            reg, w = R.tv_loss(s[1:]), 1e-2
+            loss, terms = ce + w * reg, {"ce": ce, "reg": reg}
+        elif kind == "pce_ms":
+            reg, w = R.mumford_shah(xc, s), 1e-6
+            loss, terms = ce + w * reg, {"ce": ce, "reg": reg}
+        elif kind == "pce_entropy":
+            reg, w = torch.mean(-1 * torch.sum(s * torch.log(s + 1e-6), dim=1) / math.log(4)), 0.1
+            loss, terms = ce + w * reg, {"ce": ce, "reg": reg}
+        else:
+            loss, ce_m, tv, cons = R.mean_teacher_loss(z, zt, labc, it0)
+            terms = {"ce": ce_m, "tv": tv, "cons": cons}
+        g = torch.autograd.grad(loss, [sd[k] for k in pk], retain_graph=kind != REG_KINDS[-1])
+        ref = np.concatenate([t.double().numpy().ravel() for t in g])
+        o, got = hip[kind]
+        lt = {k: abs(o[k] - float(v.detach())) / (abs(float(v.detach())) + 1e-12) for k, v in terms.items()}
+        lt["loss"] = abs(o["loss"] - float(loss.detach())) / abs(float(loss.detach()))
+        l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        rows.append((kind, lt, l2))
+    line = (f"full-resolution single-branch compositions (unet, N = {n}, {S} x {S}) vs the fp32 oracle: " +
+            "; ".join(f"{k}: loss terms {max(lt.values()):.1e}, whole-gradient L2 {l2:.2e}" for k, lt, l2 in rows) +
+            f"  [oracle {time.time() - t0:.0f} s]")
+    print(line)
+    summary_line(line)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d) and mode == "hip":
+        import json
+        with open(os.path.join(d, "fullres_regulariser_compositions.json"), "w") as fh:
+            json.dump({"N": n, "size": S, "rows": [{"composition": k, "loss_term_rel_err": lt, "whole_gradient_l2_vs_fp32_oracle": l2}
+                                                    for k, lt, l2 in rows]}, fh)
+    for kind, lt, l2 in rows:
+        assert max(lt.values()) < 1e-4, (kind, lt)
+        # (emulator run: 2 x 16 x 16, where the deepest BatchNorm normalises two values per channel -- plumbing check only)
+        assert l2 < (5e-3 if mode == "hip" else 5e-2), (kind, l2)

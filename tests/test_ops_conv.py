@@ -60,23 +60,12 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
 ]
 
 
-@pytest.fixture(params=[2, 3, "alt"])
-def variant(request, be):
-    """packed-path kernel: 2 = the product's kernels; 3 = wave-specialised persistent conv, "alt" = the first Winograd conv
-    form + the 8-wave double-buffered weight gradient -- the two experiment variants exist only in builds with
-    -DWSL_EXPERIMENTS (the host emulator; tools/exp/libwslhip_exp.so), so on the product library they are skipped."""
-    if request.param != 2 and not hasattr(be.lib, "wsl_debug_wino_variant"):
-        pytest.skip("experiment variants are compiled out of the product library")
-    be.call("wsl_debug_conv_wino", 2)          # Winograd wherever it fits, including the 16-channel blocks
-    if request.param != 2:
-        be.call("wsl_debug_conv_variant", 2 if request.param == "alt" else request.param)
-    if request.param == "alt":
-        be.call("wsl_debug_wino_variant", 1, 8)
-    yield 2 if request.param == "alt" else request.param
+@pytest.fixture
+def variant(be):
+    """the packed-path kernels with Winograd wherever it fits, including the 16-channel blocks"""
+    be.call("wsl_debug_conv_wino", 2)
+    yield 2
     be.call("wsl_debug_conv_wino", -1)
-    if request.param != 2:
-        be.call("wsl_debug_conv_variant", 2)
-        be.call("wsl_debug_wino_variant", -1, -1)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -135,8 +124,9 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
         assert close(be.np(y3), y_ref.detach().numpy(), TOL)
     # ---- Winograd F(2x2, 3x3) path for the layers it fits: same outputs and statistics
     def wino_shape(Ca_, Cb_, Co_):
+        # 32-channel output blocks on 8 x 32 / 16 x 16 tiles; 16-channel blocks only on 8 x 64 / 8 x 32 tiles
         return (ks == 3 and (Ca_ + Cb_) % 8 == 0 and Ca_ + Cb_ <= 256 and (Cb_ == 0 or Ca_ % 8 == 0) and Co_ % 16 == 0
-                and ((H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0)))
+                and ((H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0 and Co_ % 32 == 0)))
     wino = bool(be.lib.wsl_conv2d_wino_ok(N, H, W, Ca, Cb, Co, ks))
     assert wino == (variant == 2 and wino_shape(Ca, Cb, Co))
     if wino:

@@ -11,10 +11,11 @@ r = d["roofline"]
 # rocprofv3 kernel names that bench.py's event families cover (the small first-conv / classifier kernels ride in the conv
 # and weight-gradient families of the library's event bracketing)
 NAMES = {"conv_mfma2l_kernel": ("conv_mfma2l_kernel", "conv_mfma2_kernel", "conv_cls_kernel", "conv_nk16_kernel"),
-         "conv_wino2_kernel": ("conv_wino2_kernel", "conv_wino2r_kernel", "conv_wino_kernel"),
+         "conv_wino2_kernel": ("conv_wino2_kernel", "conv_wino2r_kernel"),
          "wgrad_wino_kernel": ("wgrad_wino_kernel",),
          "wgrad_direct_kernels": ("wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel", "wgrad_small_kernel"),
-         "conv_wino_kernel": ("conv_wino_kernel",),
+         "conv_sp_kernel": ("conv_sp_kernel",),
+         "wgrad_sp_kernel": ("wgrad_sp_kernel",),
          "wgrad_mfma2s_kernel": ("wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel", "wgrad_mfma2_kernel", "wgrad_small_kernel")}
 for kname, k in r.get("kernels", {r["kernel"]: r}).items():
     fam = [x for x in rows if any(n in x["Name"] for n in NAMES[kname.split()[0]])]

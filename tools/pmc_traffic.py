@@ -21,7 +21,7 @@ def per_kernel(d, counter):
             continue
         k = r["Kernel_Name"]
         k = k.replace("conv_wino2r_kernel", "conv_wino2_kernel")   # the raw-source (LDS-DMA) variant rides in the same family
-        fam = next((f for f in ("conv_wino2_kernel", "wgrad_wino_kernel", "conv_wino_kernel", "conv_mfma2l_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel",
+        fam = next((f for f in ("conv_sp_kernel", "wgrad_sp_kernel", "conv_wino2_kernel", "wgrad_wino_kernel", "conv_wino_kernel", "conv_mfma2l_kernel", "wgrad_mfma2s_kernel", "wgrad_mfma2l_kernel",
                                 "conv_mfma2_kernel", "conv_nk16_kernel", "wgrad_mfma2_kernel") if f in k), None)
         if fam is None:
             continue
@@ -33,15 +33,21 @@ def per_kernel(d, counter):
     return acc
 
 
-fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-import time
-out = {"collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1`; KiB -> bytes, "
-                 "FETCH_SIZE x2 per MI355X_MICROARCH.md (HBM section)", "kernels": {}}
-for fam in sorted(set(fetch) | set(write)):
-    n = fetch[fam][0] or write[fam][0]
-    fb = 2.0 * 1024.0 * fetch[fam][1] / max(fetch[fam][0], 1)
-    wb = 1024.0 * write[fam][1] / max(write[fam][0], 1)
-    out["kernels"][fam] = {"launches_sampled": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
-                           "hbm_bytes_per_launch": fb + wb}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out, indent=1))
+def aggregate(fetch_dir, write_dir):
+    import time
+    fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    out = {"collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1`; KiB -> bytes, "
+                     "FETCH_SIZE x2 per MI355X_MICROARCH.md (HBM section)", "kernels": {}}
+    for fam in sorted(set(fetch) | set(write)):
+        n = fetch[fam][0] or write[fam][0]
+        fb = 2.0 * 1024.0 * fetch[fam][1] / max(fetch[fam][0], 1)
+        wb = 1024.0 * write[fam][1] / max(write[fam][0], 1)
+        out["kernels"][fam] = {"launches_sampled": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                               "hbm_bytes_per_launch": fb + wb}
+    return out
+
+
+if __name__ == "__main__":
+    out = aggregate(sys.argv[1], sys.argv[2])
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))

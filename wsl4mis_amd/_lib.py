@@ -163,8 +163,6 @@ _DEBUG_PROTOS = {
     "wsl_debug_conv_plan": (i32, [i32, i32, i32]),
     "wsl_debug_conv_wino": (i32, [i32]),
     "wsl_debug_net_decisions": (i32, [PD, c_fp, sz, i32, i32, c_fp, c_fp]),
-    "wsl_debug_wino_variant": (i32, [i32, i32]),          # EXPERIMENTS build only, like the three below
-    "wsl_debug_conv_variant": (i32, [i32]),
     "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
     "wsl_debug_lds_dma_probe": (i32, [c_fp, c_fp, c_fp]),
     "wsl_debug_pk_probe": (i32, [c_fp, c_fp, c_fp]),

@@ -10,7 +10,7 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-srcs=(wsl_api wsl_conv wsl_conv2 wsl_conv3 wsl_conv4 wsl_conv5 wsl_convsp wsl_bn wsl_convt wsl_loss wsl_optim wsl_net wsl_data)
+srcs=(wsl_api wsl_conv wsl_conv2 wsl_conv4 wsl_conv5 wsl_convsp wsl_bn wsl_convt wsl_loss wsl_optim wsl_net wsl_data)
 mkdir -p "$here/build"
 objs=()
 pids=()

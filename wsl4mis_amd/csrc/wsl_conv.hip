@@ -551,7 +551,6 @@ int conv2_pack(const float* w, float* wp, int Co, int Ci, int ks, int wmode, voi
 int conv2_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
               int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
               int slots, void* stream, const BnBwdEpi* bn = nullptr, int* bn_done = nullptr);
-// wsl_conv3.hip
 int wgrad_small_kind(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks);   // wsl_conv4.hip
 int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                        int H, int W, int nsplit, void* stream);
@@ -566,15 +565,9 @@ int wino_pack(const float* w, float* u, int Co, int Ci, int dgrad, void* stream)
 int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias, float* y, int64_t y_bs, int N, int H,
              int W, int Co, int is_dgrad, float* stat_part, float* stat_cnt, int slots, void* stream,
              const BnBwdEpi* bn = nullptr, int* bn_done = nullptr);
-bool conv3_enabled();
-void conv_set_variant(int v);
-int conv3_fwd(const WslSrc& a, const WslSrc* b, const float* wp, const float* bias, float* y, int64_t y_bs, int N, int H,
-              int W, int Co, int ks, int is_dgrad, int th, int tw, int co_t, float* stat_part, float* stat_cnt,
-              void* stream);
 bool wgrad2_eligible(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, int W);
 bool wgrad2s_wide_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks);
 bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib);   // wsl_conv5.hip
-int wgrad_wino_waves();
 int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_bs, float* part_dw, float* part_db, int N,
                   int H, int W, int Co, int ks, int th, int tw, int cb, int ib, int nsplit, int items, int tiles_x,
                   int tiles_y, int co_blocks, int ci_blocks, void* stream);
@@ -595,16 +588,8 @@ extern "C" int wsl_debug_conv_wino(int on) {
 extern "C" int wsl_conv2d_wino_ok(int N, int H, int W, int Ca, int Cb, int Co, int ks) {
   if (N <= 0 || Ca <= 0 || Cb < 0) return 0;
   if (Cb > 0 && (Ca % 8)) return 0;   // a channel chunk never straddles the two sources
-  return fwd_plan(N, H, W, Co, Ca + Cb, ks).wino && !conv3_enabled() ? 1 : 0;
+  return fwd_plan(N, H, W, Co, Ca + Cb, ks).wino ? 1 : 0;
 }
-
-#ifdef WSL_EXPERIMENTS
-extern "C" int wsl_debug_conv_variant(int v) {
-  WSL_REQUIRE(v == 2 || v == 3, "debug_conv_variant: 2 (lock-step, default) or 3 (wave-specialised, experimental)");
-  conv_set_variant(v);
-  return WSL_OK;
-}
-#endif
 
 extern "C" int wsl_conv2d_pack_weights(const float* w, float* packed, int Co, int Ci, int ks, int wmode_raw, void* stream) {
   WSL_REQUIRE(w && packed && Co > 0 && Ci > 0 && (ks == 1 || ks == 3) && wmode_raw >= 0 && wmode_raw <= 3,
@@ -626,7 +611,7 @@ extern "C" int wsl_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co, int k
   if (N <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
   const FwdPlan f = fwd_plan(N, H, W, Co, Ci, ks);
   // one partial per tile; the (opt-in) wave-specialised kernel emits one per MFMA wave = four slots per tile
-  return (conv3_enabled() ? 4 : 1) * N * cdiv(H, f.th) * cdiv(W, f.tw);
+  return N * cdiv(H, f.th) * cdiv(W, f.tw);
 }
 
 static int conv2d_fwd_impl(const WslSrc* a, const WslSrc* b, const float* w, const float* bias, float* y, int64_t y_bs, int N,
@@ -651,7 +636,7 @@ static int conv2d_fwd_impl(const WslSrc* a, const WslSrc* b, const float* w, con
   WSL_REQUIRE(y_bs >= (int64_t)Co * H * W, "conv2d_fwd: y batch stride too small");
   p.w = w, p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.Co = Co, p.wmode = wmode;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
-  p.slots = conv3_enabled() ? 4 : 1;
+  p.slots = 1;
   const FwdPlan f = fwd_plan(N, H, W, Co, p.in.Ci, ks);
   if (wmode >= 2) {
     if (!conv2_eligible(p.in.a, &p.in.b, y, y_bs, W, p.in.Ci)) {
@@ -659,19 +644,16 @@ static int conv2d_fwd_impl(const WslSrc* a, const WslSrc* b, const float* w, con
       return WSL_EINVAL;
     }
     if (wmode >= 4) {   // `w` is the Winograd image of wsl_conv2d_pack_weights(wmode_raw 2 | 3)
-      WSL_REQUIRE(f.wino && !conv3_enabled(), "conv2d_fwd: wmode %d needs wsl_conv2d_wino_ok() != 0 for this layer", wmode);
+      WSL_REQUIRE(f.wino, "conv2d_fwd: wmode %d needs wsl_conv2d_wino_ok() != 0 for this layer", wmode);
       return wino_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, wmode == 5, stat_part, stat_cnt, p.slots, stream, bn, bn_done);
     }
     static const bool nk_on = (WSL_TUNE("WSL_CONV_NK16", 1) != 0);
-    if (nk_on && !conv3_enabled() && conv_nk16_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, f.th, f.tw))
+    if (nk_on && conv_nk16_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, f.th, f.tw))
       return conv_nk16_launch(p.in.a, w, bias, y, y_bs, N, H, W, wmode == 3, stat_part, stat_cnt, p.slots, bn, bn_done,
                               stream);   // first conv forward / classifier data gradient (wsl_conv4.hip)
     static const bool cls_on = (WSL_TUNE("WSL_CONV_CLS", 1) != 0);
     if (cls_on && wmode == 2 && conv_cls_eligible(p.in.a, &p.in.b, y, y_bs, H, W, Co, ks, stat_part))
       return conv_cls_launch(p.in.a, w, bias, y, y_bs, N, H, W, stream);   // 4-class classifier (wsl_conv4.hip)
-    if (conv3_enabled() && p.in.Ci <= 256)   // wave-specialised persistent kernel (wsl_conv3.hip)
-      return conv3_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
-                       stat_cnt, stream);
     return conv2_fwd(p.in.a, &p.in.b, w, bias, y, y_bs, N, H, W, Co, ks, wmode == 3, f.th, f.tw, f.co_t, stat_part,
                      stat_cnt, p.slots, stream, bn, bn_done);
   }
@@ -732,7 +714,7 @@ static int wgrad_stage1(const WslSrc* a, const WslSrc* b, const float* dy, int64
     // the 32 x 32 Winograd weight gradient holds 128 accumulator registers: 2 resident workgroups per CU -> 512 persistent ones
     // (256 when it runs as one 8-wave double-buffered workgroup per CU)
     static const int wgs_env = WSL_TUNE("WSL_WGRAD_WINO_WGS", 0);
-    const int wgs = wgs_env > 0 ? wgs_env : (wgrad_wino_waves() == 8 ? 256 : 512);
+    const int wgs = wgs_env > 0 ? wgs_env : 512;
     int want = wgs / (g.co_blocks * g.ci_blocks);
     if (want < 1) want = 1;
     if (want < g.nsplit) g.nsplit = want;   // never more partials than the workspace was sized for

@@ -7,17 +7,12 @@
 //
 //   * U = G g G^T is computed once per optimiser step and layer by wino_pack_table_kernel ([16][Ci][Co], fp32; G holds
 //     0, 1, +-1/2 only);
-//   * a workgroup owns TH x TW output pixels = 64 tiles and CO_T output channels.  Per chunk of 8 input channels it stages
-//     the raw halo tile exactly like conv_mfma2l_kernel (producer BatchNorm + LeakyReLU + dropout masks applied on the
-//     way, aligned float4 loads, register prefetch across the MFMA phase), then every thread transforms the 4x6 patch of
-//     one tile PAIR of one channel (B^T d B: adds only) and writes V[xi][ci][tile] to LDS;
-//   * for each of the 16 transform positions xi the MFMA phase runs D_xi[tile][co] += V_xi[tile][ci] * U_xi[ci][co]
-//     (v_mfma_f32_16x16x4_f32; a wave owns 16 tiles x CO_T channels for all xi = 16 * CO_T/16 accumulator tiles);
-//   * MFMA output element (tile, co) sits in the same lane and register for every xi, so the output transform A^T M A is
-//     register-only; the epilogue adds the bias, stores 2 rows x 8 pixels per lane and channel as float4 and emits the
-//     BatchNorm partials (sum, M2) like the direct kernels.
-// V is stored with an XOR swizzle (tile ^ 16 * (ci & 3)) instead of padding, so the A-operand reads are conflict-free
-// and two workgroups fit the 160 KB LDS of a CU.
+//   * conv_wino2_kernel / conv_wino2r_kernel below: the input transform B^T d B is formed in registers straight in the MFMA
+//     operand layout, D_xi[tile][co] += V_xi[tile][ci] * U_xi[ci][co] per transform position xi (v_mfma_f32_16x16x4_f32), the
+//     output transform A^T M A is register-only, the epilogue is the direct kernels' (bias, float4 stores, BatchNorm partials,
+//     BatchNorm-backward statistics).
+// (The first form -- V staged through LDS -- and the 8-wave weight gradient lost their A/B measurements in rounds 1-2 and were
+//  deleted in round 3: profiles/r1z_winograd.md keeps the numbers.)
 #include <stdlib.h>
 
 #include <type_traits>
@@ -51,312 +46,13 @@ struct WinoP {
   BnBwdEpi bn;  // data-gradient launches: BatchNorm-backward statistics of the consumer of y (wsl_rt.h)
 };
 
-template <int TH, int TW, int CO_T>
-struct WinoCfg {
-  static constexpr int KC = 8, PADL = 4;
-  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4;
-  static constexpr int G = 256 / POS, NLD = KC / G;
-  static constexpr int PLANE = ((ROWS * ROWP - 16 + 31) / 32) * 32 + 16;   // == 16 (mod 32)
-  static constexpr int TTY = TH / 2, TTX = TW / 2, TILES = TTY * TTX;
-  static constexpr int NT = CO_T / 16;
-  static constexpr int IN_FLOATS = KC * PLANE, V_FLOATS = 16 * KC * TILES, W_FLOATS = 16 * KC * CO_T;
-  static constexpr int WF4 = W_FLOATS / 4, NWL = WF4 / 256;
-  static constexpr int MAXC = 256;
-  static constexpr size_t SMEM = sizeof(float) * (IN_FLOATS + V_FLOATS + W_FLOATS + 3 * MAXC);
-  static_assert(TILES == 64 && POS <= 256 && KC % G == 0 && WF4 % 256 == 0 && TTX % 4 == 0, "tile shape");
-  static_assert(8 * CO_T <= IN_FLOATS, "reduction scratch");
-};
-
-template <int TH, int TW, int CO_T>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
-  using C = WinoCfg<TH, TW, CO_T>;
-  constexpr int KC = C::KC;
-  WSL_DYN_SMEM(smem);
-  float* in_t = reinterpret_cast<float*>(smem);                 // raw (transformed-on-load) halo tile [KC][PLANE]
-  float* v_t = in_t + C::IN_FLOATS;                             // B^T d B: [16][KC][TILES], swizzled
-  float* w_t = v_t + C::V_FLOATS;                               // U chunk, operand order: [16 xi][4 k][16 col][2 kg][NT j]
-  float2* tab = reinterpret_cast<float2*>(w_t + C::W_FLOATS);   // [Ci] {scale, shift}
-  float* cm_l = w_t + C::W_FLOATS + 2 * C::MAXC;                // [Ci] channel multiplier of this sample
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
-  const int nb = gridDim.x;
-  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD-aware tile order, as conv_mfma2_kernel
-  const int tile_id = bid;
-  const int tx_i = bid % p.tiles_x;
-  bid /= p.tiles_x;
-  const int ty_i = bid % p.tiles_y;
-  const int n = bid / p.tiles_y;
-  const int co0 = blockIdx.y * CO_T;
-  const int y0 = ty_i * TH, x0 = tx_i * TW;
-  const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
-  const int HW = H * W;
-
-  // ---- staging position of this thread (as conv_mfma2l_kernel)
-  const int grp = tid / C::POS, pos = tid - grp * C::POS;
-  const int pty = pos / C::ROWP4, ptx4 = pos - pty * C::ROWP4;
-  const int gy = y0 + pty - 1, gx = x0 + ptx4 * 4 - C::PADL;
-  const bool owner = grp < C::G;
-  const bool pvalid = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
-  const uint32_t toff = pvalid ? (uint32_t)(grp * HW + gy * W + gx) : 0u;
-  const int loff = grp * C::PLANE + pty * C::ROWP + ptx4 * 4;
-  const int64_t gstride = (int64_t)C::G * HW;
-  const float* xa_n = p.a.x + n * p.a.bs;
-  const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
-  const uint8_t* ma_n = p.a.emask ? p.a.emask + (int64_t)n * p.a.C * HW : nullptr;
-  const uint8_t* mb_n = (p.b.C && p.b.emask) ? p.b.emask + (int64_t)n * p.b.C * HW : nullptr;
-
-  // U block of a chunk and channel block: W_FLOATS contiguous floats in the packed image (wino_filter), copied verbatim
-  const float* w_n = p.u + (int64_t)blockIdx.y * C::W_FLOATS + 4 * tid;
-  const int64_t w_cstride = (int64_t)(Co / CO_T) * C::W_FLOATS;   // floats between the blocks of consecutive chunks
-
-  float4 pre[C::NLD];
-  uint32_t prm[C::NLD];
-  v4f prw[C::NWL];
-
-  auto issue = [&](int c0) __attribute__((always_inline)) {
-    const bool ina = c0 < p.a.C;                                   // uniform
-    const int chb = ina ? c0 : c0 - p.a.C;
-    const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
-    const uint8_t* mb = ina ? ma_n : mb_n;
-#pragma unroll
-    for (int i = 0; i < C::NLD; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + i * gstride + toff);
-    if (mb) {
-      mb += (int64_t)chb * HW;
-#pragma unroll
-      for (int i = 0; i < C::NLD; ++i) prm[i] = *reinterpret_cast<const uint32_t*>(mb + i * gstride + toff);
-    }
-    const float* wb = w_n + (c0 / KC) * w_cstride;
-#pragma unroll
-    for (int i = 0; i < C::NWL; ++i) prw[i] = *reinterpret_cast<const v4f*>(wb + i * (4 * kThreads));
-  };
-
-  auto commit = [&](int c0) __attribute__((always_inline)) {
-    if (pvalid) {
-      const bool ina = c0 < p.a.C;
-      const bool has_scale = (ina ? p.a.scale : p.b.scale) != nullptr;
-      const bool has_mask = (ina ? p.a.emask : p.b.emask) != nullptr;
-      const float es = ina ? p.a.es : p.b.es;
-      // all table reads of the chunk up front (one LDS round trip instead of one per load: only two waves per SIMD hide it)
-      float2 tb[C::NLD];
-      float cmv[C::NLD];
-#pragma unroll
-      for (int i = 0; i < C::NLD; ++i) tb[i] = tab[c0 + grp + i * C::G], cmv[i] = cm_l[c0 + grp + i * C::G];
-#pragma unroll
-      for (int i = 0; i < C::NLD; ++i) {
-        wsl_v2f lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
-        if (has_scale) xform_bn_leaky(lo, hi, tb[i].x, tb[i].y);
-        if (has_mask) xform_mask(lo, hi, prm[i], es);
-        lo = lo * cmv[i], hi = hi * cmv[i];   // (1.0 without a channel mask: exact, and cheaper than selecting)
-        *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < C::NWL; ++i) *reinterpret_cast<v4f*>(w_t + 4 * tid + i * (4 * kThreads)) = prw[i];
-  };
-
-  // ---- input transform: this thread owns the tile pair `pr` of channel `tci` of the chunk
-  const int pr = tid & 31, tci = tid >> 5;
-  const int ptyy = pr / (C::TTX / 2), ptx0 = 2 * (pr % (C::TTX / 2));
-  const int roff = tci * C::PLANE + (2 * ptyy) * C::ROWP + (C::PADL - 1) + 2 * ptx0;   // patch origin in the raw tile
-  const int voff = tci * C::TILES + ((ptyy * C::TTX + ptx0) ^ ((tci & 3) << 4));
-  auto wino_in = [&]() __attribute__((always_inline)) {
-    float rt[4][6];
-    {
-      float d[4][6];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* r = in_t + roff + i * C::ROWP;
-        const float2 m0 = *reinterpret_cast<const float2*>(r + 1), m1 = *reinterpret_cast<const float2*>(r + 3);
-        d[i][0] = r[0], d[i][1] = m0.x, d[i][2] = m0.y, d[i][3] = m1.x, d[i][4] = m1.y, d[i][5] = r[5];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        rt[0][c] = d[0][c] - d[2][c];
-        rt[1][c] = d[1][c] + d[2][c];
-        rt[2][c] = d[2][c] - d[1][c];
-        rt[3][c] = d[1][c] - d[3][c];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {   // the two tiles of the pair ride in the two halves of a packed-f32 register pair
-      const wsl_v2f x0 = {rt[i][0], rt[i][2]}, x1 = {rt[i][1], rt[i][3]}, x2 = {rt[i][2], rt[i][4]}, x3 = {rt[i][3], rt[i][5]};
-      const wsl_v2f o0 = x0 - x2, o1 = x1 + x2, o2 = x2 - x1, o3 = x1 - x3;
-      float* vb = v_t + (4 * i) * (KC * C::TILES) + voff;
-      *reinterpret_cast<float2*>(vb) = make_float2(o0[0], o0[1]);
-      *reinterpret_cast<float2*>(vb + KC * C::TILES) = make_float2(o1[0], o1[1]);
-      *reinterpret_cast<float2*>(vb + 2 * KC * C::TILES) = make_float2(o2[0], o2[1]);
-      *reinterpret_cast<float2*>(vb + 3 * KC * C::TILES) = make_float2(o3[0], o3[1]);
-    }
-  };
-
-#ifndef WSL_HOST_EMUL
-  uint64_t* tl = WSL_ABLATED(p, 128) ? reinterpret_cast<uint64_t*>(p.stat_part) + (int64_t)tile_id * 32 : nullptr;
-#define WSL_MARK(k) do { if (tl && tid == 0) tl[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
-  if (tl && tid == 0) tl[29] = __builtin_amdgcn_s_memrealtime(), tl[28] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-#else
-#define WSL_MARK(k)
-#endif
-  WSL_MARK(0);
-  issue(0);
-  for (int c = tid; c < Ci; c += kThreads) {
-    const bool ina = c < p.a.C;
-    const WSrc& s = ina ? p.a : p.b;
-    const int ch = ina ? c : c - p.a.C;
-    tab[c] = s.scale ? make_float2(s.scale[ch], s.shift[ch]) : make_float2(1.f, 0.f);
-    cm_l[c] = s.cmask ? s.cmask[(int64_t)n * s.C + ch] : 1.f;
-  }
-  if (owner && !pvalid) {   // positions outside the image stay zero for good
-#pragma unroll
-    for (int i = 0; i < C::NLD; ++i)
-      *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
-  v4f acc[16][C::NT];
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-#pragma unroll
-    for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-  const int a_off = (lane >> 4) * C::TILES + ((16 * wave + (lane & 15)) ^ ((lane >> 4) << 4));
-  const int b_off = lane * (2 * C::NT);   // ((k = lane >> 4) * 16 + (col = lane & 15)) * (2 kg * NT j)
-  __syncthreads();   // tables visible
-  WSL_MARK(1);
-
-  for (int c0 = 0; c0 < Ci; c0 += KC) {
-#ifndef WSL_HOST_EMUL
-    const int mk = 2 + 6 * (c0 / KC < 4 ? c0 / KC : 3);
-    if (tl) __builtin_amdgcn_s_waitcnt(0);   // prefetched data has arrived
-#endif
-    WSL_MARK(mk);
-    commit(c0);
-    // the MFMA phase of a chunk is 2.25x shorter than the direct kernel's and no longer covers the HBM latency by itself:
-    // the next chunk's loads go out as soon as the staging registers are free and fly across transform + MFMA phase
-    if (c0 + KC < Ci) issue(c0 + KC);
-    WSL_MARK(mk + 1);
-    __syncthreads();
-    WSL_MARK(mk + 2);
-    wino_in();
-    WSL_MARK(mk + 3);
-    __syncthreads();
-    WSL_MARK(mk + 4);
-    {
-      // one stage per transform position: both channel groups (kg) and all channel tiles (j) of the B operand arrive in
-      // ONE LDS read (the packed image stores them next to each other); the A operand takes one read per channel group
-      float av[2][2];
-      float bv[2][2 * C::NT];
-      auto load = [&](int xi, int buf) __attribute__((always_inline)) {
-        av[buf][0] = v_t[(xi * KC) * C::TILES + a_off];
-        av[buf][1] = v_t[(xi * KC + 4) * C::TILES + a_off];
-        const float* bp = w_t + xi * (4 * 16 * 2 * C::NT) + b_off;
-        if constexpr (C::NT == 2) {
-          const v4f b4 = *reinterpret_cast<const v4f*>(bp);
-          bv[buf][0] = b4[0], bv[buf][1] = b4[1], bv[buf][2] = b4[2], bv[buf][3] = b4[3];
-        } else {
-          const float2 b2 = *reinterpret_cast<const float2*>(bp);
-          bv[buf][0] = b2.x, bv[buf][1] = b2.y;
-        }
-      };
-      load(0, 0);
-#pragma unroll
-      for (int xi = 0; xi < 16; ++xi) {
-        if (xi + 1 < 16) load(xi + 1, (xi + 1) & 1);
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-          for (int j = 0; j < C::NT; ++j) acc[xi][j] = WSL_MFMA16(av[xi & 1][kg], bv[xi & 1][kg * C::NT + j], acc[xi][j]);
-        WSL_SCHED_BARRIER();
-      }
-    }
-    WSL_MARK(mk + 5);
-    __syncthreads();
-  }
-
-  // ---- epilogue: output transform (register-only), bias, float4 stores, BatchNorm partials
-  const int tb = 16 * wave + 4 * (lane >> 4);          // first of this lane's 4 consecutive tiles
-  const int tyy = tb / C::TTX, txb = tb % C::TTX;
-  float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
-  float o[C::NT][16];
-  float bsum[C::NT];
-#pragma unroll
-  for (int j = 0; j < C::NT; ++j) {
-    const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
-    float bs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s0[4], s1[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float m0 = acc[c][j][r], m1 = acc[4 + c][j][r], m2 = acc[8 + c][j][r], m3 = acc[12 + c][j][r];
-        s0[c] = (m0 + m1) + m2;
-        s1[c] = (m1 - m2) - m3;
-      }
-      const float y00 = ((s0[0] + s0[1]) + s0[2]) + bias, y01 = ((s0[1] - s0[2]) - s0[3]) + bias;
-      const float y10 = ((s1[0] + s1[1]) + s1[2]) + bias, y11 = ((s1[1] - s1[2]) - s1[3]) + bias;
-      o[j][2 * r] = y00, o[j][2 * r + 1] = y01, o[j][8 + 2 * r] = y10, o[j][8 + 2 * r + 1] = y11;
-      bs += (y00 + y01) + (y10 + y11);
-    }
-    float* yj = yb + (int64_t)j * 16 * HW;
-    *reinterpret_cast<float4*>(yj) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
-    *reinterpret_cast<float4*>(yj + 4) = make_float4(o[j][4], o[j][5], o[j][6], o[j][7]);
-    *reinterpret_cast<float4*>(yj + W) = make_float4(o[j][8], o[j][9], o[j][10], o[j][11]);
-    *reinterpret_cast<float4*>(yj + W + 4) = make_float4(o[j][12], o[j][13], o[j][14], o[j][15]);
-    bsum[j] = bs;
-  }
-#ifndef WSL_HOST_EMUL
-  if (tl) {
-    __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
-    WSL_MARK(26);
-    if (tid == 0) tl[30] = __builtin_amdgcn_s_memrealtime();
-    return;
-  }
-#endif
-#undef WSL_MARK
-  if (p.stat_part) {
-    float* red1 = in_t;
-    float* red2 = in_t + 4 * CO_T;
-    constexpr float cnt = (float)(TH * TW);
-#pragma unroll
-    for (int j = 0; j < C::NT; ++j) {
-      float s = bsum[j];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < C::NT; ++j) {
-      const int col = j * 16 + (lane & 15);
-      const float mean_b = (red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col]) / cnt;
-      float q = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float d = o[j][e] - mean_b;
-        q = fmaf(d, d, q);
-      }
-      q += __shfl_xor(q, 16);
-      q += __shfl_xor(q, 32);
-      if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
-    }
-    __syncthreads();
-    if (wave == 0 && lane < 16) {
-#pragma unroll
-      for (int j = 0; j < C::NT; ++j) {
-        const int col = j * 16 + lane, co = co0 + col;
-        float* dst = p.stat_part + ((int64_t)co * ((int64_t)nb * p.slots) + (int64_t)tile_id * p.slots) * 2;   // [Co][slots][2]
-        dst[0] = red1[col] + red1[CO_T + col] + red1[2 * CO_T + col] + red1[3 * CO_T + col];
-        dst[1] = red2[col] + red2[CO_T + col] + red2[2 * CO_T + col] + red2[3 * CO_T + col];
-      }
-      if (lane < p.slots && blockIdx.y == 0) p.stat_cnt[tile_id * p.slots + lane] = lane == 0 ? cnt : 0.f;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ second form
-// conv_wino_kernel with the input transform moved INTO the MFMA operand: lane (tile = l & 15, k = l >> 4) of a wave is
+// ------------------------------------------------------------------------------------------------ conv kernels
+// The input transform sits INSIDE the MFMA operand: lane (tile = l & 15, k = l >> 4) of a wave is
 // exactly the A-operand slot of (tile, input channel k of the current group of four), so it reads that channel's 4x4 patch
 // of its tile from the staged raw halo tile and forms B^T d B in registers (8 packed + 16 scalar adds) -- no V buffer in
 // LDS, no transform pass, two barriers per chunk instead of three, 24 instead of 64 LDS reads + 16 writes per chunk.
 // A wave owns MTW row-groups of 16 tiles and NT channel tiles (MTW * NT = 2: 64 tiles x 32 channels, or -- for the
-// 16-channel layers -- 128 tiles = 8 x 64 pixels x 16 channels, twice the matrix work per staged chunk of the first form).
+// 16-channel layers -- 128 tiles = 8 x 64 pixels x 16 channels).
 template <int TH, int TW, int NT>
 struct Wino2Cfg {
   static constexpr int KC = 8, PADL = 4, CO_T = 16 * NT;
@@ -892,7 +588,7 @@ __device__ __forceinline__ void wino_filter(const float* w, float* u, int Co, in
     t[2][c] = 0.5f * ((g[c] - g[3 + c]) + g[6 + c]);
     t[3][c] = g[6 + c];
   }
-  // operand order of conv_wino_kernel: [chunk = ci / 8][channel block = co / co_t][xi][k = ci % 4][col = co % 16]
+  // operand order of the conv kernels: [chunk = ci / 8][channel block = co / co_t][xi][k = ci % 4][col = co % 16]
   //                                     [kg = (ci / 4) % 2][j = (co % co_t) / 16], co_t = 32 (16 when Co % 32 != 0)
   const int co_t = (Co % 32 == 0) ? 32 : 16, nt = co_t / 16;
   const int chunk = ci >> 3, kg = (ci >> 2) & 1, k = ci & 3, cob = co / co_t, j = (co % co_t) >> 4, col = co & 15;
@@ -961,24 +657,12 @@ bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, 
   else if (W % 16 == 0 && H % 16 == 0) h = 16, w = 16;
   else return false;
   if ((int64_t)Ci * H * W >= (int64_t(1) << 31) || (int64_t)16 * Ci * Co >= (int64_t(1) << 31)) return false;
+  if (Co % 32 && !(h == 8 && (w == 64 || w == 32))) return false;   // 16-channel blocks: 8 x 64 / 8 x 32 tiles only (else direct kernels)
   if (th) *th = h;
   if (tw) *tw = w;
   if (co_t) *co_t = Co % 32 == 0 ? 32 : 16;
   return true;
 }
-
-// kernel variants.  Product: form 2 (input transform in the MFMA operand) and the 4-wave weight gradient, fixed.  EXPERIMENTS
-// build: env WSL_WINO_FORM / WSL_WGRAD_WINO_WAVES or wsl_debug_wino_variant() select the measured-slower first form / the
-// 8-wave weight gradient for A-B timing.
-#ifdef WSL_EXPERIMENTS
-static int g_wino_form = -1, g_wgrad_waves = -1;
-static int wino_form() {
-  if (g_wino_form < 0) g_wino_form = WSL_TUNE("WSL_WINO_FORM", 2) == 1 ? 1 : 2;
-  return g_wino_form;
-}
-#else
-static constexpr int wino_form() { return 2; }
-#endif
 
 template <int TH, int TW, int NT>
 static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
@@ -1014,7 +698,7 @@ template <int TH, int TW, int NT>
 static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
   static const bool dma_on = (WSL_TUNE("WSL_WINO_DMA", 1) != 0);
   const bool raw = !p.a.scale && !p.a.emask && !p.a.cmask && (p.b.C == 0 || (!p.b.scale && !p.b.emask && !p.b.cmask));
-  if (dma_on && raw && wino_form() == 2) return launch_wino2r<TH, TW, NT>(p, is_dgrad, stream);   // plain sources: LDS DMA
+  if (dma_on && raw) return launch_wino2r<TH, TW, NT>(p, is_dgrad, stream);   // plain sources: LDS DMA
   using C = Wino2Cfg<TH, TW, NT>;
   auto kern = conv_wino2_kernel<TH, TW, NT>;
   static bool attr_done = false;
@@ -1029,25 +713,6 @@ static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_wino2_kernel");
-}
-
-template <int TH, int TW, int CO_T>
-static int launch_wino(WinoP& p, int is_dgrad, void* stream) {
-  using C = WinoCfg<TH, TW, CO_T>;
-  auto kern = conv_wino_kernel<TH, TW, CO_T>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
-    attr_done = true;
-  }
-  dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
-  const double px = (double)p.N * p.H * p.W;
-  // priced at the DIRECT algorithm's flops (9 multiply-adds per pixel and channel pair): the algorithmic work
-  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
-                         2.0 * px * p.Co * p.Ci * 4);   // issued: 16 instead of 36 multiply-adds per 2x2 tile
-  WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
-  prof_end(tok, stream);
-  return check_launch("conv_wino_kernel");
 }
 
 int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias, float* y, int64_t y_bs, int N, int H,
@@ -1067,25 +732,15 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
     return WSL_EINVAL;
   }
   p.tiles_x = W / tw, p.tiles_y = H / th;
-  const int form = wino_form();   // 1: V through LDS, 2: V in registers
-  // the BatchNorm-backward statistics ride in the epilogue shared by conv_wino2 / conv_wino2r (not in the first form)
+  // every shape wino_shape_ok() admits has a kernel with the BatchNorm-backward statistics in its epilogue
   const bool narrow16 = co_t == 16 && th == 8 && tw == 32;   // 64 tiles x 16 channels: one accumulator set, 3 workgroups per CU
-  const bool bn_ok = bn && bn->part && (tw == 64 || narrow16 || (form == 2 && co_t == 32));
+  const bool bn_ok = bn && bn->part;
   if (bn_ok) p.bn = *bn;
   if (bn_done) *bn_done = bn_ok ? 1 : 0;
   if (tw == 64) return launch_wino2<8, 64, 1>(p, is_dgrad, stream);
   if (narrow16) return launch_wino2<8, 32, 1>(p, is_dgrad, stream);
-  if (form == 2 && co_t == 32) {
-    if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);
-    return launch_wino2<16, 16, 2>(p, is_dgrad, stream);
-  }
-#ifdef WSL_EXPERIMENTS
-  if (th == 8 && co_t == 32) return launch_wino<8, 32, 32>(p, is_dgrad, stream);
-  if (th == 16 && co_t == 32) return launch_wino<16, 16, 32>(p, is_dgrad, stream);
-#endif
-  // 16-channel blocks at widths below 64 (small inputs only: the networks' 16-channel layers run at full resolution)
-  if (th == 8 && co_t == 16) return launch_wino<8, 32, 16>(p, is_dgrad, stream);
-  return launch_wino<16, 16, 16>(p, is_dgrad, stream);
+  if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);
+  return launch_wino2<16, 16, 2>(p, is_dgrad, stream);
 }
 
 // ================================================================================================ Winograd weight gradient
@@ -1440,18 +1095,6 @@ static int launch_wgrad_wino(WgWinoP& p, int ci_blocks, void* stream) {
   return check_launch("wgrad_wino_kernel");
 }
 
-// waves per workgroup of the 32 x 32 variant: 4 (default: two workgroups per CU) or 8 = one double-buffered workgroup per CU
-// with the next tile's loads in flight during the compute phase -- measured equal (+-5 % per layer), so it stays opt-in
-// (env WSL_WGRAD_WINO_WAVES=8)
-#ifdef WSL_EXPERIMENTS
-int wgrad_wino_waves() {
-  if (g_wgrad_waves < 0) g_wgrad_waves = WSL_TUNE("WSL_WGRAD_WINO_WAVES", 4) == 8 ? 8 : 4;
-  return g_wgrad_waves;
-}
-#else
-int wgrad_wino_waves() { return 4; }
-#endif
-
 // takes the launches wgrad_mfma2s_kernel would get with the same plan: 3x3, 32 x 32 channel blocks (two dY tiles per wave,
 // two input-channel tiles per workgroup) or 16 x 16 (the 16-channel layers: one tile each, four tile subsets)
 bool wgrad_wino_ok(const WslSrc& a, const WslSrc* b, int H, int W, int Co, int ks, int th, int tw, int cb, int ib) {
@@ -1480,10 +1123,6 @@ int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
   if (cb == 32) {
-#ifdef WSL_EXPERIMENTS
-    if (wgrad_wino_waves() == 8)
-      return th == 4 ? launch_wgrad_wino<4, 32, 2, 2, 8>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2, 8>(p, ci_blocks, stream);
-#endif
     return th == 4 ? launch_wgrad_wino<4, 32, 2, 2, 4>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2, 4>(p, ci_blocks, stream);
   }
   if (tw == 64) return launch_wgrad_wino<4, 64, 1, 1, 4>(p, ci_blocks, stream);
@@ -1491,11 +1130,3 @@ int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t
 }
 
 }  // namespace wsl
-
-#ifdef WSL_EXPERIMENTS
-extern "C" int wsl_debug_wino_variant(int conv_form, int wgrad_waves) {
-  wsl::g_wino_form = conv_form == 1 ? 1 : conv_form == 2 ? 2 : -1;
-  wsl::g_wgrad_waves = wgrad_waves == 8 ? 8 : wgrad_waves == 4 ? 4 : -1;
-  return WSL_OK;
-}
-#endif

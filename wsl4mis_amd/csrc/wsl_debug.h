@@ -25,10 +25,8 @@ int wsl_debug_net_decisions(const struct WslNetDesc* d, const void* ws, size_t w
                             void* stream);
 
 /* Only in the EXPERIMENTS build (-DWSL_EXPERIMENTS: `build.sh exp` -> tools/exp/libwslhip_exp.so, and the host emulator):
- * measured-slower kernel families kept for A/B timing, ablation switches (env WSL_CONV_ABLATE / WSL_WGRAD_ABLATE: they skip
+ * ablation switches (env WSL_CONV_ABLATE / WSL_WGRAD_ABLATE: they skip
  * work, results are WRONG by design), ~20 env tuning knobs (WSL_TUNE in wsl_rt.h) and three machine probes. */
-int wsl_debug_wino_variant(int conv_form, int wgrad_waves);   /* 1 = first Winograd form | 8-wave weight gradient */
-int wsl_debug_conv_variant(int v);                            /* 3 = wave-specialised persistent conv (wsl_conv3.hip) */
 int wsl_debug_mfma4_probe(const float* a, const float* b, float* d, void* stream);          /* tools/probe_mfma4.py */
 int wsl_debug_mfma_stream(int shape, int blocks, int iters, float* out, void* stream);      /* tools/mfma_ceiling.py */
 int wsl_debug_pk_probe(const float* in, float* out, void* stream);                            /* tools/probe_pk.py */
