@@ -344,13 +344,15 @@ def main():
         per_kernel = {k: fam(v) for k, v in kern.items() if v}
         for k, v in per_kernel.items():      # the split kernels issue f16 MFMAs: their matrix roofline is the f16 peak
             if "_sp_kernel" in k:
-                v["issued_frac_of_f16_peak"] = round(v["issued"] / PEAK_F16_MFMA_TFLOPS, 4)
-                v["frac_of_f16_peak_over_3_passes"] = round(v["achieved"] / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
+                v["peak"] = round(PEAK_F16_MFMA_TFLOPS / 3.0, 1)      # algorithmic flops at three f16 passes per product
+                v["frac"] = round(v["achieved"] / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
+                v["issued_frac"] = round(v["issued"] / PEAK_F16_MFMA_TFLOPS, 4)
+            else:
+                v["peak"] = PEAK_F32_MFMA_TFLOPS
         name, grp = max(((k, v) for k, v in kern.items() if v), key=lambda kv: sum(r.ms for r in kv[1]))
         d = per_kernel[name]
         calls = sum(r.calls for r in grp)
         traffic = pmc_traffic(name, grp, calls)
-        iss_step = sum(r.issued_flops for r in conv) / nsteps
         # HBM-bound kernel families: SURVEY 8d's algorithmic bytes / measured time / 8 TB/s
         hbm = {}
         for k in ("bnact_bwd(reduce+finalize+apply)", "bilinear_up2(fwd+bwd)", "pool2_fwd+feat_grad_combine", "gatedcrf_fwd_kernel",
@@ -361,21 +363,21 @@ def main():
                 hbm[k] = {"ms_per_step": round(r.ms / nsteps, 3), "launches_per_step": round(r.calls / nsteps, 1),
                           "algorithmic_bytes_per_step": round(r.bytes / nsteps), "achieved_GBps": round(gbs, 1),
                           "frac": round(gbs / PEAK_HBM_GBS, 4)}
-        if "_sp_kernel" in name:
-            # split-precision record: algorithmic flops against what three f16 passes can deliver (2500 / 3 TFLOP/s); the HBM side
-            # of the same launches is in kernels[*].algo_frac_of_hbm_peak
-            d = dict(d, frac=d["frac_of_f16_peak_over_3_passes"])
-        return {"bound": "mfma", "kernel": name, "achieved": d["achieved"],
-                "peak": round(PEAK_F16_MFMA_TFLOPS / 3.0, 1) if "_sp_kernel" in name else PEAK_F32_MFMA_TFLOPS,
+        # (split-precision kernels: algorithmic flops against what three f16 passes can deliver, 2500 / 3 TFLOP/s, issued flops against
+        #  the f16 peak; the HBM side of the same launches is in kernels[*].algo_frac_of_hbm_peak.)  whole_step_issued_frac: every MFMA
+        #  kernel's issued flops over the peak of the instruction it issues = the matrix pipe's busy share of the timed step
+        pipe_s = sum(r.issued_flops / ((PEAK_F16_MFMA_TFLOPS if "_sp_kernel" in r.name.decode() else PEAK_F32_MFMA_TFLOPS) * 1e12) for r in conv) / nsteps
+        return {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": d["peak"],
                 "unit": "TFLOP/s", "frac": d["frac"],
                 "issued": d["issued"], "issued_frac": d["issued_frac"],
-                "whole_step_issued_frac": round(iss_step / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "whole_step_issued_frac": round(pipe_s / (ms_per_step * 1e-3), 4),
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,     # HBM bytes per launch (PMC)
                 "traffic_detail": traffic,
                 "launches": int(calls), "avg_launch_us": d["avg_launch_us"], "flops_per_launch": sum(r.flops for r in grp) / calls,
                 "flops_counted": "frac/achieved: algorithmic (direct convolution); issued/issued_frac: matrix-core flops issued "
-                                 "(= algorithmic / 2.25 for the Winograd kernels); whole_step_issued_frac: all MFMA kernels' issued "
-                                 "flops per step / the timed region's ms_per_step / peak",
+                                 "(= algorithmic / 2.25 for the Winograd kernels, x 3 for the split-precision kernels, against the f32 resp. f16 MFMA "
+                                 "peak); whole_step_issued_frac: all MFMA kernels' issued flops / the peak of the instruction each issues, per "
+                                 "step / the timed region's ms_per_step",
                 "kernels": per_kernel,
                 "all_mfma_kernels_tflops": round(sum(r.flops for r in conv) / (sum(r.ms for r in conv) * 1e-3) / 1e12, 2),
                 "all_mfma_kernels_ms_per_step": round(sum(r.ms for r in conv) / nsteps, 3),

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce4_kernel(BnBwdP p, float*
 // pass leaves ONE partial maximum (bit pattern of a non-negative float: orders like the float) in a scratch array, and a 64-block
 // fold kernel reduces them into the tensor's WSL_SP_AMAX_SLOTS slots.  No atomics: tens of thousands of short-lived workgroups
 // raising 64 words with atomicMax cost 70 us per launch (bnact_bwd_apply4: 126 us against 56 without the maximum, 19 % of the
-// split step -- profiles/r3_rocprofv3_kernel_stats_split_first.csv), with or without a pre-check load of the slot.
+// split step -- profiles/r3_rocprofv3_kernel_stats_split_asm_chains_atomic_amax.csv), with or without a pre-check load of the slot.
 __device__ __forceinline__ void amax_block_store(float m, uint32_t* pmax) {
 #ifdef WSL_AMAX_ATOMIC_AB   // A / B build (tools/ab_split_fullsize.py): the round's first form, pmax = the tensor's 64 slots (cleared by the caller)
 #pragma unroll
