@@ -104,8 +104,15 @@ def main(argv=None):
                 if not args.quiet:
                     print("iteration %d : " % it + ", ".join(f"{k} {v:.4f}" for k, v in o.items()), flush=True)
             if len(val) and it % args.val_every == 0:
-                # every rank validates its share of the volumes (replicas are bit-identical), then one all-reduce of the sums:
-                # nobody sits blocked in the next step's gradient all-reduce while rank 0 works through the whole set
+                # every rank validates its share of the volumes, then one all-reduce of the sums: nobody sits blocked in the next
+                # step's gradient all-reduce while rank 0 works through the whole set.  Parameters are bit-identical on all ranks
+                # (all-reduced gradients); the BatchNorm running statistics are NOT -- every rank saw other batches -- so rank 0's
+                # buffers are broadcast first (what DistributedDataParallel(broadcast_buffers=True) does before every forward):
+                # the Dice that is reported and written into the checkpoint's file name then belongs to the state_dict rank 0
+                # saves
+                if world > 1:
+                    dist.broadcast(eng.model._buf_arena, src=0)
+                    dist.broadcast(eng.model._nbt, src=0)
                 volume_fn = val_2D.test_single_volume_cct if args.model == "unet_cct" else val_2D.test_single_volume
                 acc = np.zeros(2 * (args.num_classes - 1) + 1)
                 for i in range(rank, len(val), world):

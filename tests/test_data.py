@@ -265,3 +265,24 @@ def test_two_stream_batch_sampler_matches_the_reference_semantics():
         assert len(set(flat)) == len(flat) and set(flat) <= set(prim) and all(set(b[bs - sb:]) <= set(sec) for b in got)
     with pytest.raises(AssertionError):
         TwoStreamBatchSampler(prim, sec, 40, 2)
+
+
+def test_device_cache_keys_on_the_case_and_is_bounded(mode):
+    """a non-caching dataset returns fresh arrays on every access -- the device cache must hit on the sample's 'case' and
+    refuse to grow without bound when there is none"""
+    from wsl4mis_amd import _lib
+    from wsl4mis_amd.dataloaders import dataset
+    rng = np.random.default_rng(3)
+    base = make_samples(rng, 4)
+    gen = dataset.BatchRandomGenerator((32, 32), device_cache=True, max_cached=6)
+    for rep in range(5):                            # fresh array objects every time, same four cases
+        fresh = [{"image": s["image"].copy(), "label": s["label"].copy(), "case": f"patient{i:03d}_slice_1.h5"} for i, s in enumerate(base)]
+        random.seed(7), np.random.seed(8)
+        img, lab = gen(fresh)
+        assert len(gen._dev) == 4
+        random.seed(7), np.random.seed(8)
+        ref_img, ref_lab = dataset.BatchRandomGenerator((32, 32))(fresh)
+        assert np.array_equal(img.cpu().numpy(), ref_img.cpu().numpy()) and np.array_equal(lab.cpu().numpy(), ref_lab.cpu().numpy())
+    with pytest.raises(_lib.WslError, match="distinct sources"):
+        for rep in range(3):                        # no 'case': keyed by identity, fresh arrays never hit
+            gen([{"image": s["image"].copy(), "label": s["label"].copy()} for s in base])

@@ -80,6 +80,7 @@ class BaseDataSets(Dataset):
         if self.split == "train" and self.transform is not None:
             sample = self.transform(sample)
         sample["idx"] = case.split("_")[0]
+        sample["case"] = case                                  # the file name: what BatchRandomGenerator(device_cache=True) keys on
         return sample
 
 
@@ -151,20 +152,28 @@ class RandomGenerator(object):
 class BatchRandomGenerator(object):
     """The batched form the engine wants: a list of samples in, one device batch out (one kernel launch)."""
 
-    def __init__(self, output_size, device_cache=False):
-        """device_cache: keep each distinct source array on the device after its first use (keyed by the identity of the
-        numpy arrays a caching BaseDataSets hands out), so a step stages nothing over PCIe."""
+    def __init__(self, output_size, device_cache=False, max_cached=16384):
+        """device_cache: keep each distinct source slice on the device after its first use, so a step stages nothing over PCIe.
+        Keyed by the sample's 'case' (the file name BaseDataSets puts into every sample); samples without one are keyed by the
+        identity of their arrays, which only a caching dataset keeps stable -- a source that hands out fresh arrays on every
+        access would grow the cache without bound, so more than `max_cached` entries raise instead."""
         self.output_size = output_size
         self._dev = {} if device_cache else None
+        self._max = max_cached
 
     def _staged(self, s):
-        key = (id(s["image"]), id(s["label"]))
+        case = s.get("case") if isinstance(s, dict) else None
+        key = ("case", case) if case is not None else (id(s["image"]), id(s["label"]))
         hit = self._dev.get(key)
         if hit is None:
+            if len(self._dev) >= self._max:
+                raise _lib.WslError(f"BatchRandomGenerator(device_cache=True): {len(self._dev)} distinct sources staged -- the dataset "
+                                    "hands out new arrays on every access (use BaseDataSets(cache=True) or samples with a 'case' key), "
+                                    "or raise max_cached")
             lab = np.asarray(s["label"])
             hit = (torch.as_tensor(np.asarray(s["image"]), dtype=torch.float32).to(rt.device()).contiguous(),
                    torch.as_tensor(lab, dtype=torch.uint8).to(rt.device()).contiguous(), bool(4 in np.unique(lab)),
-                   s["image"], s["label"])                    # (the arrays themselves: keeps the ids alive)
+                   s["image"], s["label"])                    # (the arrays themselves: keeps identity keys alive)
             self._dev[key] = hit
         return hit
 
