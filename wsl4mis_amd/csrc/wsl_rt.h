@@ -66,11 +66,20 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //   WSL_MFMA_SRC_RELEASE* last MFMA reading operand registers -> the next LDS read that overwrites them;
 //   WSL_MFMA_DRAIN        last MFMA of a chain -> any other reader / writer of the accumulator (4 passes + margin).
 // Which of these the hardware needs is not separated (the round's GPU minutes ended with the A/B); the set is what was measured.
+// A / B builds for the open question (tools/build_sp_variants.sh -> tools/exp/libwslhip_sp_*.so, measured with
+// tools/ab_split_fullsize.py; the product defines none of these): WSL_SP_AB_FORM = 1 compiler chains (the builtin) | 2 inline
+// assembly with an early-clobber destination that is NOT the accumulator (a renamed chain whose destination can overlap no
+// operand); WSL_SP_AB_NO_FENCE / _NO_RELEASE / _SHORT_DRAIN drop one ingredient each.
 #ifndef WSL_SP_RELEASE_ASM
 #define WSL_SP_RELEASE_ASM "s_nop 7\n\ts_nop 3"
 #endif
+#if defined(WSL_SP_AB_NO_FENCE) || (defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 1)
+#define WSL_LDS_READ_FENCE2(a, b)
+#define WSL_LDS_READ_FENCE4(a, b, c, d)
+#else
 #define WSL_LDS_READ_FENCE2(a, b) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" : "+v"(a), "+v"(b))
 #define WSL_LDS_READ_FENCE4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#endif
 // v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8 (l >> 4) + e], B[k = 8 (l >> 4) + e][j = l & 15] (8 halves = 4 VGPRs each, passed as
 // four 32-bit words), D as WSL_MFMA16 (probed: tools/probe_sp.hip).  Products exact in fp32, fp32 accumulation, f16 subnormals kept.
 typedef uint32_t wsl_u4 __attribute__((ext_vector_type(4)));
@@ -79,15 +88,44 @@ typedef _Float16 wsl_h8 __attribute__((ext_vector_type(8)));
 typedef short wsl_s4 __attribute__((ext_vector_type(4)));
 #define WSL_MFMA_F16(a, b, c) \
   __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wsl_h8, (a)), __builtin_bit_cast(wsl_h8, (b)), (c), 0, 0, 0)
+#if defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 1
+#define WSL_MFMA_F16_INPLACE(a, b, c) (c) = WSL_MFMA_F16(a, b, c)
+#define WSL_MFMA_F16_INPLACE_V(a, b, c) (c) = WSL_MFMA_F16(a, b, c)
+#elif defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 2
+#define WSL_MFMA_F16_INPLACE(a, b, c)                                                                              \
+  do {                                                                                                             \
+    v4f wsl_t_;                                                                                                    \
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %1" : "=&v"(wsl_t_) : "v"(c), "v"(a), "v"(b));               \
+    (c) = wsl_t_;                                                                                                  \
+  } while (0)
+#define WSL_MFMA_F16_INPLACE_V(a, b, c)                                                                            \
+  do {                                                                                                             \
+    v4f wsl_t_;                                                                                                    \
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %2, %3, %1" : "=&v"(wsl_t_) : "v"(c), "v"(a), "v"(b));    \
+    (c) = wsl_t_;                                                                                                  \
+  } while (0)
+#else
 #define WSL_MFMA_F16_INPLACE(a, b, c) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 // ... with an operand the compiler materialises with vector moves right in front of it (a constant): VALU write -> MFMA read
 #define WSL_MFMA_F16_INPLACE_V(a, b, c) asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#endif
+#if defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 1
+#define WSL_MFMA_DRAIN(c)
+#elif defined(WSL_SP_AB_SHORT_DRAIN)
+#define WSL_MFMA_DRAIN(c) asm volatile("s_nop 7" : "+v"(c))      /* the 8 states hipcc itself places after a 4-pass XDL write */
+#else
 #define WSL_MFMA_DRAIN(c) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(c))
+#endif
 // a value that is the same in every lane of the wave, held in a scalar register: branches on it are real branches (inline-assembly
 // MFMAs ignore the EXEC mask the compiler would otherwise predicate a wave-dependent block with)
 #define WSL_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#if defined(WSL_SP_AB_NO_RELEASE) || (defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 1)
+#define WSL_MFMA_SRC_RELEASE2(a, b)
+#define WSL_MFMA_SRC_RELEASE4(a, b, c, d)
+#else
 #define WSL_MFMA_SRC_RELEASE2(a, b) asm volatile(WSL_SP_RELEASE_ASM : "+v"(a), "+v"(b))
 #define WSL_MFMA_SRC_RELEASE4(a, b, c, d) asm volatile(WSL_SP_RELEASE_ASM : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#endif
 // ds_read_b64_tr_b16: inside a group of 16 lanes, lane i receives as element e the (i & 3)-th half of the four contiguous halves
 // at the (8-byte aligned) LDS address supplied by lane 4 e + (i >> 2) of the group -- a 4 x 16 block of halves read row-wise,
 // delivered column-wise (probed: tools/probe_sp.hip)
