@@ -148,6 +148,12 @@ def test_sp_not_eligible(be):
     s2 = be.src(x2, 16)
     assert be.lib.wsl_sp_conv2d_ok(s2, be.src(), None, 0, 1, 8, 32, 16, 1) == 0       # 1x1
     assert be.lib.wsl_sp_conv2d_ok(s2, be.src(), None, 0, 1, 8, 32, 16, 3) == 1
+    # BatchNorm coefficients are fetched as float4 pairs: a scale / shift array off a 16-byte boundary leaves the layer to the f32 kernels
+    coef = be.zeros((40,))
+    s3 = be.src(x2, 16, scale=coef, shift=coef)
+    assert be.lib.wsl_sp_conv2d_ok(s3, be.src(), None, 0, 1, 8, 32, 16, 3) == 1
+    s3.scale = be.ptr(coef) + 4
+    assert be.lib.wsl_sp_conv2d_ok(s3, be.src(), None, 0, 1, 8, 32, 16, 3) == 0
     with pytest.raises(Exception, match="eligible"):
         be.call("wsl_sp_conv2d_fwd", s, be.src(), be.ptr(x), be.ptr(x), None, None, be.ptr(x), 16 * 8 * 32, 1, 8, 32, 16, None, None,
                 be.stream)
