@@ -35,7 +35,7 @@ def main(argv=None):
     ap.add_argument("--num_classes", type=int, default=4)
     ap.add_argument("--max_iterations", type=int, default=60000)
     ap.add_argument("--stop_iterations", type=int, default=0, help="stop after this many iterations while keeping the poly schedule "
-                    "of --max_iterations (short-schedule comparisons against the oracle: tools/oracle_acdc_short.py)")
+                    "of --max_iterations (short-schedule comparisons against the oracle: tests/acdc_oracle_arm/oracle_acdc_short.py)")
     ap.add_argument("--batch_size", type=int, default=12)
     ap.add_argument("--base_lr", type=float, default=0.01)
     ap.add_argument("--patch_size", type=int, nargs=2, default=[256, 256])
@@ -50,7 +50,7 @@ def main(argv=None):
     ap.add_argument("--quiet", action="store_true", help="no per-iteration lines (validation lines stay)")
     ap.add_argument("--curve_json", default=None, help="write the loss / validation curve here (rank 0)")
     ap.add_argument("--oracle_stream", action="store_true", help="draw the nn.Dropout masks on the CPU generator in the order "
-                    "tools/oracle_acdc_short.py draws them (with --resume of its initial state and the same --seed, the two arms then "
+                    "tests/acdc_oracle_arm/oracle_acdc_short.py draws them (with --resume of its initial state and the same --seed, the two arms then "
                     "run the SAME trajectory up to fp32 round-off: profiles/r3_acdc_short_schedule.md)")
     ap.add_argument("--resume", default=None, help="a state_dict .pth (the reference's or ours: same keys) to start from")
     args = ap.parse_args(argv)

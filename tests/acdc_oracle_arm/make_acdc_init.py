@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""The initial state the oracle arm of profiles/r3_acdc_short_schedule.md started from (tools/oracle_acdc_short.py: torch.manual_seed(seed),
+"""The initial state the oracle arm of profiles/r3_acdc_short_schedule.md started from (oracle_acdc_short.py next to this file: torch.manual_seed(seed),
 then nn.Conv2d / nn.BatchNorm2d default initialisation in construction order), saved as a state_dict the HIP arm loads with --resume.
-Build container only (imports the oracle's layout).     python tools/make_acdc_init.py 2022 11"""
+Build container only (imports the oracle's layout).     python tests/acdc_oracle_arm/make_acdc_init.py 2022 11"""
 import os
 import sys
 
@@ -13,6 +13,6 @@ from oracle_acdc_short import default_init  # noqa: E402
 for seed in sys.argv[1:]:
     torch.manual_seed(int(seed))
     sd = {k: v.detach().clone() for k, v in default_init("unet").items()}
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", f"acdc_init_unet_seed{seed}.pth")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools", "exp", f"acdc_init_unet_seed{seed}.pth")
     torch.save(sd, out)
     print(out, sum(v.numel() for v in sd.values()), "values")

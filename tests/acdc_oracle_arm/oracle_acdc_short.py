@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Short-schedule ACDC training of the ORACLE (stock torch CPU ops, oracle/torch_ref.py) -- the reference-side arm of
+"""(Checker-side script: it lives under tests/ because it imports the oracle, which only tests/, smoke() and the bench CPU leg may.)
+Short-schedule ACDC training of the ORACLE (stock torch CPU ops, oracle/torch_ref.py) -- the reference-side arm of
 profiles/r3_acdc_short_schedule.md.  Build container only: it reads the reference's data directory in
 place and never travels to the GPU box.  The HIP arm is examples/train_acdc_scribble.py with the same flags
 (--stop_iterations); both arms share file selection, batch order, augmentation draws (python `random` / numpy in the
 reference's order), the poly schedule of the 60 000-iteration run and the validation protocol (code/val_2D.py:18-50: zoom,
 eval forward, argmax, zoom back, Dice per class over the 20 fold-1 validation volumes).
 
-    python tools/oracle_acdc_short.py --root_path /root/reference/data/ACDC --loss pce_tv --seed 2022 \
+    python tests/acdc_oracle_arm/oracle_acdc_short.py --root_path /root/reference/data/ACDC --loss pce_tv --seed 2022 \
         --stop_iterations 2000 --val_every 200 --curve_json profiles/r3_acdc_short_oracle_pce_tv_seed2022.json
 
 Loss compositions (single-branch unet, as code/train_wss.sh runs them):
@@ -25,7 +26,7 @@ import numpy as np
 import torch
 from scipy.ndimage import zoom
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import data_ref, torch_ref as R  # noqa: E402
 from wsl4mis_amd.dataloaders.dataset import BaseDataSets, draw_params  # noqa: E402  (file selection + draw order only: no kernels)

@@ -1,9 +1,9 @@
 #!/usr/bin/env bash
-# HIP arm of profiles/r3_acdc_short_schedule.md: the schedule of tools/oracle_acdc_short.sh (1500 iterations of the 60000-iteration
+# HIP arm of profiles/r3_acdc_short_schedule.md: the schedule of tests/acdc_oracle_arm/oracle_acdc_short.sh (1500 iterations of the 60000-iteration
 # poly schedule, batch 12, validation every 100, seeds 2022 and 11, pCE and pCE + TV), four trainer processes side by side on ONE
 # MI355X.  Needs data/ACDC.      bash tools/acdc_short_hip.sh gpurun_out/<tag> [matched]
 set -u
-# "matched": the oracle arm's initial state (tools/make_acdc_init.py) and its dropout-mask stream (--oracle_stream) -- the two arms
+# "matched": the oracle arm's initial state (tests/acdc_oracle_arm/make_acdc_init.py) and its dropout-mask stream (--oracle_stream) -- the two arms
 # then run the same trajectory up to fp32 round-off
 O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd "$R"
 M="${2:-}"; tag=hip; [ "$M" = matched ] && tag=hip_matched
