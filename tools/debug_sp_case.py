@@ -5,7 +5,6 @@ import ctypes as C
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 
