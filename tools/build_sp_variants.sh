@@ -22,3 +22,6 @@ build no_fence          -DWSL_SP_AB_NO_FENCE
 build no_release        -DWSL_SP_AB_NO_RELEASE
 build short_drain       -DWSL_SP_AB_SHORT_DRAIN
 build bare_inplace      -DWSL_SP_AB_NO_FENCE -DWSL_SP_AB_NO_RELEASE -DWSL_SP_AB_SHORT_DRAIN
+# speed (tools/sweep_layers_sp.py with WSL_LIB=...), not a correctness question: weight-gradient images on the pitch / plane offset of
+# profiles/r3_wgrad_sp_lds_conflicts.md
+build wg_layout2         -DWSL_SP_WG_LAYOUT2

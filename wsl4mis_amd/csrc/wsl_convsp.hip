@@ -39,13 +39,13 @@ constexpr int kSpMaxC = 512;   // channels whose loader coefficients fit the LDS
 //     hl * HL + o * PLANE + r * ROWB + ((c & 3) * P + (c >> 2)) * 16
 // P_ = 0: the pitch the conv kernels' row reads need (>= NQ and = 4 or 12 mod 16); the weight gradient's transpose reads take
 // compact images (P_ = NQ).
-template <int ROWS_, int NQ_, int NOCT_, int P_ = 0>
+template <int ROWS_, int NQ_, int NOCT_, int P_ = 0, int PAD_ = 0>
 struct SpImg {
   static constexpr int ROWS = ROWS_, NQ = NQ_, NOCT = NOCT_;
   static constexpr int P = P_ ? P_ : (NQ <= 12 ? 12 : (NQ <= 20 ? 20 : 28));
   static constexpr int RS = 4 * P + 2;                              // slots per row (+2: consecutive rows rotate by two slots)
   static constexpr int ROWB = RS * 16;
-  static constexpr int PLANE = ((ROWS * ROWB + 255) / 256) * 256;   // = 0 (mod 256): the octets of one read hit the same bank groups
+  static constexpr int PLANE = ((ROWS * ROWB + 255) / 256) * 256 + PAD_;   // PAD_ = 0: = 0 (mod 256), the octets of one read hit the same bank groups
   static constexpr int HL = NOCT * PLANE;
   static constexpr int BYTES = 2 * HL;
   static constexpr int NTASK = ROWS * NQ * NOCT, NR = (NTASK + 255) / 256;
@@ -641,8 +641,14 @@ struct WgradSpP {
 
 template <int TH, int TW, int CB>
 struct WgradSpCfg {
+#ifdef WSL_SP_WG_LAYOUT2   // A / B build (tools/build_sp_variants.sh): the pitch / plane offset that halves the transpose reads' bank
+                           // conflicts in the model of tools/lds_tr_conflicts.py (profiles/r3_wgrad_sp_lds_conflicts.md); 32-pixel rows only
+  using In = SpImg<TH + 2, (TW + 8) / 4, CB / 8, (TW == 32 ? 12 : (TW + 8) / 4), (TW == 32 ? 16 : 0)>;
+  using Dy = SpImg<TH, TW / 4, CB / 8, (TW == 32 ? 12 : TW / 4), (TW == 32 ? 16 : 0)>;
+#else
   using In = SpImg<TH + 2, (TW + 8) / 4, CB / 8, (TW + 8) / 4>;
   using Dy = SpImg<TH, TW / 4, CB / 8, TW / 4>;
+#endif
   static constexpr int KS = TH * TW / 32, KROWS = 32 / TW;      // K-steps per tile; tile rows per K-step
   static constexpr size_t SMEM = In::BYTES + Dy::BYTES;
   static_assert(TW == 16 || TW == 32, "a K-step is one row of 32 pixels or two rows of 16");
