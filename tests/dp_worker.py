@@ -38,8 +38,10 @@ def run_kind(rank, world, outdir, kind, dev=None):
     all-reduce in the same step) through the engine's data-parallel route"""
     from detinit import det_state
     from wsl4mis_amd.engine import TrainEngine
+    split = kind.endswith("_split")                      # the same composition on the opt-in split-precision conv path
+    kind = kind[:-6] if split else kind
     net = "unet_cct" if kind == "pce_gatedcrf" else "unet"
-    eng = TrainEngine(net, 1, 4, base_lr=0.01, loss=kind, crf_radius=2)
+    eng = TrainEngine(net, 1, 4, base_lr=0.01, loss=kind, crf_radius=2, conv_precision="split_f16x3" if split else "f32")
     assert eng.dp and eng.world == world
     models = [eng.model] + ([eng.teacher] if eng.teacher is not None else [])
     for i, m in enumerate(models):

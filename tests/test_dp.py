@@ -53,8 +53,9 @@ def test_two_rank_gloo_on_one_gpu_match_the_oracle(tmp_path, kind):
     _two_rank_against_the_oracle(tmp_path, kind, gpu=True)
 
 
-@pytest.mark.parametrize("kind", ["pce_gatedcrf", "mean_teacher"])
+@pytest.mark.parametrize("kind", ["pce_gatedcrf", "mean_teacher", "pce_gatedcrf_split"])
 def test_two_rank_gloo_other_compositions_match_the_oracle(tmp_path, kind):
+    """(`_split`: the headline composition with the eligible layers on the split-precision conv path -- same oracle, same criteria)"""
     _two_rank_against_the_oracle(tmp_path, kind, gpu=False)
 
 
@@ -67,11 +68,12 @@ def _two_rank_against_the_oracle(tmp_path, kind, gpu):
     from detinit import det_state
     from oracle import torch_ref as R
     import dp_worker
+    worker_kind, kind = kind, (kind[:-6] if kind.endswith("_split") else kind)
     if not gpu:
         get_backend("emul")
     port = str(free_port())
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", port, str(tmp_path), kind] +
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", port, str(tmp_path), worker_kind] +
                               (["gpu"] if gpu else []), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=1500)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
