@@ -91,17 +91,22 @@ def full(mode):
     out["hip"]["z"] = (z1.cpu().numpy(), z2.cpu().numpy())
     # the forward's discrete decisions as the kernels took them (LeakyReLU sign per BatchNorm layer, max-pool position per level)
     import ctypes as C
-    d_, ws_, nws_ = model._saved[0], model._saved[1], model._saved[2]
-    hip_signs, hip_args = [], []
-    for i in range(26):
-        c_, l_ = _BN_SHAPES[i]
-        buf = torch.empty((n, c_, S >> l_, S >> l_), dtype=torch.uint8, device=dev)
-        runtime.call("wsl_debug_net_decisions", C.byref(d_), runtime.ptr(ws_), nws_, 0, i, runtime.ptr(buf), runtime.stream())
-        hip_signs.append(buf.cpu().bool())
-    for l_ in range(1, 5):
-        buf = torch.empty((n, 16 << (l_ - 1), S >> l_, S >> l_), dtype=torch.uint8, device=dev)
-        runtime.call("wsl_debug_net_decisions", C.byref(d_), runtime.ptr(ws_), nws_, 1, l_, runtime.ptr(buf), runtime.stream())
-        hip_args.append(buf.cpu())
+
+    def decisions(m):
+        d_, ws_, nws_ = m._saved[0], m._saved[1], m._saved[2]
+        signs, args = [], []
+        for i in range(26):
+            c_, l_ = _BN_SHAPES[i]
+            buf = torch.empty((n, c_, S >> l_, S >> l_), dtype=torch.uint8, device=dev)
+            runtime.call("wsl_debug_net_decisions", C.byref(d_), runtime.ptr(ws_), nws_, 0, i, runtime.ptr(buf), runtime.stream())
+            signs.append(buf.cpu().bool())
+        for l_ in range(1, 5):
+            buf = torch.empty((n, 16 << (l_ - 1), S >> l_, S >> l_), dtype=torch.uint8, device=dev)
+            runtime.call("wsl_debug_net_decisions", C.byref(d_), runtime.ptr(ws_), nws_, 1, l_, runtime.ptr(buf), runtime.stream())
+            args.append(buf.cpu())
+        return signs, args
+
+    hip_signs, hip_args = decisions(model)
     from wsl4mis_amd.utils import losses as HL
     out["hip"]["pseudo"] = HL.mix_argmax(HL.softmax(z1), HL.softmax(z2), BETA).cpu().numpy()
     for kind in KINDS:
@@ -121,25 +126,31 @@ def full(mode):
     model_s.train()
     eng = TrainEngine("unet_cct", 1, 4, loss=TRUTH_KIND, crf_radius=5, model=model_s)
     model_s.set_dropout_masks(emd, cmd)
+    zs1, zs2 = model_s._run_forward(x, keep_for_backward=True)
+    zs = (zs1.cpu().numpy(), zs2.cpu().numpy())
+    split_signs, split_args = decisions(model_s)          # the decisions the SPLIT forward took (its own replay below: "f64rs")
+    model_s.set_dropout_masks(emd, cmd)
     eng.forward_backward(x, lab, BETA)
-    out["hip_split"] = {TRUTH_KIND: {"losses": eng.losses(), "grads": model_s.flat_grads().cpu().numpy().astype(np.float64)}}
+    out["hip_split"] = {"z": zs, TRUTH_KIND: {"losses": eng.losses(), "grads": model_s.flat_grads().cpu().numpy().astype(np.float64)}}
     xc, labc = x.cpu(), lab.cpu()
     del model, model_s, eng
     if dev.type == "cuda":
         torch.cuda.empty_cache()
     # ---- (b), (c) the oracle on the host cores
     from netutil import DecisionReplay
-    out["f64r"] = {}
-    # f32 / f64: the oracle free-running; f64r: the oracle in fp64 evaluating the piecewise-linear function the HIP forward chose
-    for tag, dt in (("f32", torch.float32), ("f64", torch.float64), ("f64r", torch.float64)):
+    out["f64r"], out["f64rs"] = {}, {}
+    # f32 / f64: the oracle free-running; f64r / f64rs: the oracle in fp64 evaluating the piecewise-linear function the HIP forward of
+    # the f32 path / of the split-precision path chose
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64), ("f64r", torch.float64), ("f64rs", torch.float64)):
         t0 = time.time()
         sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
         for k in pk:
             sd[k].requires_grad_(True)
-        ctx = DecisionReplay(hip_signs, hip_args) if tag == "f64r" else DecisionReplay(record=True)
+        ctx = (DecisionReplay(hip_signs, hip_args) if tag == "f64r" else DecisionReplay(split_signs, split_args) if tag == "f64rs"
+               else DecisionReplay(record=True))
         with ctx:
             o1, o2 = R.net_forward(sd, xc.to(dt), "unet_cct", em, [c.to(dt) for c in cm], True)
-        if tag != "f64r":       # how many decisions this free-running oracle takes differently from the HIP forward, per layer
+        if tag not in ("f64r", "f64rs"):       # how many decisions this free-running oracle takes differently from the HIP forward, per layer
             out[tag]["flips"] = [int((a != b).sum()) for a, b in zip(ctx.signs, hip_signs)] + \
                                 [int((a != b).sum()) for a, b in zip(ctx.args, hip_args)]
             ctx.signs, ctx.args = [], []
@@ -283,13 +294,19 @@ def test_full_batch_gradients_strict_with_replayed_decisions(full, mode):
     composition must agree at the element-wise 1e-4 criterion (RMS floor) -- a layer wrong by 0.1 % fails, which the error budget
     above (dominated by flipped decisions) cannot resolve.  The number of decisions the free-running oracles take differently,
     per layer, is reported next to it: that is what the budget's deviations consist of."""
+    for path, replay in (("hip", "f64r"), ("hip_split", "f64rs")):
+        _strict(full, mode, path, replay)
+
+
+def _strict(full, mode, path, replay):
     import json
     from conftest import close, mixed_err, rel_err, summary_line
     pk, sizes = full["pk"], full["sizes"]
-    gh, gr, gt, gc = (full[a][TRUTH_KIND]["grads"] for a in ("hip", "f64r", "f64", "f32"))
+    gh, gr, gt, gc = (full[a][TRUTH_KIND]["grads"] for a in (path, replay, "f64", "f32"))
+    tagp = "split-precision conv path" if path == "hip_split" else "f32 path"
     # forward: logits against the replayed truth
     for b in range(2):
-        assert close(full["hip"]["z"][b], full["f64r"]["z"][b]), (b, rel_err(full["hip"]["z"][b], full["f64r"]["z"][b]))
+        assert close(full[path]["z"][b], full[replay]["z"][b]), (path, b, rel_err(full[path]["z"][b], full[replay]["z"][b]))
     rows, off, worst = [], 0, (0.0, "")
     bad = []
     for k, n in zip(pk, sizes):
@@ -308,25 +325,26 @@ def test_full_batch_gradients_strict_with_replayed_decisions(full, mode):
     flips32, flips64 = full["f32"]["flips"], full["f64"]["flips"]
     names = [f"bn{i}" for i in range(26)] + [f"pool{l}" for l in range(1, 5)]
     fl = {nm: (a, b) for nm, a, b in zip(names, flips32, flips64) if a or b}
-    line = (f"strict full-size gradients, decisions replayed (N = {full['n']}): whole-gradient L2 HIP vs fp64 {tot:.2e}; worst tensor "
-            f"{worst[0]:.3f} of the element-wise 1e-4 budget ({worst[1]}); decisions taken differently from the HIP forward by the "
-            f"free-running oracle: fp32 {sum(flips32)}, fp64 {sum(flips64)} of ~1e9")
+    line = (f"strict full-size gradients [{tagp}], decisions replayed (N = {full['n']}): whole-gradient L2 HIP vs fp64 {tot:.2e}; worst tensor "
+            f"{worst[0]:.3f} of the element-wise 1e-4 budget ({worst[1]})" +
+            (f"; decisions taken differently from the HIP forward by the free-running oracle: fp32 {sum(flips32)}, fp64 {sum(flips64)} of ~1e9"
+             if path == "hip" else ""))
     print(line)
     summary_line(line)
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "fullsize_replayed_decisions.json"), "w") as fh:
-            json.dump({"N": full["n"], "composition": TRUTH_KIND, "whole_gradient_l2_hip_vs_replayed_fp64": tot,
+        with open(os.path.join(d, "fullsize_replayed_decisions.json" if path == "hip" else "fullsize_replayed_decisions_split.json"), "w") as fh:
+            json.dump({"N": full["n"], "composition": TRUTH_KIND, "path": tagp, "whole_gradient_l2_hip_vs_replayed_fp64": tot,
                        "worst_tensor_mixed_err": worst[0], "worst_tensor": worst[1],
                        "flipped_decisions_vs_hip_forward": {"layers (fp32 oracle, fp64 oracle)": fl, "fp32_total": sum(flips32),
                                                             "fp64_total": sum(flips64)},
                        "tensors": rows}, fh)
     if mode == "hip":
-        assert not bad, bad[:4]
+        assert not bad, (path, bad[:4])
     else:
         # the emulator run only checks this test's plumbing: at 2 x 16 x 16 the deepest BatchNorm normalises TWO values per channel
         # (1 x 1 pixels x 2 samples), whose gradient amplifies fp32 round-off by orders of magnitude in any implementation
-        assert tot <= 2.0 * float(np.linalg.norm(gc - gt) / np.linalg.norm(gt)) + 1e-6, tot
+        assert tot <= 2.0 * float(np.linalg.norm(gc - gt) / np.linalg.norm(gt)) + 1e-6, (path, tot)
 
 
 REG_KINDS = ("pce_tv", "pce_ms", "pce_entropy", "mean_teacher")

@@ -123,8 +123,9 @@ __device__ __forceinline__ float sp_f4(const float4& v, int i) { return i == 0 ?
 // cf: the thread's OWN BatchNorm coefficients {scale, shift} of the eight channels of each task, in REGISTERS, times cmul (the
 // operand scale of a BatchNorm source is folded into its coefficients: exact, a power of two) -- a
 // staging thread works on the same octet in every tile, so they are fetched from global memory (L1) once per kernel (weight
-// gradient) or per channel chunk (conv), never from an LDS table: table reads inside the staging code returned wrong pairs on
-// MI355X whenever a second workgroup shared the CU (profiles/r3_sp_hunt.md, cause 1).  cml: this sample's channel multipliers (global
+// gradient) or per channel chunk (conv).  (Round 3 read them from an LDS float2 table and got wrong tiles whenever a second workgroup
+// shared the CU: not the table reads -- the packed FMA hipcc built from the float2 is unsafe next to f16 MFMAs on gfx950,
+// profiles/r4_sp_root_cause.md; xform_bn_leaky now detaches its scalars, so either source of coefficients is safe.)  cml: this sample's channel multipliers (global
 // memory), indexed by the channel inside the concatenated input (tc0 = index of channel chb).  `zero_fill`: tasks outside the
 // image write zero slots.
 template <typename I>
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
         bh[j] = *reinterpret_cast<const wsl_u4*>(q);
         bl[j] = *reinterpret_cast<const wsl_u4*>(q + 5 * 4 * CO_T * 16);
       }
-      // pairs of row tiles: four operand reads, one LDS fence in front of the inline-assembly MFMAs (wsl_rt.h), 6 NT MFMAs
+      // pairs of row tiles: four operand reads, 6 NT MFMAs
 #pragma unroll
       for (int i0 = 0; i0 < C::MT; i0 += 2) {
         wsl_u4 ah[2], al[2];
@@ -425,31 +426,19 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
           const unsigned char* q = a_img + aoff[s] + (mt / C::SEGS) * I::ROWB + (mt % C::SEGS) * 64;
           ah[d] = *reinterpret_cast<const wsl_u4*>(q), al[d] = *reinterpret_cast<const wsl_u4*>(q + I::HL);
         }
-        WSL_LDS_READ_FENCE4(ah[0], al[0], ah[1], al[1]);
-        if (i0 == 0) {
-#pragma unroll
-          for (int j = 0; j < C::NT; ++j) WSL_LDS_READ_FENCE2(bh[j], bl[j]);
-        }
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const int i = i0 + d;
 #pragma unroll
           for (int j = 0; j < C::NT; ++j) {
-            WSL_MFMA_F16_INPLACE(ah[d], bl[j], acc[i][j]);
-            WSL_MFMA_F16_INPLACE(al[d], bh[j], acc[i][j]);
-            WSL_MFMA_F16_INPLACE(ah[d], bh[j], acc[i][j]);
+            acc[i][j] = WSL_MFMA_F16(ah[d], bl[j], acc[i][j]);
+            acc[i][j] = WSL_MFMA_F16(al[d], bh[j], acc[i][j]);
+            acc[i][j] = WSL_MFMA_F16(ah[d], bh[j], acc[i][j]);
           }
         }
-        WSL_MFMA_SRC_RELEASE4(ah[0], al[0], ah[1], al[1]);
       }
-#pragma unroll
-      for (int j = 0; j < C::NT; ++j) WSL_MFMA_SRC_RELEASE2(bh[j], bl[j]);
     }
     if (c0 + 16 >= Ci) {
-#pragma unroll
-      for (int i = 0; i < C::MT; ++i)
-#pragma unroll
-        for (int j = 0; j < C::NT; ++j) WSL_MFMA_DRAIN(acc[i][j]);
       // ---- epilogue of tile t: undo the operand scales, bias, float4 stores, statistics (tiles and channel blocks are full)
       const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y;
       const int y0 = ty * TH, x0 = tx * TW;
@@ -729,14 +718,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
       const wsl_u2 a0 = WSL_DS_READ_TR16(dy_img + dyo[0] + dk), a1 = WSL_DS_READ_TR16(dy_img + dyo[1] + dk);
       const wsl_u2 a2 = WSL_DS_READ_TR16(dy_img + ID::HL + dyo[0] + dk), a3 = WSL_DS_READ_TR16(dy_img + ID::HL + dyo[1] + dk);
       ah = wsl_u4{a0[0], a0[1], a1[0], a1[1]}, al = wsl_u4{a2[0], a2[1], a3[0], a3[1]};
-      WSL_LDS_READ_FENCE2(ah, al);   // (the operands of inline-assembly MFMAs: wsl_rt.h)
     };
     auto read_b = [&](int row_off, int kx, wsl_u4& bh, wsl_u4& bl) __attribute__((always_inline)) {
       const unsigned char* q = in_img + row_off;
       const wsl_u2 b0 = WSL_DS_READ_TR16(q + ino[0][kx]), b1 = WSL_DS_READ_TR16(q + ino[1][kx]);
       const wsl_u2 b2 = WSL_DS_READ_TR16(q + II::HL + ino[0][kx]), b3 = WSL_DS_READ_TR16(q + II::HL + ino[1][kx]);
       bh = wsl_u4{b0[0], b0[1], b1[0], b1[1]}, bl = wsl_u4{b2[0], b2[1], b3[0], b3[1]};
-      WSL_LDS_READ_FENCE2(bh, bl);
     };
     if constexpr (CB == 32 && TW == 32) {
       // a K-step is one tile row: walk the INPUT rows r = 0 .. TH + 1 of the halo image; the three column-shifted operands of row r
@@ -748,8 +735,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
         if (r < TH) {
           read_a(r, ah[r % 3], al[r % 3]);
           if (want_db) {
-            WSL_MFMA_F16_INPLACE_V(al[r % 3], ones, accdb);
-            WSL_MFMA_F16_INPLACE_V(ah[r % 3], ones, accdb);
+            accdb = WSL_MFMA_F16(al[r % 3], ones, accdb);
+            accdb = WSL_MFMA_F16(ah[r % 3], ones, accdb);
           }
         }
 #pragma unroll
@@ -760,14 +747,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
           for (int ky = 0; ky < 3; ++ky) {
             const int y = r - ky;
             if (y >= 0 && y < TH) {
-              WSL_MFMA_F16_INPLACE(ah[y % 3], bl, acc[ky * 3 + kx]);
-              WSL_MFMA_F16_INPLACE(al[y % 3], bh, acc[ky * 3 + kx]);
-              WSL_MFMA_F16_INPLACE(ah[y % 3], bh, acc[ky * 3 + kx]);
+              acc[ky * 3 + kx] = WSL_MFMA_F16(ah[y % 3], bl, acc[ky * 3 + kx]);
+              acc[ky * 3 + kx] = WSL_MFMA_F16(al[y % 3], bh, acc[ky * 3 + kx]);
+              acc[ky * 3 + kx] = WSL_MFMA_F16(ah[y % 3], bh, acc[ky * 3 + kx]);
             }
           }
-          WSL_MFMA_SRC_RELEASE2(bh, bl);
         }
-        if (r >= 2) WSL_MFMA_SRC_RELEASE2(ah[(r - 2) % 3], al[(r - 2) % 3]);   // output row r - 2 is complete: its slot is re-read next
       }
     } else {
 #pragma unroll
@@ -776,28 +761,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
         wsl_u4 ah, al;
         read_a(ks, ah, al);
         if (want_db) {
-          WSL_MFMA_F16_INPLACE_V(al, ones, accdb);
-          WSL_MFMA_F16_INPLACE_V(ah, ones, accdb);
+          accdb = WSL_MFMA_F16(al, ones, accdb);
+          accdb = WSL_MFMA_F16(ah, ones, accdb);
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           wsl_u4 bh, bl;
           read_b(ks * C::KROWS * II::ROWB + (tap / 3) * II::ROWB, tap % 3, bh, bl);
-          WSL_MFMA_F16_INPLACE(ah, bl, acc[tap]);
-          WSL_MFMA_F16_INPLACE(al, bh, acc[tap]);
-          WSL_MFMA_F16_INPLACE(ah, bh, acc[tap]);
-          WSL_MFMA_SRC_RELEASE2(bh, bl);
+          acc[tap] = WSL_MFMA_F16(ah, bl, acc[tap]);
+          acc[tap] = WSL_MFMA_F16(al, bh, acc[tap]);
+          acc[tap] = WSL_MFMA_F16(ah, bh, acc[tap]);
         }
-        WSL_MFMA_SRC_RELEASE2(ah, al);
       }
     }
     __syncthreads();
     t = tn;
   }
 
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) WSL_MFMA_DRAIN(acc[tap]);
-  WSL_MFMA_DRAIN(accdb);
   // ---- partials: D[row = co][col = ci]; lane holds rows 4 (lane >> 4) + r of column lane & 15
   const float u1 = sp_pow2(-e_dy), u2 = sp_pow2(-WSL_SP_ACT_EXP);
   const int sidx = CB == 32 ? split : split * 4 + wave;

@@ -24,6 +24,11 @@ struct WslNetDesc;
 int wsl_debug_net_decisions(const struct WslNetDesc* d, const void* ws, size_t ws_bytes, int which, int index, unsigned char* out,
                             void* stream);
 
+/* Named regions of a network workspace in allocation order (raw conv outputs, decoder tensors, scratch sets, weight images):
+ * index 0, 1, ... until the return value is 1.  Offsets / sizes in floats.  For tools that compare the workspaces of two runs
+ * (tools/diff_runs_split.py). */
+int wsl_debug_net_ws_region(const struct WslNetDesc* d, int index, char* name, size_t name_len, size_t* off_floats, size_t* n_floats);
+
 /* Only in the EXPERIMENTS build (-DWSL_EXPERIMENTS: `build.sh exp` -> tools/exp/libwslhip_exp.so, and the host emulator):
  * ablation switches (env WSL_CONV_ABLATE / WSL_WGRAD_ABLATE: they skip
  * work, results are WRONG by design), ~20 env tuning knobs (WSL_TUNE in wsl_rt.h) and three machine probes. */

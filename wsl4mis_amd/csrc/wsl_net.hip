@@ -19,6 +19,7 @@ int sp_pack_table(const PackTable& t, const int64_t* img_off_bytes, const float*
 static const int kFt[5] = {16, 32, 64, 128, 256};            // unet.py:291
 static const float kDrop[5] = {0.05f, 0.1f, 0.2f, 0.3f, 0.5f};  // unet.py:292
 static const float kEps = 1e-5f, kMom = 0.1f;
+constexpr int kSpMaxLayers = 40;   // = PackTable's capacity: conv layers of one network (36 in unet_cct)
 
 struct ConvRef { int64_t w, b; int Ci, Co, ks; int li; };   // li: index in the pack table
 struct BnRef { int64_t gamma, beta, rmean, rvar; int nbt, C; };
@@ -44,6 +45,9 @@ struct Plan {
   size_t spf, spd, sp_wmax, sp_dymax;
   int sp;
   size_t wg_bytes, bn_bytes, bn_coef_bytes, total_floats;   // wg_bytes: per scratch set, room for the partials of EVERY layer of a phase
+  // named regions of the workspace, in allocation order (wsl_debug_net_ws_region: the tools that compare two runs' workspaces)
+  struct Region { char name[48]; size_t off, n; } regs[192];
+  int nregs;
 };
 
 struct Bump {
@@ -108,7 +112,24 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   }
 
   // ---- workspace
-  Bump B;
+  Bump B0;
+  P.nregs = 0;
+  struct Named {   // Bump that also records what it hands out
+    Bump& b;
+    Plan& P;
+    const char* tag = "";
+    int i0 = 0, i1 = 0;
+    size_t& off;
+    size_t take(size_t n, const char* what = "") {
+      const size_t o = b.take(n);
+      if (P.nregs < 192) {
+        Plan::Region& r = P.regs[P.nregs++];
+        snprintf(r.name, sizeof(r.name), "%s[%d,%d].%s", tag, i0, i1, what);
+        r.off = o, r.n = n;
+      }
+      return o;
+    }
+  } B{B0, P, "", 0, 0, B0.off};
   const size_t N = d->N;
   size_t max_stat = 0, max_cnt = 0;
   // weight-gradient partials stay alive until the phase's single second-stage launch: one region per layer.  A scratch set
@@ -119,8 +140,8 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   size_t* wg_acc = &wg_enc;
   auto plan_blkws = [&](BlkWs& w, const BlockRef& k, int l) {
     const size_t e = N * k.c1.Co * P.H[l] * P.W[l];
-    w.y1 = B.take(e), w.y2 = B.take(e);
-    w.st1 = B.take(4 * k.c1.Co), w.st2 = B.take(4 * k.c1.Co);
+    w.y1 = B.take(e, "y1"), w.y2 = B.take(e, "y2");
+    w.st1 = B.take(4 * k.c1.Co, "st1"), w.st2 = B.take(4 * k.c1.Co, "st2");
     for (const ConvRef* c : {&k.c1, &k.c2}) {
       size_t nb = wsl_conv2d_stat_blocks(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
       size_t wgb = wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l], P.W[l], c->Ci, c->Co, 3);
@@ -148,20 +169,22 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
     if (bb > P.bn_bytes) P.bn_bytes = bb;
   };
   for (int l = 0; l < 5; ++l) {
+    B.tag = "enc", B.i0 = l, B.i1 = 0;
     plan_blkws(P.wenc[l], P.enc[l], l);
-    P.pooled[l] = l ? B.take(N * kFt[l - 1] * P.H[l] * P.W[l]) : 0;
+    P.pooled[l] = l ? B.take(N * kFt[l - 1] * P.H[l] * P.W[l], "pooled") : 0;
   }
   for (int k = 0; k < d->n_dec; ++k) {
     wg_dec = 0, wg_acc = &wg_dec;
     for (int i = 0; i < 4; ++i) {
       const int l = 3 - i, c2 = kFt[l];
-      P.wdec[k].u[i] = B.take(N * c2 * P.H[l + 1] * P.W[l + 1]);
-      P.wdec[k].up[i] = B.take(N * c2 * P.H[l] * P.W[l]);
-      P.wdec[k].dcat[i] = B.take(N * 2 * c2 * P.H[l] * P.W[l]);
+      B.tag = "dec", B.i0 = k, B.i1 = i;
+      P.wdec[k].u[i] = B.take(N * c2 * P.H[l + 1] * P.W[l + 1], "u");
+      P.wdec[k].up[i] = B.take(N * c2 * P.H[l] * P.W[l], "up");
+      P.wdec[k].dcat[i] = B.take(N * 2 * c2 * P.H[l] * P.W[l], "dcat");
       plan_blkws(P.wdec[k].blk[i], P.dec[k].blk[i], l);
       wg_add(wg_dec, wsl_conv2d_wgrad_ws_bytes(d->N, P.H[l + 1], P.W[l + 1], kFt[l + 1], c2, 1));
     }
-    P.wdec[k].glow4 = B.take(N * kFt[4] * P.H[4] * P.W[4]);
+    P.wdec[k].glow4 = B.take(N * kFt[4] * P.H[4] * P.W[4], "glow4");
     wg_add(wg_dec, wsl_conv2d_wgrad_ws_bytes(d->N, P.H[0], P.W[0], kFt[0], d->n_class, 3));
   }
   P.wg_bytes = wg_enc > wg_dec ? wg_enc : wg_dec;
@@ -174,16 +197,23 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   }
   for (int k = 0; k < d->n_dec; ++k) {
     Plan::Scratch& S = P.scr[k];
-    S.tmp_g = B.take(big), S.tmp_g1 = B.take(big), S.tmp_dy = B.take(big);
-    S.tmp_du = B.take(big / 4), S.tmp_gpool = B.take(big / 4);
-    S.stat_part = B.take(max_stat), S.stat_cnt = B.take(max_cnt);
-    S.wg_ws = B.take((P.wg_bytes + 3) / 4), S.bn_ws = B.take((P.bn_bytes + 3) / 4), S.bn_coef = B.take((P.bn_coef_bytes + 3) / 4);
+    B.tag = "scratch", B.i0 = k, B.i1 = 0;
+    S.tmp_g = B.take(big, "tmp_g"), S.tmp_g1 = B.take(big, "tmp_g1"), S.tmp_dy = B.take(big, "tmp_dy");
+    S.tmp_du = B.take(big / 4, "tmp_du"), S.tmp_gpool = B.take(big / 4, "tmp_gpool");
+    S.stat_part = B.take(max_stat, "stat_part"), S.stat_cnt = B.take(max_cnt, "stat_cnt");
+    S.wg_ws = B.take((P.wg_bytes + 3) / 4, "wg_ws"), S.bn_ws = B.take((P.bn_bytes + 3) / 4, "bn_ws");
+    S.bn_coef = B.take((P.bn_coef_bytes + 3) / 4, "bn_coef");
   }
   if (d->n_dec == 1) P.scr[1] = P.scr[0];
-  P.packf = B.take(P.n_param), P.packd = B.take(P.n_param);  // packed [tap][ci][co] weight images (fwd / data-gradient)
-  P.winof = B.take(2 * P.n_param), P.winod = B.take(2 * P.n_param);
+  B.tag = "images", B.i0 = 0, B.i1 = 0;
+  P.packf = B.take(P.n_param, "packf"), P.packd = B.take(P.n_param, "packd");  // packed [tap][ci][co] weight images (fwd / data-gradient)
+  P.winof = B.take(2 * P.n_param, "winof"), P.winod = B.take(2 * P.n_param, "winod");
   P.spf = P.spd = P.sp_wmax = P.sp_dymax = 0;
-  if (P.sp) P.spf = B.take(P.n_param * 10 / 9 + 64), P.spd = B.take(P.n_param * 10 / 9 + 64), P.sp_wmax = B.take(64), P.sp_dymax = B.take(32 * WSL_SP_AMAX_SLOTS);   // (26 BatchNorm layers in unet_cct)
+  if (P.sp) {
+    // one max |w| slot per pack-table entry, WSL_SP_AMAX_SLOTS max |dy| slots per BatchNorm layer: sized from the plan
+    P.spf = B.take(P.n_param * 10 / 9 + 64, "spf"), P.spd = B.take(P.n_param * 10 / 9 + 64, "spd");
+    P.sp_wmax = B.take(kSpMaxLayers, "sp_wmax"), P.sp_dymax = B.take((size_t)P.n_bn * WSL_SP_AMAX_SLOTS, "sp_dymax");
+  }
   P.total_floats = B.off;
   return WSL_OK;
 }
@@ -353,11 +383,12 @@ static int pack_all(const Ctx& c, int with_dgrad) {
   WSL_TRY(conv2_pack_table(t, c.params, c.ws + P.packf, c.ws + P.packd, with_dgrad, c.stream));
   WSL_TRY(wino_pack_table(t, c.params, c.ws + P.winof, c.ws + P.winod, with_dgrad, c.stream));
   if (P.sp) {   // f16 hi / lo images + the layers' max |w|; a training forward also clears the max |dy| slots of its backward
-    int64_t off[40];
+    WSL_REQUIRE(t.n <= kSpMaxLayers, "net: %d conv layers exceed the split path's table (%d)", t.n, kSpMaxLayers);
+    int64_t off[kSpMaxLayers];
     for (int i = 0; i < t.n; ++i) off[i] = 4 * (int64_t)(4 * ((10 * t.e[i].w + 35) / 36));
-    // (sp_wmax and sp_dymax are adjacent workspace regions: one clear)
-    const size_t clr = with_dgrad ? (P.sp_dymax - P.sp_wmax) + 32 * WSL_SP_AMAX_SLOTS : 64;
-    if (hipMemsetAsync(c.ws + P.sp_wmax, 0, clr * sizeof(float), (hipStream_t)c.stream) != hipSuccess) {
+    // two regions, two clears (their sizes come from the plan; nothing assumes they are neighbours)
+    if (hipMemsetAsync(c.ws + P.sp_wmax, 0, kSpMaxLayers * sizeof(float), (hipStream_t)c.stream) != hipSuccess ||
+        (with_dgrad && hipMemsetAsync(c.ws + P.sp_dymax, 0, (size_t)P.n_bn * WSL_SP_AMAX_SLOTS * sizeof(float), (hipStream_t)c.stream) != hipSuccess)) {
       set_error("net: clearing the split path's maxima failed");
       return WSL_EHIP;
     }
@@ -701,6 +732,16 @@ __global__ __launch_bounds__(256) void dbg_argmax_kernel(const float* y, const f
   }
 }
 }  // namespace wsl
+
+extern "C" int wsl_debug_net_ws_region(const WslNetDesc* d, int index, char* name, size_t name_len, size_t* off_floats, size_t* n_floats) {
+  Plan P;
+  WSL_TRY(make_plan(d, P));
+  if (index < 0 || index >= P.nregs) return 1;   // (past the end: not an error worth a message)
+  WSL_REQUIRE(name && name_len > 0 && off_floats && n_floats, "debug_net_ws_region: null argument");
+  snprintf(name, name_len, "%s", P.regs[index].name);
+  *off_floats = P.regs[index].off, *n_floats = P.regs[index].n;
+  return WSL_OK;
+}
 
 extern "C" int wsl_debug_net_decisions(const WslNetDesc* d, const void* ws, size_t ws_bytes, int which, int index, unsigned char* out,
                                        void* stream) {

@@ -20,17 +20,10 @@ typedef wsl_v4f v4f;
 #define WSL_LDS_DMA16(gsrc, lds_wave_base) wsl_emu_lds_dma16(gsrc, lds_wave_base)
 #define WSL_WAIT_ALL()
 #define WSL_SCHED_BARRIER()
-#define WSL_LDS_READ_FENCE2(a, b)
-#define WSL_LDS_READ_FENCE4(a, b, c, d)
 typedef wsl_emu_u4 wsl_u4;
 typedef wsl_emu_u2 wsl_u2;
 #define WSL_MFMA_F16(a, b, c) wsl_emu_mfma16x32_f16(a, b, c)
-#define WSL_MFMA_F16_INPLACE(a, b, c) (c) = wsl_emu_mfma16x32_f16(a, b, c)
-#define WSL_MFMA_F16_INPLACE_V(a, b, c) (c) = wsl_emu_mfma16x32_f16(a, b, c)
 #define WSL_WAVE_UNIFORM(x) (x)
-#define WSL_MFMA_DRAIN(c)
-#define WSL_MFMA_SRC_RELEASE2(a, b)
-#define WSL_MFMA_SRC_RELEASE4(a, b, c, d)
 #define WSL_DS_READ_TR16(p) wsl_emu_ds_read_tr16(p)
 #else
 #include <hip/hip_runtime.h>
@@ -53,79 +46,20 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define WSL_WAIT_ALL() __builtin_amdgcn_s_waitcnt(0)
 // keeps the instruction scheduler from moving LDS reads / MFMAs across a software-pipeline stage boundary
 #define WSL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-// The split-precision kernels (wsl_convsp.hip) issue their f16 MFMAs through inline assembly with the accumulator IN PLACE
-// (vDst == SrcC).  Reason (profiles/r3_sp_hunt.md, cause 2): with the builtin, hipcc (ROCm 7.2) renames the accumulators of a
-// hi*lo + lo*hi + hi*hi chain -- MFMA k + 1 takes MFMA k's vDst as SrcC but writes ANOTHER register tuple -- and places its own
-// wait states.  Every per-kernel test passes in that form; the full-size NETWORK gradient (kernels of the two decoder streams
-// sharing CUs) was wrong by 4e-3 .. 1e-2 and different from run to run with it, with or without full waits around the commits,
-// and is right and bit-reproducible with the chains below (tools/ab_split_fullsize.py: 2.23e-3 from the f32 path on every run,
-// the distance the fp32 kernels themselves keep from torch).  Inline assembly is invisible to the compiler's hazard recogniser
-// and wait-count pass, so every dependence of these MFMAs is spelled out here:
-//   WSL_LDS_READ_FENCE*   LDS operand reads -> MFMA: all of the wave's LDS operations complete (tied to the operand registers so
-//                         no consumer moves above it), + 2 states for a register copy hipcc may have placed in front of it;
-//   WSL_MFMA_SRC_RELEASE* last MFMA reading operand registers -> the next LDS read that overwrites them;
-//   WSL_MFMA_DRAIN        last MFMA of a chain -> any other reader / writer of the accumulator (4 passes + margin).
-// Which of these the hardware needs is not separated (the round's GPU minutes ended with the A/B); the set is what was measured.
-// A / B builds for the open question (tools/build_sp_variants.sh -> tools/exp/libwslhip_sp_*.so, measured with
-// tools/ab_split_fullsize.py; the product defines none of these): WSL_SP_AB_FORM = 1 compiler chains (the builtin) | 2 inline
-// assembly with an early-clobber destination that is NOT the accumulator (a renamed chain whose destination can overlap no
-// operand); WSL_SP_AB_NO_FENCE / _NO_RELEASE / _SHORT_DRAIN drop one ingredient each.
-#ifndef WSL_SP_RELEASE_ASM
-#define WSL_SP_RELEASE_ASM "s_nop 7\n\ts_nop 3"
-#endif
-#if defined(WSL_SP_AB_NO_FENCE) || (defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 1)
-#define WSL_LDS_READ_FENCE2(a, b)
-#define WSL_LDS_READ_FENCE4(a, b, c, d)
-#else
-#define WSL_LDS_READ_FENCE2(a, b) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" : "+v"(a), "+v"(b))
-#define WSL_LDS_READ_FENCE4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-#endif
 // v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8 (l >> 4) + e], B[k = 8 (l >> 4) + e][j = l & 15] (8 halves = 4 VGPRs each, passed as
 // four 32-bit words), D as WSL_MFMA16 (probed: tools/probe_sp.hip).  Products exact in fp32, fp32 accumulation, f16 subnormals kept.
+// The split-precision kernels use the compiler's builtin and its scheduling: round 3 had wrapped these chains in inline assembly with
+// fences and wait states because the full-size network gradient was wrong with the builtin -- the chains were never the problem
+// (profiles/r4_sp_root_cause.md: every MFMA source / destination hazard is interlocked on gfx950; the wrong results came from a packed-f32
+// op_sel form in the OTHER kernels on the CU, see WSL_DETACH32 below).
 typedef uint32_t wsl_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t wsl_u2 __attribute__((ext_vector_type(2)));
 typedef _Float16 wsl_h8 __attribute__((ext_vector_type(8)));
 typedef short wsl_s4 __attribute__((ext_vector_type(4)));
 #define WSL_MFMA_F16(a, b, c) \
   __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wsl_h8, (a)), __builtin_bit_cast(wsl_h8, (b)), (c), 0, 0, 0)
-#if defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 1
-#define WSL_MFMA_F16_INPLACE(a, b, c) (c) = WSL_MFMA_F16(a, b, c)
-#define WSL_MFMA_F16_INPLACE_V(a, b, c) (c) = WSL_MFMA_F16(a, b, c)
-#elif defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 2
-#define WSL_MFMA_F16_INPLACE(a, b, c)                                                                              \
-  do {                                                                                                             \
-    v4f wsl_t_;                                                                                                    \
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %1" : "=&v"(wsl_t_) : "v"(c), "v"(a), "v"(b));               \
-    (c) = wsl_t_;                                                                                                  \
-  } while (0)
-#define WSL_MFMA_F16_INPLACE_V(a, b, c)                                                                            \
-  do {                                                                                                             \
-    v4f wsl_t_;                                                                                                    \
-    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %2, %3, %1" : "=&v"(wsl_t_) : "v"(c), "v"(a), "v"(b));    \
-    (c) = wsl_t_;                                                                                                  \
-  } while (0)
-#else
-#define WSL_MFMA_F16_INPLACE(a, b, c) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
-// ... with an operand the compiler materialises with vector moves right in front of it (a constant): VALU write -> MFMA read
-#define WSL_MFMA_F16_INPLACE_V(a, b, c) asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
-#endif
-#if defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 1
-#define WSL_MFMA_DRAIN(c)
-#elif defined(WSL_SP_AB_SHORT_DRAIN)
-#define WSL_MFMA_DRAIN(c) asm volatile("s_nop 7" : "+v"(c))      /* the 8 states hipcc itself places after a 4-pass XDL write */
-#else
-#define WSL_MFMA_DRAIN(c) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(c))
-#endif
-// a value that is the same in every lane of the wave, held in a scalar register: branches on it are real branches (inline-assembly
-// MFMAs ignore the EXEC mask the compiler would otherwise predicate a wave-dependent block with)
+// a value that is the same in every lane of the wave, held in a scalar register (branches on it are real branches)
 #define WSL_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
-#if defined(WSL_SP_AB_NO_RELEASE) || (defined(WSL_SP_AB_FORM) && WSL_SP_AB_FORM == 1)
-#define WSL_MFMA_SRC_RELEASE2(a, b)
-#define WSL_MFMA_SRC_RELEASE4(a, b, c, d)
-#else
-#define WSL_MFMA_SRC_RELEASE2(a, b) asm volatile(WSL_SP_RELEASE_ASM : "+v"(a), "+v"(b))
-#define WSL_MFMA_SRC_RELEASE4(a, b, c, d) asm volatile(WSL_SP_RELEASE_ASM : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-#endif
 // ds_read_b64_tr_b16: inside a group of 16 lanes, lane i receives as element e the (i & 3)-th half of the four contiguous halves
 // at the (8-byte aligned) LDS address supplied by lane 4 e + (i >> 2) of the group -- a 4 x 16 block of halves read row-wise,
 // delivered column-wise (probed: tools/probe_sp.hip)
@@ -193,8 +127,23 @@ __device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : WSL_LEAKY
 // The loader transform on one float4, written on 2-wide native vectors so the compiler emits packed f32 math
 // (v_pk_fma_f32 / v_pk_mul_f32): BN affine, LeakyReLU as max(z, slope*z) (bit-identical to leaky()), keep mask bytes
 // (0 or 1) and scale as float factors.  `m` is the uchar4 of keep bytes read as one 32-bit word.
+//
+// HARDWARE RULE (gfx950, measured: profiles/r4_sp_root_cause.md, tools/probe_pk_opsel.hip): v_pk_fma_f32 / v_pk_mul_f32 whose op_sel
+// takes the LOW half of src1 (or src2) from the HIGH register of the source pair return a wrong low half while another wave of the SIMD
+// issues v_mfma_f32_16x16x32_f16 -- and with the split-precision conv path one decoder's f16-MFMA kernels run beside every other
+// kernel of the step.  hipcc emits exactly that form when a broadcast operand is the .y of a float2 that was loaded as one 64-bit
+// value (`x * {t.x, t.x} + {t.y, t.y}` -> v_pk_fma_f32 d, x, t, t op_sel:[0,0,1] op_sel_hi:[1,0,1]).  WSL_DETACH32 cuts a scalar
+// loose from the register pair it was loaded in (a 32-bit copy), after which a broadcast is formed from the LOW register of a fresh
+// pair (op_sel_hi only: measured clean).  tools/scan_vop3p.py (tests/test_abi.py) fails the build if an unsafe form is left anywhere.
 typedef float wsl_v2f __attribute__((ext_vector_type(2)));
+#ifdef WSL_HOST_EMUL
+#define WSL_DETACH32(x)
+#else
+#define WSL_DETACH32(x) asm volatile("" : "+v"(x))
+#endif
 __device__ __forceinline__ void xform_bn_leaky(wsl_v2f& lo, wsl_v2f& hi, float sc, float sh) {
+  WSL_DETACH32(sc);
+  WSL_DETACH32(sh);
   const wsl_v2f sc2 = {sc, sc}, sh2 = {sh, sh};
   lo = __builtin_elementwise_fma(lo, sc2, sh2), hi = __builtin_elementwise_fma(hi, sc2, sh2);
   const wsl_v2f l2 = lo * WSL_LEAKY_SLOPE, h2 = hi * WSL_LEAKY_SLOPE;
