@@ -48,8 +48,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps after >= 10 warm-up steps
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--conv-precision", default="f32", choices=["f32", "split_f16x3"],
-                    help="f32 (the headline) | split_f16x3: the opt-in split-precision conv path (f16 hi / lo operands, three MFMA "
-                         "passes, fp32 accumulate) -- a separately labelled record (dtype f32-split-f16x3), never the headline")
+                    help="f32 (the headline) | split_f16x3: the split-precision conv path (f16 hi / lo operands, three MFMA "
+                         "passes, fp32 accumulate) as the primary record (dtype f32-split-f16x3)")
+    ap.add_argument("--no-split-record", action="store_true",
+                    help="by default an f32 run is followed by the SAME workload on the split-precision conv path (own engine, own "
+                         "warm-up, >= 20 timed steps, own serialised roofline segment), nested as \"split_f16x3\" in the one JSON line")
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce", "mean_teacher", "ustm", "pce_tv", "pce_ms", "pce_entropy", "ce_dice"])
@@ -179,45 +182,51 @@ def main():
     from wsl4mis_amd.engine import TrainEngine
     from wsl4mis_amd.synthetic import batch
     dev = torch.device("cuda", local)
-    torch.manual_seed(2022)                                   # same initial weights on every rank
-    eng = TrainEngine(args.net, 1, 4, base_lr=0.01, max_iterations=60000, loss=args.loss, crf_radius=args.crf_radius,
-                      force_dp=args.force_dp, conv_precision=args.conv_precision)
-    torch.manual_seed(2022 + 1000 * rank)                     # different dropout masks / data per rank
-    x, lab = batch(args.batch, args.size, args.size, 2022 + rank, dev)
-    random.seed(2022)                                         # identical beta stream on all ranks
     L = _lib.lib()
-    if args.serial_decoders:
-        L.wsl_net_concurrent(0)
-        eng.concurrent = False
-    for _ in range(args.warmup):
-        eng.step(x, lab, random.random() + 1e-10)
-    if world > 1 or args.force_dp:
-        torch.cuda.synchronize()
-        C.CDLL(None).fflush(None)     # RCCL prints its version banner through C stdio: out now, not after the JSON line
+    x, lab = batch(args.batch, args.size, args.size, 2022 + rank, dev)
     overlapped = (args.net == "unet_cct" or args.loss == "mean_teacher") and not args.serial_decoders
     # per-launch HIP events cost ~2 % of the step rate: when the roofline comes from its own serialised segment anyway
     # (overlapped run) the timed region stays uninstrumented unless --prof-timed asks for its overlapping figures too
     prof_timed = not args.no_prof and (not overlapped or args.prof_timed)
-    if prof_timed:
-        L.wsl_prof_enable(1)
-    if eng.dp:
-        eng.comm_diag(True)                                   # two events per step around the wait for the comm stream
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step(x, lab, random.random() + 1e-10)
-    torch.cuda.synchronize()
-    dt_own = time.perf_counter() - t0                         # this rank's own time, before it waits for the others
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+
+    def timed_region(precision, steps, warmup):
+        """engine of this conv precision, `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both
+        sides; returns (engine, max-over-ranks seconds, this rank's own seconds)"""
+        torch.manual_seed(2022)                                   # same initial weights on every rank
+        eng = TrainEngine(args.net, 1, 4, base_lr=0.01, max_iterations=60000, loss=args.loss, crf_radius=args.crf_radius,
+                          force_dp=args.force_dp, conv_precision=precision)
+        torch.manual_seed(2022 + 1000 * rank)                     # different dropout masks / data per rank
+        random.seed(2022)                                         # identical beta stream on all ranks
+        if args.serial_decoders:
+            L.wsl_net_concurrent(0)
+            eng.concurrent = False
+        for _ in range(warmup):
+            eng.step(x, lab, random.random() + 1e-10)
+        if world > 1 or args.force_dp:
+            torch.cuda.synchronize()
+            C.CDLL(None).fflush(None)     # RCCL prints its version banner through C stdio: out now, not after the JSON line
+        if prof_timed:
+            L.wsl_prof_enable(1)
+        if eng.dp:
+            eng.comm_diag(True)                                   # two events per step around the wait for the comm stream
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step(x, lab, random.random() + 1e-10)
+        torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0                         # this rank's own time, before it waits for the others
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return eng, float(tt.item()), dt_own
+
+    eng, dt, dt_own = timed_region(args.conv_precision, args.steps, args.warmup)
     losses = eng.losses()
     dp_diag = None
     if eng.dp:
@@ -268,7 +277,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import pmc_traffic as agg
         tmp = tempfile.mkdtemp(prefix="wsl_pmc_", dir="/tmp")
-        child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-prof",
+        child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-prof", "--no-split-record",
                  "--serial-decoders", "--conv-precision", args.conv_precision, "--loss", args.loss, "--net", args.net, "--batch", str(args.batch),
                  "--size", str(args.size), "--crf-radius", str(args.crf_radius)]
         try:
@@ -384,19 +393,23 @@ def main():
                 "hbm_roofline": {"peak_GBps": PEAK_HBM_GBS, "kernels": hbm,
                                  "all_hbm_kernels_ms_per_step": round(sum(v["ms_per_step"] for v in hbm.values()), 3)}}
 
-    roof, fams = None, {}
     if args.pmc_refresh and world == 1 and not args.no_prof:
         pmc_refresh()                  # (after the timed region: the child processes share this GPU)
-    if not args.no_prof:
+
+    def roofline_segment(eng, dt, steps):
+        """(roofline object, per-family rows) of the engine that just ran a timed region of `steps` steps in `dt` seconds"""
+        roof, fams = None, {}
+        if args.no_prof:
+            return roof, fams
         timed = None
         if prof_timed:
             rows, fams = report()
-            roof = roofline_of(rows, args.steps, 1e3 * dt / args.steps)
+            roof = roofline_of(rows, steps, 1e3 * dt / steps)
         if overlapped:
             # second segment, decoders serialised: launches of the dominant kernel no longer overlap each other
             if roof:
                 timed = {k: roof[k] for k in ("achieved", "frac", "launches", "avg_launch_us", "all_mfma_kernels_tflops")}
-            seg = max(1, min(args.steps, 5))
+            seg = max(1, min(steps, 5))
             L.wsl_net_concurrent(0)
             eng.concurrent = False
             eng.step(x, lab, random.random() + 1e-10)
@@ -410,13 +423,36 @@ def main():
             rows2, fams = report()
             L.wsl_net_concurrent(1)
             eng.concurrent = True
-            roof = roofline_of(rows2, seg, 1e3 * dt / args.steps)
+            roof = roofline_of(rows2, seg, 1e3 * dt / steps)
             if roof:
                 roof["measured"] = (f"{seg} extra steps of the same workload right after the timed region, two decoder streams "
                                     f"serialised ({round(seg_ms, 3)} ms/step incl. event overhead); in the timed region "
                                     "launches of this kernel overlap each other, so a per-launch duration does not measure it")
                 if timed:
                     roof["timed_region_overlapped"] = timed
+        return roof, fams
+
+    roof, fams = roofline_segment(eng, dt, args.steps)
+    # the SAME workload on the split-precision conv path, as a nested record: its own engine, warm-up, timed region
+    # (barrier + synchronize on both sides, max over ranks) and serialised roofline segment.  Headline fields stay the f32 path's.
+    split_rec = None
+    if args.conv_precision == "f32" and not args.no_split_record and args.loss != "ustm":
+        del eng
+        torch.cuda.empty_cache()
+        s_steps, s_warm = max(20, min(args.steps, 50)), max(5, min(args.warmup, 10))
+        eng_s, dt_s, _ = timed_region("split_f16x3", s_steps, s_warm)
+        if eng_s.dp:
+            eng_s.comm_diag(False)
+        losses_s = eng_s.losses()
+        roof_s, _ = roofline_segment(eng_s, dt_s, s_steps)
+        split_rec = {"value": round(args.batch * world * s_steps / dt_s, 2), "unit": "slices/s", "ms_per_step": round(1e3 * dt_s / s_steps, 3),
+                     "steps": s_steps, "warmup": s_warm, "dtype": "f32-split-f16x3",
+                     "what": "the same workload with the 3x3 convolutions (forward, data gradient, weight gradient of the layers with >= 32 "
+                             "channels) on v_mfma_f32_16x16x32_f16: every operand split into f16 hi + lo while a tile is staged, three passes, "
+                             "fp32 accumulation; fp32 storage everywhere.  Same parity tests and tolerances as the f32 path "
+                             "(tests/test_ops_convsp.py, test_net.py, test_error_budget.py, test_fullsize.py, test_concurrency.py)",
+                     "roofline": roof_s, "last_losses": {k: round(v, 5) for k, v in losses_s.items()}}
+        del eng_s
     if rank == 0:
         gflop = 28.98 if args.net == "unet_cct" else 17.68     # conv-stack training GFLOP/slice
         if args.loss == "mean_teacher":
@@ -425,7 +461,12 @@ def main():
             gflop += 9 * 5.899                                 # + 1 + 4 x 2 teacher forwards per student slice
         value = args.batch * world * args.steps / dt
         split = args.conv_precision != "f32"
-        out = {"metric": "training slices/sec (256x256, bs64, unet_cct pCE+GatedCRF)" + (" -- SPLIT-PRECISION RECORD, not the headline" if split else ""),
+        headline = args.net == "unet_cct" and args.loss == "pce_gatedcrf" and args.size == 256 and args.batch == 64
+        wl = {"pce_gatedcrf": "pCE+GatedCRF", "ours_proposed": "pCE+mixed pseudo-label Dice", "pce": "pCE", "mean_teacher": "mean teacher pCE+TV+consistency",
+              "ustm": "USTM", "pce_tv": "pCE+TV", "pce_ms": "pCE+Mumford-Shah", "pce_entropy": "pCE+entropy", "ce_dice": "CE+Dice"}[args.loss]
+        out = {"metric": ("training slices/sec (256x256, bs64, unet_cct pCE+GatedCRF)" if headline else
+                          f"training slices/sec ({args.size}x{args.size}, bs{args.batch}, {args.net} {wl}) -- not BASELINE.json's headline workload")
+                         + (" -- SPLIT-PRECISION RECORD" if split else ""),
                "value": round(value, 2),
                "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -436,6 +477,8 @@ def main():
                           "conv_precision": args.conv_precision},
                "whole_step_conv_mfma_frac": round(value / world * gflop * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
                "roofline": roof, "kernels": fams, "last_losses": {k: round(v, 5) for k, v in losses.items()}}
+        if split_rec:
+            out["split_f16x3"] = split_rec
         if dp_diag:
             out["dp"] = dp_diag
         if world == 1 and not args.no_cpu_baseline:

@@ -283,6 +283,18 @@ def test_device_cache_keys_on_the_case_and_is_bounded(mode):
         random.seed(7), np.random.seed(8)
         ref_img, ref_lab = dataset.BatchRandomGenerator((32, 32))(fresh)
         assert np.array_equal(img.cpu().numpy(), ref_img.cpu().numpy()) and np.array_equal(lab.cpu().numpy(), ref_lab.cpu().numpy())
+    # the same file names from ANOTHER dataset (other label kind / fold / root) must not alias: 'source' is part of the key
+    other = [{"image": s["image"].copy(), "label": (3 - s["label"]).astype(s["label"].dtype), "case": f"patient{i:03d}_slice_1.h5",
+              "source": ("/data/ACDC", "train", "label")} for i, s in enumerate(base)]
+    same = [dict(o, source=("/data/ACDC", "train", "scribble")) for o in fresh]
+    gen2 = dataset.BatchRandomGenerator((32, 32), device_cache=True)
+    random.seed(7), np.random.seed(8)
+    _, lab_a = gen2(same)
+    random.seed(7), np.random.seed(8)
+    _, lab_b = gen2(other)
+    random.seed(7), np.random.seed(8)
+    _, ref_b = dataset.BatchRandomGenerator((32, 32))(other)
+    assert len(gen2._dev) == 8 and np.array_equal(lab_b.cpu().numpy(), ref_b.cpu().numpy()) and not np.array_equal(lab_a.cpu().numpy(), lab_b.cpu().numpy())
     with pytest.raises(_lib.WslError, match="distinct sources"):
         for rep in range(3):                        # no 'case': keyed by identity, fresh arrays never hit
             gen([{"image": s["image"].copy(), "label": s["label"].copy()} for s in base])

@@ -8,9 +8,13 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import explib  # noqa: E402
-
-_lib = explib.use()
+if os.environ.get("WSL_LIB"):          # any other build of the library (A / B timing)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from wsl4mis_amd import _lib  # noqa: E402
+    _lib.LIB_PATH = os.environ["WSL_LIB"]
+else:
+    import explib  # noqa: E402
+    _lib = explib.use()
 L = _lib.lib()
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream

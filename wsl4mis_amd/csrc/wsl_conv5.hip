@@ -737,6 +737,20 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
   const bool bn_ok = bn && bn->part;
   if (bn_ok) p.bn = *bn;
   if (bn_done) *bn_done = bn_ok ? 1 : 0;
+#ifdef WSL_EXPERIMENTS
+  {   // A / B: WIDE tiles (same pixels and tile count per workgroup, so the same BatchNorm-partial blocks): halo rows are fetched in
+      // 544-byte instead of 288- / 160-byte runs (tools/probe_tile_loads.hip: 3.7 against 3.1 / 2.5 TB/s of pure tile fetch at 256 x 256)
+    static const int wide = WSL_TUNE("WSL_WINO_WIDE", 0);
+    if ((wide & 1) && tw == 64 && W % 128 == 0 && H % 4 == 0) {
+      p.tiles_x = W / 128, p.tiles_y = H / 4;
+      return launch_wino2<4, 128, 1>(p, is_dgrad, stream);
+    }
+    if ((wide & 2) && th == 8 && tw == 32 && !narrow16 && W % 64 == 0 && H % 4 == 0) {
+      p.tiles_x = W / 64, p.tiles_y = H / 4;
+      return launch_wino2<4, 64, 2>(p, is_dgrad, stream);
+    }
+  }
+#endif
   if (tw == 64) return launch_wino2<8, 64, 1>(p, is_dgrad, stream);
   if (narrow16) return launch_wino2<8, 32, 1>(p, is_dgrad, stream);
   if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);

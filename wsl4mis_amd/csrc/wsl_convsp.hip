@@ -42,14 +42,14 @@ constexpr int kSpMaxC = 512;   // channels whose loader coefficients fit the LDS
 template <int ROWS_, int NQ_, int NOCT_, int P_ = 0, int PAD_ = 0>
 struct SpImg {
   static constexpr int ROWS = ROWS_, NQ = NQ_, NOCT = NOCT_;
-  static constexpr int P = P_ ? P_ : (NQ <= 12 ? 12 : (NQ <= 20 ? 20 : 28));
+  static constexpr int P = P_ ? P_ : (NQ <= 12 ? 12 : (NQ <= 20 ? 20 : (NQ <= 28 ? 28 : 36)));
   static constexpr int RS = 4 * P + 2;                              // slots per row (+2: consecutive rows rotate by two slots)
   static constexpr int ROWB = RS * 16;
   static constexpr int PLANE = ((ROWS * ROWB + 255) / 256) * 256 + PAD_;   // PAD_ = 0: = 0 (mod 256), the octets of one read hit the same bank groups
   static constexpr int HL = NOCT * PLANE;
   static constexpr int BYTES = 2 * HL;
   static constexpr int NTASK = ROWS * NQ * NOCT, NR = (NTASK + 255) / 256;
-  static_assert(NQ <= 28, "tile too wide");
+  static_assert(NQ <= 36, "tile too wide");
 };
 
 template <int NR>
@@ -288,7 +288,10 @@ struct ConvSpCfg {
   static constexpr int B_PIECES = B_BYTES / 16, NBW = (B_PIECES + 255) / 256;
   static constexpr int RED_BYTES = 8 * CO_T * 4;
   // waves per SIMD the register allocator must leave room for (a tighter cap spills the staging state into scratch)
-  static constexpr int MINW = NT == 1 ? 3 : 2;
+#ifndef WSL_SP_MINW16
+#define WSL_SP_MINW16 3   // (A / B: 2 = no register cap for the 16-channel blocks: no spills, one workgroup per CU fewer)
+#endif
+  static constexpr int MINW = (NT == 1 && Img::NR == 1) ? WSL_SP_MINW16 : 2;
   static size_t smem(int Ci, bool bres) { return Img::BYTES + (size_t)(bres ? Ci / 16 : 1) * B_BYTES + RED_BYTES; }
   static_assert(MT_TOTAL % 4 == 0 && MT % SEGS == 0 && MT % 2 == 0, "tile shape");
 };
@@ -538,6 +541,9 @@ struct SpPlan {
 static SpPlan sp_plan(int N, int H, int W, int Ci, int Co) {
   SpPlan f{0, 0, 0, false};
   if (Ci <= 0 || Co <= 0 || (Ci % 16) || (Co % 16) || Ci > kSpMaxC) return f;
+  // (4 x 128 tiles for the 16-channel layers -- 544-byte instead of 160-byte runs per halo row, 3.7 against 2.5 TB/s of pure tile fetch in
+  //  tools/probe_tile_loads.hip -- were built and measured in round 4: 204 / 291 us against 198 / 273 for 16 -> 16 / 32 -> 16 @ 256 x 256.
+  //  The wider tile costs a second round of staging registers and the third workgroup per CU; profiles/r4_conv_sp_where_the_time_goes.md)
   if (H % 8 == 0 && W % 32 == 0) f.th = 8, f.tw = 32;
   else if (H % 8 == 0 && W % 16 == 0) f.th = 8, f.tw = 16;
   else return f;

@@ -260,20 +260,32 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(HeadP h, int64_t* pseu
 // scal: 0 inv_nvalid; 1+c ca1, 1+C+c cb1, 1+2C+c ca2, 1+3C+c cb2 (already times w_pse*0.5/C)
 __global__ __launch_bounds__(256) void head_finalize_kernel(const float* part, int nblk, int C, int N, int dual,
                                                             float w_pse, float* out, float* scal) {
-  __shared__ double red[kThreads];
+  // all K <= 64 column sums of part[nblk][K] in ONE sweep: thread (quarter w, column k) adds every fourth row in fp64 (consecutive
+  // lanes read consecutive floats), the four quarters are merged in a fixed order.  (Round 3: 23 separate block reductions of 17
+  // barriers each -- 34 us for this single-workgroup kernel.)
   constexpr int K = 3 + 5 * kMaxC;
-  const double nll1 = col_sum(part, nblk, K, 0, red), nll2 = col_sum(part, nblk, K, 1, red),
-               cnt = col_sum(part, nblk, K, 2, red);
+  static_assert(K <= 64, "one column per lane");
+  __shared__ double red4[4][64];
+  __shared__ double tot[64];
+  {
+    const int w = threadIdx.x >> 6, k = threadIdx.x & 63;
+    double acc = 0;
+    if (k < K)
+      for (int b = w; b < nblk; b += 4) acc += part[(int64_t)b * K + k];
+    red4[w][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) tot[threadIdx.x] = (red4[0][threadIdx.x] + red4[1][threadIdx.x]) + (red4[2][threadIdx.x] + red4[3][threadIdx.x]);
+    __syncthreads();
+  }
+  const double nll1 = tot[0], nll2 = tot[1], cnt = tot[2];
   const float ce1 = (float)(nll1 / cnt), ce2 = (float)(nll2 / cnt);
   float pse = 0.f;
   if (dual) {
     float d1 = 0.f, d2 = 0.f;
     const float Nf = (float)N;  // pseudo labels are never `ignore`: the broadcast multiplies every sum by N
     for (int c = 0; c < C; ++c) {
-      const float I1 = Nf * (float)col_sum(part, nblk, K, 3 + c, red), Z1 = Nf * (float)col_sum(part, nblk, K, 3 + kMaxC + c, red),
-                  I2 = Nf * (float)col_sum(part, nblk, K, 3 + 2 * kMaxC + c, red),
-                  Z2 = Nf * (float)col_sum(part, nblk, K, 3 + 3 * kMaxC + c, red),
-                  Y = Nf * (float)col_sum(part, nblk, K, 3 + 4 * kMaxC + c, red);
+      const float I1 = Nf * (float)tot[3 + c], Z1 = Nf * (float)tot[3 + kMaxC + c], I2 = Nf * (float)tot[3 + 2 * kMaxC + c],
+                  Z2 = Nf * (float)tot[3 + 3 * kMaxC + c], Y = Nf * (float)tot[3 + 4 * kMaxC + c];
       const float D1 = Z1 + Y + 1e-5f, D2 = Z2 + Y + 1e-5f;
       d1 += 1.f - (2.f * I1 + 1e-5f) / D1;
       d2 += 1.f - (2.f * I2 + 1e-5f) / D2;
@@ -299,21 +311,23 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* part, i
 
 // gy != NULL: + wgt * softmax_bwd(s, gy) -- the gradient through the mixed prediction y (GatedCRF term), what
 // mixprob_bwd_kernel would accumulate in a pass of its own (same expressions; the contraction of the final sum may differ)
-__device__ __forceinline__ void head_branch_bwd(const float* s, int C, int t, int l, bool valid, const float* ca,
-                                                const float* cb, float kce, float gscale, float* dz, int64_t stride,
-                                                const float* gy = nullptr, float wgt = 1.f) {
+// (has_dice / has_gy as flags next to array REFERENCES: a pointer that may be null -- `dy_mix ? gy : nullptr` -- makes the per-class
+//  arrays address-taken and puts them into scratch memory: 48 bytes per lane in round 3's head_bwd_kernel<4>)
+__device__ __forceinline__ void head_branch_bwd(const float (&s)[kMaxC], int C, int t, int l, bool valid, bool has_dice,
+                                                const float (&ca)[kMaxC], const float (&cb)[kMaxC], float kce, float gscale, float* dz,
+                                                int64_t stride, bool has_gy, const float (&gy)[kMaxC], float wgt) {
   float dsv[kMaxC], dot = 0.f, doty = 0.f;
   for (int c = 0; c < C; ++c) {
-    dsv[c] = cb ? ca[c] * (c == t ? 1.f : 0.f) + cb[c] * s[c] : 0.f;
+    dsv[c] = has_dice ? ca[c] * (c == t ? 1.f : 0.f) + cb[c] * s[c] : 0.f;
     dot = fmaf(dsv[c], s[c], dot);
   }
-  if (gy)
+  if (has_gy)
     for (int c = 0; c < C; ++c) doty = fmaf(gy[c], s[c], doty);
   for (int c = 0; c < C; ++c) {
     float g = s[c] * (dsv[c] - dot);
     if (valid) g += kce * (s[c] - (c == l ? 1.f : 0.f));
     g = g * gscale;
-    if (gy) g = g + wgt * s[c] * (gy[c] - doty);
+    if (has_gy) g = g + wgt * s[c] * (gy[c] - doty);
     dz[c * stride] = g;
   }
 }
@@ -331,16 +345,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadP h, const float* sca
     const int l = h.label[i];
     const bool valid = (l != h.ignore) && l < C;
     float s1[kMaxC], s2[kMaxC], gy[kMaxC];
-    if (dy_mix)
-      for (int c = 0; c < C; ++c) gy[c] = ky * dy_mix[base + (int64_t)c * h.HW];
+    const bool has_gy = dy_mix != nullptr;
+    for (int c = 0; c < C; ++c) gy[c] = has_gy ? ky * dy_mix[base + (int64_t)c * h.HW] : 0.f;
     softmax_c(h.z1 + base, h.HW, C, s1);
     if (dual) {
       softmax_c(h.z2 + base, h.HW, C, s2);
       const int t = mix_argmax_c(s1, s2, C, h.bf, h.omb);
-      head_branch_bwd(s1, C, t, l, valid, ca1, cb1, kce, gscale, dz1 + base, h.HW, dy_mix ? gy : nullptr, h.bf);
-      head_branch_bwd(s2, C, t, l, valid, ca2, cb2, kce, gscale, dz2 + base, h.HW, dy_mix ? gy : nullptr, h.omb);
+      head_branch_bwd(s1, C, t, l, valid, true, ca1, cb1, kce, gscale, dz1 + base, h.HW, has_gy, gy, h.bf);
+      head_branch_bwd(s2, C, t, l, valid, true, ca2, cb2, kce, gscale, dz2 + base, h.HW, has_gy, gy, h.omb);
     } else {
-      head_branch_bwd(s1, C, 0, l, valid, nullptr, nullptr, kce, gscale, dz1 + base, h.HW, dy_mix ? gy : nullptr, 1.f);
+      head_branch_bwd(s1, C, 0, l, valid, false, ca1, cb1, kce, gscale, dz1 + base, h.HW, has_gy, gy, 1.f);
     }
   }
 }

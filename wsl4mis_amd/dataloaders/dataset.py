@@ -80,7 +80,10 @@ class BaseDataSets(Dataset):
         if self.split == "train" and self.transform is not None:
             sample = self.transform(sample)
         sample["idx"] = case.split("_")[0]
-        sample["case"] = case                                  # the file name: what BatchRandomGenerator(device_cache=True) keys on
+        sample["case"] = case                                  # the file name ...
+        # ... and WHICH dataset it came from: what BatchRandomGenerator(device_cache=True) keys on.  Two datasets that share file names
+        # but not content (another sup_type, fold or root) must not alias in one generator's device cache.
+        sample["source"] = (os.path.abspath(self._base_dir), self.split, self.sup_type if self.split == "train" else "label")
         return sample
 
 
@@ -154,7 +157,8 @@ class BatchRandomGenerator(object):
 
     def __init__(self, output_size, device_cache=False, max_cached=16384):
         """device_cache: keep each distinct source slice on the device after its first use, so a step stages nothing over PCIe.
-        Keyed by the sample's 'case' (the file name BaseDataSets puts into every sample); samples without one are keyed by the
+        Keyed by the sample's ('source', 'case') (dataset identity -- root, split, label kind -- and file name, which BaseDataSets puts
+        into every sample); samples without a 'case' are keyed by the
         identity of their arrays, which only a caching dataset keeps stable -- a source that hands out fresh arrays on every
         access would grow the cache without bound, so more than `max_cached` entries raise instead."""
         self.output_size = output_size
@@ -163,7 +167,7 @@ class BatchRandomGenerator(object):
 
     def _staged(self, s):
         case = s.get("case") if isinstance(s, dict) else None
-        key = ("case", case) if case is not None else (id(s["image"]), id(s["label"]))
+        key = ("case", s.get("source"), case) if case is not None else (id(s["image"]), id(s["label"]))
         hit = self._dev.get(key)
         if hit is None:
             if len(self._dev) >= self._max:

@@ -411,7 +411,9 @@ class UpBlock(nn.Module):
     def forward(self, x1, x2):
         if self.training and torch.is_grad_enabled():
             return _UpFn.apply(self, x1, x2, *[p for p, _, _, _ in self._plist])
-        if torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad or any(p.requires_grad for p, _, _, _ in self._plist)):
-            raise NotImplementedError("UpBlock: gradients in eval mode are not built (the backward kernels replay the training-mode "
-                                      "BatchNorm); call .train() or wrap the forward in torch.no_grad()")
+        # eval (or no-grad) forward: same convention as UNet / UNet_CCT.forward -- a gradient with respect to an INPUT is refused,
+        # otherwise the result comes back without a graph (gradients in eval mode are not built: the backward kernels replay the
+        # training-mode BatchNorm); wrap evaluation in torch.no_grad() as the reference's val_2D.py does
+        if torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad):
+            raise NotImplementedError("UpBlock: gradients in eval mode are not built; call .train() or wrap the forward in torch.no_grad()")
         return self._run_forward(x1, x2)
