@@ -282,6 +282,19 @@ int wsl_gatedcrf_fwd(const float* y, const float* img, float* msg, float* loss, 
                      float sigma_xy, float sigma_rgb, float weight, void* ws, size_t ws_bytes, void* stream);
 int wsl_gatedcrf_bwd(const float* msg, const float* gout, float gscale, float* dy, int N, int C, int H, int W,
                      void* stream);
+/* The single-branch regulariser compositions in ONE call: partial CE + reg_weight * R(softmax(z))
+ * [+ cons_weight * mean((softmax(z) - softmax(zt))^2)], R = tv_loss(softmax[1:]) | MumfordShah_Loss(image, softmax) | entropy_loss(softmax, C)
+ * (ref: train_weakly_supervised_pCE_TV_2D.py:108-114, ..._pCE_MumfordShah_Loss_2D.py:97-107, ..._pCE_Entropy_Mini_2D.py:99-102,
+ * train_mean_teacher_2D.py:147-171).  The head's first pass keeps softmax(z) in `s`, the regulariser kernels turn it into the weighted
+ * gradient `ds`, the head's second pass writes dz = w_ce * dCE/dz + softmax_backward(s, ds) once: instead of the chain
+ * head -> softmax -> R -> softmax-backward -> axpy (-> softmax-MSE -> axpy) three to five launches and as many passes over [N,C,H,W] fewer.
+ * out[0..3] as wsl_head_fwd_bwd (single branch), out[4] = R (unweighted), out[5] = the consistency term (unweighted; only with zt). */
+#define WSL_REG_TV 1
+#define WSL_REG_MS 2
+#define WSL_REG_ENTROPY 3
+int wsl_head_reg_fwd_bwd(const float* z, const uint8_t* label, int ignore, float w_ce, int reg_kind, float reg_weight,
+                         const float* img, const float* zt, float cons_weight, float* out, float* dz, float* s, float* ds, int N,
+                         int C, int H, int W, void* ws, size_t ws_bytes, void* stream);
 /* tv_loss(p) (ref: train_weakly_supervised_pCE_TV_2D.py:58-65) on p[n0:] (n0 = 1 reproduces outputs_soft[1:]). */
 int wsl_tv_fwd_bwd(const float* p, int n0, float* loss, float* dp, float gscale, int N, int C, int H, int W, void* ws,
                    size_t ws_bytes, void* stream);

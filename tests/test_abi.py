@@ -76,3 +76,39 @@ def test_no_packed_f32_forms_unsafe_next_to_f16_mfma():
     total, bad = scan_vop3p.scan(LIB)
     assert total > 1000, total                                   # the scan sees the device code
     assert not bad, f"{len(bad)} unsafe packed-f32 instructions, e.g. {bad[:3]}"
+
+
+def test_kernels_of_the_step_do_not_spill_beyond_the_known_few():
+    """scratch (private segment) per kernel, read from the code objects' metadata.  Round 4 removed the
+    scratch of the loss head (address-taken per-class arrays) and of the narrow-K convolution (register cap 3 -> 2: classifier data
+    gradient 134 -> 97 us).  What is left is listed here with its size, so that a change that makes a hot kernel spill fails:
+    a handful of registers in kernels that sit exactly at a register cap which was MEASURED faster with the cap (conv_sp 16-channel
+    blocks: 3 workgroups per CU; the 128-tile Winograd form: 256 registers), and the generic fallbacks no step of the networks launches."""
+    import subprocess
+    import sys
+    import tempfile
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scan_vop3p
+    if not os.path.exists(scan_vop3p.OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    readelf = os.path.join(os.path.dirname(scan_vop3p.OBJDUMP), "llvm-readelf")
+    allowed = {   # kernel-name fragment -> bytes of scratch tolerated
+        "conv_sp_kernelILi8ELi32ELi16ELb1": 16, "conv_sp_kernelILi8ELi32ELi16ELb0": 24, "conv_sp_kernelILi8ELi32ELi64ELb0": 32,
+        "conv_wino2_kernelILi8ELi64ELi1": 16, "conv_wino2r_kernelILi8ELi64ELi1": 16,
+        "conv_mfma2_kernel": 64,            # generic direct fallback (odd shapes in tests; not launched by a 16-aligned network)
+        "head_reduce_kernelILi0": 176,      # generic class count (C != 4): per-class arrays indexed at run time
+    }
+    bad = []
+    with tempfile.TemporaryDirectory() as work:
+        for co in scan_vop3p.code_objects(LIB, work):
+            notes = subprocess.run([readelf, "--notes", co], check=True, capture_output=True, text=True).stdout
+            for blk in notes.split("- .agpr_count")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+                scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+                if scratch == 0:
+                    continue
+                lim = max([v for k, v in allowed.items() if k in name] or [0])
+                if scratch > lim:
+                    bad.append((name, scratch, lim))
+    assert not bad, bad

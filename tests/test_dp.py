@@ -151,21 +151,22 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from wsl4mis_amd.engine import TrainEngine
 from wsl4mis_amd.synthetic import batch
-outs = []
-for force in (False, True):
-    torch.manual_seed(5)
-    eng = TrainEngine("unet_cct", 1, 4, loss="pce_gatedcrf", force_dp=force)
-    assert eng.dp == force and (eng.comm is not None) == force
-    x, lab = batch(4, 64, 64, 11, torch.device("cuda", 0))
-    random.seed(3)
-    for _ in range(3):
-        eng.step(x, lab, random.random() + 1e-10)
-    outs.append((eng.model.flat_params().clone(), eng.losses()))
+for prec in ("f32", "split_f16x3"):       # both conv precisions take the same route (VERDICT r3 item 8)
+    outs = []
+    for force in (False, True):
+        torch.manual_seed(5)
+        eng = TrainEngine("unet_cct", 1, 4, loss="pce_gatedcrf", force_dp=force, conv_precision=prec)
+        assert eng.dp == force and (eng.comm is not None) == force
+        x, lab = batch(4, 64, 64, 11, torch.device("cuda", 0))
+        random.seed(3)
+        for _ in range(3):
+            eng.step(x, lab, random.random() + 1e-10)
+        outs.append((eng.model.flat_params().clone(), eng.losses()))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1], (prec, outs[0][1], outs[1][1])
 dist.barrier()
 t = torch.ones(1, device="cuda") * 3
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert float(t) == 3.0
-assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1], (outs[0][1], outs[1][1])
 dist.destroy_process_group()
 print("DP_ROUTE_OK")
 """ % (ROOT, free_port())

@@ -263,3 +263,48 @@ def test_fused_head_gatedcrf_equals_the_four_call_composition(be, dual):
     assert rel_err(be.np(b1), be.np(a1)) < 5e-7
     if dual:
         assert rel_err(be.np(b2), be.np(a2)) < 5e-7
+
+
+@pytest.mark.parametrize("kind,teacher", [(1, False), (2, False), (3, False), (1, True)])
+def test_fused_regulariser_head_equals_the_chain_of_calls(be, kind, teacher):
+    """wsl_head_reg_fwd_bwd == wsl_head_fwd_bwd + wsl_softmax_fwd + {tv | mumford_shah | entropy}_fwd_bwd + wsl_softmax_bwd + wsl_axpy
+    (+ wsl_softmax_mse_fwd_bwd + wsl_axpy for the mean-teacher composition) to round-off: same kernels for the regulariser, ONE softmax
+    backward of the summed gradient instead of one per term (ref: train_weakly_supervised_pCE_TV_2D.py:108-114,
+    ..._pCE_MumfordShah_Loss_2D.py:97-107, ..._pCE_Entropy_Mini_2D.py:99-102, train_mean_teacher_2D.py:147-171)."""
+    rng = np.random.default_rng(40 + kind)
+    N, C, H, W = 3, 4, 40, 44
+    w = {1: 1e-2, 2: 1e-6, 3: 0.1}[kind]
+    cw = 0.07
+    z, zt = (rng.standard_normal((N, C, H, W)) * 2).astype(np.float32), (rng.standard_normal((N, C, H, W)) * 2).astype(np.float32)
+    lab = np.full((N, H, W), 4, np.uint8)
+    lab[rng.random((N, H, W)) < 0.1] = rng.integers(0, 4)
+    img = rng.random((N, 1, H, W)).astype(np.float32)
+    d = {k: be.arr(v) for k, v in dict(z=z, zt=zt, lab=lab, img=img).items()}
+    ws, n = lws(be, N, C, H * W)
+    # the chain
+    o1, a, s1, ds1, dzx = be.zeros((8,)), be.zeros(z.shape), be.zeros(z.shape), be.zeros(z.shape), be.zeros(z.shape)
+    be.call("wsl_head_fwd_bwd", be.ptr(d["z"]), None, be.ptr(d["lab"]), 4, 0.0, 0.0, 1.0, be.ptr(o1), None, be.ptr(a), None, N, C, H * W,
+            be.ptr(ws), n, be.stream)
+    be.call("wsl_softmax_fwd", be.ptr(d["z"]), be.ptr(s1), N, C, H * W, be.stream)
+    reg = be.zeros((2,))
+    if kind == 1:
+        be.call("wsl_tv_fwd_bwd", be.ptr(s1), 1, be.ptr(reg), be.ptr(ds1), w, N, C, H, W, be.ptr(ws), n, be.stream)
+    elif kind == 2:
+        be.call("wsl_mumford_shah_fwd_bwd", be.ptr(d["img"]), be.ptr(s1), be.ptr(reg), be.ptr(ds1), w, N, C, H, W, be.ptr(ws), n, be.stream)
+    else:
+        be.call("wsl_entropy_fwd_bwd", be.ptr(s1), be.ptr(reg), be.ptr(ds1), w, N, C, H * W, C, be.ptr(ws), n, be.stream)
+    be.call("wsl_softmax_bwd", be.ptr(s1), be.ptr(ds1), be.ptr(dzx), N, C, H * W, be.stream)
+    be.call("wsl_axpy", be.ptr(a), be.ptr(dzx), 1.0, N * C * H * W, be.stream)
+    cons = be.zeros((1,))
+    if teacher:
+        be.call("wsl_softmax_mse_fwd_bwd", be.ptr(d["z"]), be.ptr(d["zt"]), be.ptr(cons), be.ptr(dzx), cw, N, C, H * W, be.ptr(ws), n, be.stream)
+        be.call("wsl_axpy", be.ptr(a), be.ptr(dzx), 1.0, N * C * H * W, be.stream)
+    # one call
+    o2, b, s2, ds2 = be.zeros((8,)), be.zeros(z.shape), be.zeros(z.shape), be.zeros(z.shape)
+    be.call("wsl_head_reg_fwd_bwd", be.ptr(d["z"]), be.ptr(d["lab"]), 4, 1.0, kind, w, be.ptr(d["img"]), be.ptr(d["zt"]) if teacher else None,
+            cw, be.ptr(o2), be.ptr(b), be.ptr(s2), be.ptr(ds2), N, C, H, W, be.ptr(ws), n, be.stream)
+    assert rel_err(be.np(s2), be.np(s1)) < 5e-7
+    assert rel_err(be.np(o2)[:4], be.np(o1)[:4]) < 1e-6 and abs(be.np(o2)[4] - be.np(reg)[0]) <= 1e-6 * abs(be.np(reg)[0])
+    if teacher:
+        assert abs(be.np(o2)[5] - be.np(cons)[0]) <= 1e-6 * abs(be.np(cons)[0])
+    assert rel_err(be.np(b), be.np(a)) < 2e-6, rel_err(be.np(b), be.np(a))

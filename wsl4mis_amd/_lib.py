@@ -122,6 +122,7 @@ _PROTOS = {
     "wsl_mixprob_bwd": (i32, [c_fp, c_fp, f64, c_fp, f32, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "wsl_gatedcrf_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, f32, f32, c_fp, sz, c_fp]),
     "wsl_gatedcrf_bwd": (i32, [c_fp, c_fp, f32, c_fp, i32, i32, i32, i32, c_fp]),
+    "wsl_head_reg_fwd_bwd": (i32, [c_fp, c_fp, i32, f32, i32, f32, c_fp, c_fp, f32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_tv_fwd_bwd": (i32, [c_fp, i32, c_fp, c_fp, f32, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_mumford_shah_fwd_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, f32, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "wsl_softmax_mse_fwd_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, f32, i32, i32, i32, c_fp, sz, c_fp]),

@@ -828,6 +828,26 @@ __global__ __launch_bounds__(256) void softmax_mse_kernel(const float* a, const 
   write_partials<1>(v, part, red);
 }
 
+// the same term for the FUSED regulariser head (wsl_head_reg_fwd_bwd): the student's softmax `sa` is already in memory and the
+// gradient is wanted with respect to it (the head's backward pass does the ONE softmax backward of all terms): ds += 2 (sa - sb) k
+__global__ __launch_bounds__(256) void softmax_mse_ds_kernel(const float* sa_, const float* b, int C, int HW, int64_t P, float k,
+                                                             float* ds, float* part) {
+  __shared__ float red[4];
+  float v[1] = {0.f};
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < P; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t n = i / HW, p = i - n * HW, base = n * C * HW + p;
+    float sb[kMaxC];
+    softmax_c(b + base, HW, C, sb);
+    for (int c = 0; c < C; ++c) {
+      const int64_t idx = base + (int64_t)c * HW;
+      const float d = sa_[idx] - sb[c];
+      v[0] = fmaf(d, d, v[0]);
+      ds[idx] += 2.f * d * k;
+    }
+  }
+  write_partials<1>(v, part, red);
+}
+
 // ------------------------------------------------------------------------------------------------ entropy minimisation
 // entropy_loss(p, C) = mean_px( -sum_c p log(p + 1e-6) ) / log(C)   (ref: utils/losses.py:30-36; used on softmax(outputs)
 // with weight 0.1 by train_weakly_supervised_pCE_Entropy_Mini_2D.py:99-102).  d/dp_c = -(log(p_c + 1e-6) + p_c/(p_c + 1e-6)) * k.
@@ -1205,6 +1225,61 @@ extern "C" int wsl_head_gatedcrf_fwd_bwd(const float* z1, const float* z2, const
     head_stage2(h, scal, 1.f, dz1, dz2, msg, (float)(-2.0 * (double)crf_weight / ((double)N * HW)), C, nb, stream);
   }
   return check_launch("head_gatedcrf_fwd_bwd");
+}
+
+extern "C" int wsl_head_reg_fwd_bwd(const float* z, const uint8_t* label, int ignore, float w_ce, int reg_kind, float reg_weight,
+                                    const float* img, const float* zt, float cons_weight, float* out, float* dz, float* s, float* ds,
+                                    int N, int C, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+  WSL_REQUIRE(z && label && out && dz && s && ds && N > 0 && H > 0 && W > 0 && C > 0 && C <= kMaxC, "head_reg_fwd_bwd: bad args");
+  WSL_REQUIRE(reg_kind >= WSL_REG_TV && reg_kind <= WSL_REG_ENTROPY, "head_reg_fwd_bwd: reg_kind %d", reg_kind);
+  WSL_REQUIRE(reg_kind != WSL_REG_MS || img, "head_reg_fwd_bwd: Mumford-Shah needs the image");
+  const int HW = H * W, HW_ = HW;
+  WSL_WS_OK("head_reg_fwd_bwd");
+  HeadP h{z, nullptr, label, ignore, C, HW, N, (int64_t)N * HW, 0.f, 1.f};
+  const int nb = grid_for(h.P);
+  float* part = static_cast<float*>(ws);
+  float* scal = part + (size_t)kMaxBlocks * kMaxK;
+  // the regulariser's partial sums: the head's own partials (ws[0 .. kMaxBlocks * kMaxK)) are dead once its finalize kernel ran, but its
+  // coefficients `scal` right behind them (and the Mumford-Shah moments behind those) must survive until the last pass -- small
+  // problems re-use the head's region, large ones (more TV tiles than it holds) the rest of the workspace behind the moments
+  const int chunks = cdiv(HW, 4096);
+  float* mom = scal + 64;
+  const size_t rneed = (size_t)N * C * cdiv(W, 16) * cdiv(H, 16) + (size_t)N * chunks * 2 + kMaxBlocks;
+  float* rpart = rneed <= (size_t)kMaxBlocks * kMaxK ? part : mom + (size_t)N * chunks * (kMaxC + 1);
+  WSL_REQUIRE((size_t)(rpart - part) + rneed <= ws_bytes / sizeof(float), "head_reg_fwd_bwd: workspace too small for the regulariser's partials");
+  {   // pass 1: softmax (kept in s), partial-CE sums -> the head's coefficients
+    ProfScope ps(PF_LOSS_HEAD, 0.0, (double)N * HW * (4.0 * C + 1.0 + 4.0 * C), stream);
+    head_stage1(h, nullptr, s, 0.f, out, C, N, 0, part, scal, nb, stream);
+  }
+  {   // regulariser on s: value -> out[4], weighted gradient -> ds
+    ProfScope ps(PF_LOSS_HEAD, 0.0, (double)N * HW * 8.0 * C, stream);
+    if (reg_kind == WSL_REG_TV) {
+      WSL_REQUIRE(N > 1, "head_reg_fwd_bwd: tv_loss(outputs_soft[1:]) needs a batch of at least two");
+      const double numel = (double)(N - 1) * C * H * W;
+      TvP q{s, ds, 1, N, C, H, W, cdiv(W, 16), cdiv(H, 16), (float)(reg_weight / numel)};
+      const int nt = N * C * q.tiles_x * q.tiles_y;
+      WSL_LAUNCH(tv_fwd_bwd_kernel, dim3(nt), dim3(kThreads), 0, stream, q, rpart);
+      WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, rpart, nt, 1, 1.0 / numel, out + 4);
+    } else if (reg_kind == WSL_REG_MS) {
+      WSL_LAUNCH(ms_moment_kernel, dim3(chunks, N), dim3(kThreads), 0, stream, img, s, C, HW, chunks, mom);
+      WSL_LAUNCH(ms_main_kernel, dim3(chunks, N), dim3(kThreads), 0, stream, img, s, mom, C, H, W, chunks, reg_weight, ds, rpart);
+      WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, rpart, N * chunks, 2, 1.0, out + 4);
+    } else {
+      const double norm = 1.0 / ((double)h.P * log((double)C));
+      WSL_LAUNCH(entropy_kernel, dim3(nb), dim3(kThreads), 0, stream, s, C, HW, h.P, (float)(reg_weight * norm), ds, rpart);
+      WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, rpart, nb, 1, norm, out + 4);
+    }
+    if (zt) {   // consistency with a teacher's logits: mean((softmax(z) - softmax(zt))^2), gradient added to ds
+      const double numel = (double)N * C * HW;
+      WSL_LAUNCH(softmax_mse_ds_kernel, dim3(nb), dim3(kThreads), 0, stream, s, zt, C, HW, h.P, (float)(cons_weight / numel), ds, rpart);
+      WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, rpart, nb, 1, 1.0 / numel, out + 5);
+    }
+  }
+  {   // pass 2: dz = w_ce * dCE/dz + softmax_backward(s, ds) -- written once
+    ProfScope ps(PF_LOSS_HEAD, 0.0, (double)N * HW * (4.0 * C + 1.0 + 4.0 * C + 4.0 * C), stream);
+    head_stage2(h, scal, w_ce, dz, nullptr, ds, 1.f, C, nb, stream);
+  }
+  return check_launch("head_reg_fwd_bwd");
 }
 
 extern "C" int wsl_tv_fwd_bwd(const float* p, int n0, float* loss, float* dp, float gscale, int N, int C, int H, int W,

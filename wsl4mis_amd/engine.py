@@ -35,6 +35,7 @@ from .networks.net_factory import net_factory
 class TrainEngine:
     # pCE + weight * regulariser(softmax(outputs)) of the single-branch scripts: (weight, reference lines)
     REGULARISED = ("pce_tv", "pce_ms", "pce_entropy", "ce_dice")
+    FUSED_REG = {"pce_tv": 1, "pce_ms": 2, "pce_entropy": 3}     # WSL_REG_* of wsl_head_reg_fwd_bwd (include/wsl_hip.h)
     REG_WEIGHT = {"pce_tv": 1e-2,        # train_weakly_supervised_pCE_TV_2D.py:113-114 (tv_loss on outputs_soft[1:])
                   "pce_ms": 1e-6,        # ..._pCE_MumfordShah_Loss_2D.py:102-103 (MumfordShah_Loss(image, softmax))
                   "pce_entropy": 0.1,    # ..._pCE_Entropy_Mini_2D.py:99-102 (entropy_loss(softmax, C=4))
@@ -76,6 +77,7 @@ class TrainEngine:
         self._diag = None                                  # comm_diag(True): [(event, event)] around the waits for the comm stream
         self.teacher = None
         self._tstream, self._zt = None, None
+        self.fused_heads = True                            # regulariser / mean-teacher loss heads through wsl_head_reg_fwd_bwd (False: the chain of calls)
         self.concurrent = True                             # teacher forward on a side stream; set False to serialise
         if loss in ("mean_teacher", "ustm"):
             if self.dual:
@@ -166,6 +168,12 @@ class TrainEngine:
         nl = rt.L().wsl_loss_ws_bytes(N, C_, HW)
         lws = rt.workspace("loss", nl)
         lo, w = self.loss_out, self.REG_WEIGHT[self.loss_kind]
+        if self.loss_kind in self.FUSED_REG and self.fused_heads:
+            # one call: the head's first pass keeps softmax(z), the regulariser turns it into its weighted gradient, the head's second
+            # pass writes dz once (wsl_head_reg_fwd_bwd; the chain below is kept for ce_dice and as the reference of the fused form)
+            rt.call("wsl_head_reg_fwd_bwd", rt.ptr(z), rt.ptr(label_u8), self.ignore, 1.0, self.FUSED_REG[self.loss_kind], w, rt.ptr(x),
+                    None, 0.0, rt.ptr(lo), rt.ptr(t["dz1"]), rt.ptr(t["s"]), rt.ptr(t["ds"]), N, C_, H, W, rt.ptr(lws), nl, rt.stream())
+            return
         w_ce = 0.5 if self.loss_kind == "ce_dice" else 1.0
         rt.call("wsl_head_fwd_bwd", rt.ptr(z), None, rt.ptr(label_u8), self.ignore, 0.0, 0.0, w_ce, rt.ptr(lo), None,
                 rt.ptr(t["dz1"]), None, N, C_, HW, rt.ptr(lws), nl, rt.stream())
@@ -230,6 +238,12 @@ class TrainEngine:
         nl = rt.L().wsl_loss_ws_bytes(N, C_, HW)
         lws = rt.workspace("loss", nl)
         lo = self.loss_out
+        from .utils.ramps import sigmoid_rampup
+        self._cons_w = self.cons_max * sigmoid_rampup(self.it // 300, 200.0)
+        if self.fused_heads:      # pCE + tv_weight * TV(softmax[1:]) + w(t) * softmax-MSE(student, teacher): one call, dz written once
+            rt.call("wsl_head_reg_fwd_bwd", rt.ptr(z), rt.ptr(label_u8), self.ignore, 1.0, 1, self.tv_weight, None, rt.ptr(zt),
+                    self._cons_w, rt.ptr(lo), rt.ptr(t["dz1"]), rt.ptr(t["s"]), rt.ptr(t["ds"]), N, C_, H, W, rt.ptr(lws), nl, rt.stream())
+            return
         rt.call("wsl_head_fwd_bwd", rt.ptr(z), None, rt.ptr(label_u8), self.ignore, 0.0, 0.0, 1.0, rt.ptr(lo), None,
                 rt.ptr(t["dz1"]), None, N, C_, HW, rt.ptr(lws), nl, rt.stream())
         rt.call("wsl_softmax_fwd", rt.ptr(z), rt.ptr(t["s"]), N, C_, HW, rt.stream())
@@ -237,8 +251,6 @@ class TrainEngine:
                 nl, rt.stream())
         rt.call("wsl_softmax_bwd", rt.ptr(t["s"]), rt.ptr(t["ds"]), rt.ptr(t["dzx"]), N, C_, HW, rt.stream())
         rt.call("wsl_axpy", rt.ptr(t["dz1"]), rt.ptr(t["dzx"]), 1.0, N * C_ * HW, rt.stream())
-        from .utils.ramps import sigmoid_rampup
-        self._cons_w = self.cons_max * sigmoid_rampup(self.it // 300, 200.0)
         rt.call("wsl_softmax_mse_fwd_bwd", rt.ptr(z), rt.ptr(zt), rt.ptr(lo[5:]), rt.ptr(t["dzx"]), self._cons_w, N, C_, HW,
                 rt.ptr(lws), nl, rt.stream())
         rt.call("wsl_axpy", rt.ptr(t["dz1"]), rt.ptr(t["dzx"]), 1.0, N * C_ * HW, rt.stream())
