@@ -214,6 +214,18 @@ size_t wsl_sp_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
 int wsl_sp_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, const uint32_t* dy_amax,
                                 float* dw, float* db, int N, int H, int W, int Co, void* ws, size_t ws_bytes,
                                 WslWgradPending* pending, void* stream);
+/* Raw (scale == NULL) FORWARD sources -- the upsampled tensor of a decoder block (ref: networks/unet.py:63-68: x1 = up(conv1x1(x1)),
+ * cat([x2, x1])) -- are not BatchNorm-normalised, so the static activation scale could saturate them silently.  Their maximum
+ * is tracked: wsl_bilinear_up2_fwd_amax leaves max |u| (>= max of the bilinear output: a convex combination) in amax_slots
+ * [WSL_SP_AMAX_SLOTS]; wsl_sp_conv2d_fwd takes it as `in_amax` (with a BatchNorm source present the operand scale is then
+ * min(2^WSL_SP_ACT_EXP, the scale of that maximum): unchanged results unless the raw source really exceeds the static range) and
+ * wsl_sp_conv2d_wgrad_partial_amax as `in_amax`.  ws: wsl_bilinear_up2_fwd_amax_ws_bytes (partial maxima); amax_slots NULL = the plain call. */
+size_t wsl_bilinear_up2_fwd_amax_ws_bytes(int N, int C, int h, int w);
+int wsl_bilinear_up2_fwd_amax(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* ws, size_t ws_bytes,
+                              uint32_t* amax_slots, void* stream);
+int wsl_sp_conv2d_wgrad_partial_amax(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, const uint32_t* dy_amax,
+                                     const uint32_t* in_amax, float* dw, float* db, int N, int H, int W, int Co, void* ws,
+                                     size_t ws_bytes, WslWgradPending* pending, void* stream);
 /* wsl_bnact_bwd / wsl_bnact_bwd_finish that also leave max |dy| in dy_amax[0 .. WSL_SP_AMAX_SLOTS) (NULL = the plain calls; every
  * slot is written, none needs clearing).  Workspace of the finish form: wsl_bnact_bwd_finish_ws_bytes(..., dy_amax != NULL). */
 size_t wsl_bnact_bwd_finish_ws_bytes(int N, int C, int H, int W, int with_amax);

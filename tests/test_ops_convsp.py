@@ -142,6 +142,61 @@ def test_sp_conv_fwd_dgrad_wgrad(be, case):
     assert close(be.np(db), bt.grad.numpy(), TOL)
 
 
+def test_sp_raw_source_beyond_the_static_range(be):
+    """the second source of a decoder block's first convolution is the RAW upsampled tensor (networks/unet.py:63-68) -- not
+    BatchNorm-normalised, so nothing bounds it by the static activation scale 2^4 (|v| < 4094).  Its maximum is tracked by the
+    upsampling pass (wsl_bilinear_up2_fwd_amax: max |u| bounds the bilinear output) and handed to the forward conv and the weight
+    gradient as `in_amax`: results stay at the 1e-4 criterion for values far beyond 4094, and are bit-identical to the untracked call
+    when the source is small."""
+    import ctypes as C
+    from wsl4mis_amd import _lib
+    rng = np.random.default_rng(77)
+    N, H, W, Ca, Cb, Co = 2, 8, 32, 16, 16, 32
+    for big in (False, True):
+        h, w_ = H // 2, W // 2
+        u = (rng.standard_normal((N, Cb, h, w_)) * (3.0e4 if big else 2.0)).astype(np.float32)       # the 1x1-conv output that is upsampled
+        xa = rng.standard_normal((N, Ca, H, W)).astype(np.float32)
+        scale, shift = (rng.standard_normal(Ca) * 0.5 + 1).astype(np.float32), (rng.standard_normal(Ca) * 0.3).astype(np.float32)
+        wgt = (rng.standard_normal((Co, Ca + Cb, 3, 3)) * 0.07).astype(np.float32)
+        r = (rng.standard_normal((N, Co, H, W)) * 3e-5).astype(np.float32)
+        d = {k: be.arr(v) for k, v in dict(u=u, xa=xa, scale=scale, shift=shift, w=wgt, r=r).items()}
+        up, slots = be.zeros((N, Cb, H, W)), be.arr(np.zeros(32, np.int64))
+        nws = be.lib.wsl_bilinear_up2_fwd_amax_ws_bytes(N, Cb, h, w_)
+        ws = be.ws(nws)
+        be.call("wsl_bilinear_up2_fwd_amax", be.ptr(d["u"]), be.ptr(up), Cb * H * W, N, Cb, h, w_, be.ptr(ws), nws, be.ptr(slots), be.stream)
+        up_np = be.np(up)
+        ref_up = F.interpolate(torch.from_numpy(u), scale_factor=2, mode="bilinear", align_corners=True).numpy()
+        assert close(up_np, ref_up, 1e-5)
+        tracked = be.np(slots).view(np.uint32).view(np.float32).max()
+        assert tracked == np.abs(u).max() and tracked >= np.abs(up_np).max()
+        va = virt_input(xa, scale, shift, None, 1.0, None)
+        vin = torch.cat([va, torch.from_numpy(up_np)], 1).requires_grad_()
+        wt = torch.from_numpy(wgt).requires_grad_()
+        y_ref = F.conv2d(vin, wt, None, padding=1)
+        (y_ref * torch.from_numpy(r)).sum().backward()
+        sa, sb = be.src(d["xa"], Ca, scale=d["scale"], shift=d["shift"]), be.src(up, Cb)
+        img, wmax = be.ws(be.lib.wsl_sp_weight_image_bytes(Co, Ca + Cb)), _amax_bits(be)
+        be.call("wsl_sp_pack_weights", be.ptr(d["w"]), be.ptr(img), be.ptr(wmax), Co, Ca + Cb, 0, be.stream)
+        ys = []
+        for amax in (be.ptr(slots), None):
+            y = be.zeros((N, Co, H, W))
+            be.call("wsl_sp_conv2d_fwd", sa, sb, be.ptr(img), be.ptr(wmax), amax, None, be.ptr(y), Co * H * W, N, H, W, Co, None, None, be.stream)
+            ys.append(be.np(y).copy())
+        assert close(ys[0], y_ref.detach().numpy(), TOL), rel_err(ys[0], y_ref.detach().numpy())
+        if big:
+            assert not close(ys[1], y_ref.detach().numpy(), TOL)          # the untracked call saturates: what the tracking is for
+        else:
+            assert np.array_equal(ys[0], ys[1])                            # inside the static range nothing changes
+        rmax = _set_amax(be, None, np.abs(r).max())
+        nwg = be.lib.wsl_sp_conv2d_wgrad_ws_bytes(N, H, W, Ca + Cb, Co)
+        wsg, dw, db = be.ws(nwg), be.zeros((Co, Ca + Cb, 3, 3)), be.zeros((Co,))
+        pend = _lib.WslWgradPending()
+        be.call("wsl_sp_conv2d_wgrad_partial_amax", sa, sb, be.ptr(d["r"]), Co * H * W, be.ptr(rmax), be.ptr(slots), be.ptr(dw), be.ptr(db),
+                N, H, W, Co, be.ptr(wsg), nwg, C.byref(pend), be.stream)
+        be.call("wsl_wgrad_reduce_batch", C.byref(pend), 1, be.stream)
+        assert close(be.np(dw), wt.grad.numpy(), TOL), rel_err(be.np(dw), wt.grad.numpy())
+
+
 def test_sp_not_eligible(be):
     x = be.zeros((1, 8, 8, 32))
     s = be.src(x, 8)

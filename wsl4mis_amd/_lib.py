@@ -102,6 +102,10 @@ _PROTOS = {
     "wsl_sp_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "wsl_sp_conv2d_wgrad_partial": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, sz,
                                           C.POINTER(WslWgradPending), c_fp]),
+    "wsl_sp_conv2d_wgrad_partial_amax": (i32, [PS, PS, c_fp, i64, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, sz,
+                                               C.POINTER(WslWgradPending), c_fp]),
+    "wsl_bilinear_up2_fwd_amax_ws_bytes": (sz, [i32, i32, i32, i32]),
+    "wsl_bilinear_up2_fwd_amax": (i32, [c_fp, c_fp, i64, i32, i32, i32, i32, c_fp, sz, c_fp, c_fp]),
     "wsl_bnact_bwd_finish_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "wsl_bnact_bwd_amax": (i32, [c_fp, i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32,
                                  c_fp, sz, c_fp, c_fp]),

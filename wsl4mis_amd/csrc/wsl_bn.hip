@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwdc_kernel(const float* u, 
 // output quad instead of four 4-byte ones, sources read from LDS.  Same expressions as the kernels above.
 constexpr int kUpFR = 32;                    // output rows per workgroup
 __global__ __launch_bounds__(256) void bilinear_up2_fwd4_kernel(const float* u, float* out, int64_t out_bs, int C, int h, int w,
-                                                                int lq) {
+                                                                int lq, uint32_t* pmax) {
   __shared__ __attribute__((aligned(16))) float st[(kUpFR / 2 + 3) * 128];
   const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
   const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
@@ -590,9 +590,12 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd4_kernel(const float* u, 
   lerp_coord(oy0, sy, h, &ya, &dummy, &fdummy);          // first source row of the block
   lerp_coord(oy1 - 1, sy, h, &dummy, &yb, &fdummy);      // last one
   const int nrows = yb - ya + 1, w4 = w >> 2;
+  float vmax = 0.f;   // max |source| of the rows this workgroup stages: bounds its outputs (bilinear weights are a convex combination)
   for (int e = threadIdx.x; e < nrows * w4; e += kThreads) {
     const int r = e / w4, q = e - r * w4;
-    *reinterpret_cast<float4*>(st + r * w + 4 * q) = *reinterpret_cast<const float4*>(src + (int64_t)(ya + r) * w + 4 * q);
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)(ya + r) * w + 4 * q);
+    *reinterpret_cast<float4*>(st + r * w + 4 * q) = v;
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   const int quads = Wo >> 2;                              // 2^lq column quads per output row
   const int cq = threadIdx.x & (quads - 1), rl = threadIdx.x >> lq, rstep = kThreads >> lq;
@@ -615,6 +618,23 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd4_kernel(const float* u, 
       o[j] = (1.f - ly) * top + ly * bot;
     }
     *reinterpret_cast<float4*>(dst + (int64_t)oy * Wo + 4 * cq) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (pmax) amax_block_store(vmax, pmax);   // (kernel argument: uniform)
+}
+
+// max |x| of a plain tensor into WSL_SP_AMAX_SLOTS slots (cleared by the caller): the fallback producer of a raw source's maximum
+__global__ __launch_bounds__(256) void amax_tensor_kernel(const float* x, int64_t n4, uint32_t* slots) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kThreads) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+  if ((threadIdx.x & 63) == 0) {
+    uint32_t u;
+    memcpy(&u, &m, 4);
+    atomicMax(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (WSL_SP_AMAX_SLOTS - 1)), u);   // integer max: order-independent
   }
 }
 
@@ -854,14 +874,30 @@ extern "C" int wsl_feat_grad_combine_bn(const WslSrc* f, const float* ga, int64_
   return check_launch("feat_grad_combine_bn_kernel");
 }
 
-extern "C" int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream) {
+extern "C" size_t wsl_bilinear_up2_fwd_amax_ws_bytes(int N, int C, int h, int w) {
+  return N > 0 && C > 0 && h > 0 && w > 0 ? sizeof(uint32_t) * (size_t)N * C * cdiv(2 * h, kUpFR) : 0;
+}
+
+extern "C" int wsl_bilinear_up2_fwd_amax(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* ws, size_t ws_bytes,
+                                         uint32_t* amax_slots, void* stream) {
   WSL_REQUIRE(u && out && N > 0 && C > 0 && h > 0 && w > 0, "bilinear_up2_fwd: bad args");
   WSL_REQUIRE(out_bs >= (int64_t)C * 4 * h * w, "bilinear_up2_fwd: out batch stride too small");
+  WSL_REQUIRE(!amax_slots || (ws && ws_bytes >= wsl_bilinear_up2_fwd_amax_ws_bytes(N, C, h, w)), "bilinear_up2_fwd_amax: workspace too small");
   ProfScope ps(PF_BILINEAR, 0.0, 20.0 * (double)N * C * h * w, stream);            // read 4 B per input, write 4 x 4 B
   if (up2_fast_ok(out, out_bs, w) && (reinterpret_cast<uintptr_t>(u) & 15) == 0) {
-    WSL_LAUNCH(bilinear_up2_fwd4_kernel, dim3(cdiv(2 * h, kUpFR), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C, h, w,
-               ilog2(2 * w) - 2);
+    const dim3 grid(cdiv(2 * h, kUpFR), C, N);
+    uint32_t* pmax = amax_slots ? static_cast<uint32_t*>(ws) : nullptr;
+    WSL_LAUNCH(bilinear_up2_fwd4_kernel, grid, dim3(kThreads), 0, stream, u, out, out_bs, C, h, w, ilog2(2 * w) - 2, pmax);
+    if (amax_slots) WSL_LAUNCH(amax_fold_kernel, dim3(WSL_SP_AMAX_SLOTS), dim3(kThreads), 0, stream, pmax, (int)(grid.x * grid.y * grid.z), amax_slots);
     return check_launch("bilinear_up2_fwd4_kernel");
+  }
+  if (amax_slots) {   // the other forms do not carry the maximum: one pass over the (4x smaller) source
+    WSL_REQUIRE(((int64_t)N * C * h * w) % 4 == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0, "bilinear_up2_fwd_amax: source not float4-aligned");
+    if (hipMemsetAsync(amax_slots, 0, WSL_SP_AMAX_SLOTS * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
+      set_error("bilinear_up2_fwd_amax: clearing the slots failed");
+      return WSL_EHIP;
+    }
+    WSL_LAUNCH(amax_tensor_kernel, dim3(256), dim3(kThreads), 0, stream, u, (int64_t)N * C * h * w / 4, amax_slots);
   }
   if (up2_fast_ok(out, out_bs, w)) {
     const int lw = ilog2(2 * w);                                    // output row width = 2^lw <= 256
@@ -874,6 +910,10 @@ extern "C" int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, 
   WSL_LAUNCH(bilinear_up2_fwd_kernel, dim3(cdiv(4 * h * w, kChunk), C, N), dim3(kThreads), 0, stream, u, out, out_bs, C,
              h, w);
   return check_launch("bilinear_up2_fwd_kernel");
+}
+
+extern "C" int wsl_bilinear_up2_fwd(const float* u, float* out, int64_t out_bs, int N, int C, int h, int w, void* stream) {
+  return wsl_bilinear_up2_fwd_amax(u, out, out_bs, N, C, h, w, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int wsl_bilinear_up2_bwd(const float* dout, int64_t dout_bs, float* du, int N, int C, int h, int w,

@@ -309,7 +309,15 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
   const int co0 = blockIdx.y * CO_T;
   const int nb = p.ntiles;
 
-  const int e_w = sp_exp_of(*p.w_amax), e_in = p.in_amax ? sp_exp_of(sp_amax_fold(p.in_amax)) : WSL_SP_ACT_EXP;
+  // operand scale of the input: a plain source (a gradient: data-gradient launches) takes it from the tensor's tracked maximum; BatchNorm
+  // sources the static 2^WSL_SP_ACT_EXP (normalised values stay far below 4094).  Both at once -- the decoder blocks' first convolution:
+  // BatchNorm-ed skip + the raw upsampled tensor, whose maximum is tracked -- share ONE scale (one accumulator): the smaller
+  int e_in = WSL_SP_ACT_EXP;
+  if (p.in_amax) {
+    const int e_t = sp_exp_of(sp_amax_fold(p.in_amax));
+    e_in = (p.a.scale || p.b.scale) ? (e_t < WSL_SP_ACT_EXP ? e_t : WSL_SP_ACT_EXP) : e_t;
+  }
+  const int e_w = sp_exp_of(*p.w_amax);
   const float in_mul = sp_pow2(e_in);
   const float u1 = sp_pow2(-e_w), u2 = sp_pow2(-e_in);
 
@@ -629,6 +637,7 @@ struct WgradSpP {
   const float* dy;
   int64_t dy_bs;
   const uint32_t* dy_amax;
+  const uint32_t* in_amax;   // tracked maximum of a raw input source (null: static activation scale)
   float* part_dw;   // [splits][9][Co][Ci]
   float* part_db;   // [splits][Co]
   int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, ci_blocks;
@@ -667,7 +676,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
   const SpSrc& src = ina ? p.a : p.b;
   const int chb = ina ? ci0 : ci0 - p.a.C;
   const int e_dy = sp_exp_of(sp_amax_fold(p.dy_amax));
-  const float dy_mul = sp_pow2(e_dy), act_mul = sp_pow2(WSL_SP_ACT_EXP);
+  int e_act = WSL_SP_ACT_EXP;   // (the conv kernel's rule: one scale for both sources, lowered when a raw source's maximum asks for it)
+  if (p.in_amax) {
+    const int e_t = sp_exp_of(sp_amax_fold(p.in_amax));
+    e_act = e_t < WSL_SP_ACT_EXP ? e_t : WSL_SP_ACT_EXP;
+  }
+  const float dy_mul = sp_pow2(e_dy), act_mul = sp_pow2(e_act);
 
   // operand addresses of K-step 0: supplier lane s = lane & 15 of a 16-lane group hands out pixel (s >> 2) (+ 4 for the second
   // read) of the group's eight, channels 4 (s & 3) .. + 3 of the 16-channel tile
@@ -785,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
   }
 
   // ---- partials: D[row = co][col = ci]; lane holds rows 4 (lane >> 4) + r of column lane & 15
-  const float u1 = sp_pow2(-e_dy), u2 = sp_pow2(-WSL_SP_ACT_EXP);
+  const float u1 = sp_pow2(-e_dy), u2 = sp_pow2(-e_act);
   const int sidx = CB == 32 ? split : split * 4 + wave;
   const int64_t E = (int64_t)9 * Co * Ci;
   float* pdw = p.part_dw + (int64_t)sidx * E;
@@ -887,7 +901,8 @@ extern "C" int wsl_sp_conv2d_fwd(const WslSrc* a, const WslSrc* b, const void* i
   WSL_REQUIRE((stat_part == nullptr) == (stat_cnt == nullptr), "sp_conv2d_fwd: stat_part and stat_cnt come together");
   WSL_REQUIRE(y_bs >= (int64_t)Co * H * W, "sp_conv2d_fwd: y batch stride too small");
   WSL_REQUIRE(wsl_sp_conv2d_ok(a, b, y, y_bs, N, H, W, Co, 3), "sp_conv2d_fwd: layer not eligible (wsl_sp_conv2d_ok)");
-  return sp_conv_launch(*a, b, image, w_amax, in_amax, bias, y, y_bs, N, H, W, Co, in_amax != nullptr, stat_part, stat_cnt, nullptr,
+  const int is_dgrad = in_amax != nullptr && !a->scale && !(b && b->C > 0);   // (profiling family only: a plain single source = a gradient)
+  return sp_conv_launch(*a, b, image, w_amax, in_amax, bias, y, y_bs, N, H, W, Co, is_dgrad, stat_part, stat_cnt, nullptr,
                         nullptr, stream);
 }
 
@@ -916,6 +931,12 @@ extern "C" size_t wsl_sp_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int 
 extern "C" int wsl_sp_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, const uint32_t* dy_amax,
                                            float* dw, float* db, int N, int H, int W, int Co, void* ws, size_t ws_bytes,
                                            WslWgradPending* pending, void* stream) {
+  return wsl_sp_conv2d_wgrad_partial_amax(a, b, dy, dy_bs, dy_amax, nullptr, dw, db, N, H, W, Co, ws, ws_bytes, pending, stream);
+}
+
+extern "C" int wsl_sp_conv2d_wgrad_partial_amax(const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, const uint32_t* dy_amax,
+                                                const uint32_t* in_amax, float* dw, float* db, int N, int H, int W, int Co, void* ws,
+                                                size_t ws_bytes, WslWgradPending* pending, void* stream) {
   WSL_REQUIRE(a && dy && dy_amax && dw && ws && pending, "sp_conv2d_wgrad_partial: null argument");
   WSL_REQUIRE(wsl_sp_conv2d_ok(a, b, nullptr, 0, N, H, W, Co, 3) && aligned16(dy) && !(dy_bs & 3) && dy_bs >= (int64_t)Co * H * W,
               "sp_conv2d_wgrad_partial: layer not eligible (wsl_sp_conv2d_ok, float4-aligned dy)");
@@ -930,7 +951,7 @@ extern "C" int wsl_sp_conv2d_wgrad_partial(const WslSrc* a, const WslSrc* b, con
   WgradSpP p;
   p.a = to_spsrc(*a);
   p.b = Cb ? to_spsrc(*b) : SpSrc{};
-  p.dy = dy, p.dy_bs = dy_bs, p.dy_amax = dy_amax;
+  p.dy = dy, p.dy_bs = dy_bs, p.dy_amax = dy_amax, p.in_amax = in_amax;
   p.part_dw = static_cast<float*>(ws);
   p.part_db = db ? p.part_dw + (size_t)g.splits * 9 * Co * Ci : nullptr;
   p.N = N, p.H = H, p.W = W, p.Ci = Ci, p.Co = Co;

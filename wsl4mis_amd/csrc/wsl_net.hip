@@ -42,7 +42,7 @@ struct Plan {
   size_t winof, winod;   // Winograd filter images [16][Ci][Co] of the 3x3 layers, at twice the raw weight's offset
   // split-precision path (d.precision == 1): f16 hi / lo weight images (10 floats per 9 raw weights: sp_img_off()), one max |w|
   // slot per conv layer (pack-table order) and one max |dy| slot per BatchNorm layer
-  size_t spf, spd, sp_wmax, sp_dymax;
+  size_t spf, spd, sp_wmax, sp_dymax, sp_upmax;   // sp_upmax: WSL_SP_AMAX_SLOTS max |u| words per decoder stage (the raw upsampled source)
   int sp;
   size_t wg_bytes, bn_bytes, bn_coef_bytes, total_floats;   // wg_bytes: per scratch set, room for the partials of EVERY layer of a phase
   // named regions of the workspace, in allocation order (wsl_debug_net_ws_region: the tools that compare two runs' workspaces)
@@ -195,6 +195,11 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
     const size_t b = wsl_bnact_bwd_finish_ws_bytes(d->N, kFt[l], P.H[l], P.W[l], 1);
     if (b > P.bn_coef_bytes) P.bn_coef_bytes = b;
   }
+  if (P.sp)
+    for (int l = 0; l < 4; ++l) {   // + the partial maxima of the upsampling passes (split path; forward only)
+      const size_t b = wsl_bilinear_up2_fwd_amax_ws_bytes(d->N, kFt[l], P.H[l + 1], P.W[l + 1]);
+      if (b > P.bn_coef_bytes) P.bn_coef_bytes = b;
+    }
   for (int k = 0; k < d->n_dec; ++k) {
     Plan::Scratch& S = P.scr[k];
     B.tag = "scratch", B.i0 = k, B.i1 = 0;
@@ -208,11 +213,12 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
   B.tag = "images", B.i0 = 0, B.i1 = 0;
   P.packf = B.take(P.n_param, "packf"), P.packd = B.take(P.n_param, "packd");  // packed [tap][ci][co] weight images (fwd / data-gradient)
   P.winof = B.take(2 * P.n_param, "winof"), P.winod = B.take(2 * P.n_param, "winod");
-  P.spf = P.spd = P.sp_wmax = P.sp_dymax = 0;
+  P.spf = P.spd = P.sp_wmax = P.sp_dymax = P.sp_upmax = 0;
   if (P.sp) {
     // one max |w| slot per pack-table entry, WSL_SP_AMAX_SLOTS max |dy| slots per BatchNorm layer: sized from the plan
     P.spf = B.take(P.n_param * 10 / 9 + 64, "spf"), P.spd = B.take(P.n_param * 10 / 9 + 64, "spd");
     P.sp_wmax = B.take(kSpMaxLayers, "sp_wmax"), P.sp_dymax = B.take((size_t)P.n_bn * WSL_SP_AMAX_SLOTS, "sp_dymax");
+    P.sp_upmax = B.take((size_t)d->n_dec * 4 * WSL_SP_AMAX_SLOTS, "sp_upmax");
   }
   P.total_floats = B.off;
   return WSL_OK;
@@ -247,7 +253,7 @@ struct WgBatch {
 
 // weight gradient of one layer: stage 1 now (its partials get their own region of wg_ws), stage 2 with the phase's batch
 static int wgrad_layer(const Ctx& c, const WslSrc* a, const WslSrc* b, const float* dy, int64_t dy_bs, float* dw, float* db, int H,
-                       int W, int Co, int ks, const uint32_t* dy_amax = nullptr) {
+                       int W, int Co, int ks, const uint32_t* dy_amax = nullptr, const uint32_t* raw_amax = nullptr) {
   const int N = c.P.d.N, Ci = a->C + (b ? b->C : 0);
   // (the split weight gradient is taken where it wins: 32-channel blocks on both sides.  On the 16-channel full-resolution layers
   // the f32 Winograd kernel is the faster one -- profiles/r3_sweep_layers_sp.md -- and just as much an fp32 result.)
@@ -262,7 +268,7 @@ static int wgrad_layer(const Ctx& c, const WslSrc* a, const WslSrc* b, const flo
     return WSL_EWORKSPACE;
   }
   char* ws = reinterpret_cast<char*>(c.ws + c.S().wg_ws) + wb->off;
-  if (sp) WSL_TRY(wsl_sp_conv2d_wgrad_partial(a, b, dy, dy_bs, dy_amax, dw, db, N, H, W, Co, ws, need, &wb->items[wb->n], c.stream));
+  if (sp) WSL_TRY(wsl_sp_conv2d_wgrad_partial_amax(a, b, dy, dy_bs, dy_amax, raw_amax, dw, db, N, H, W, Co, ws, need, &wb->items[wb->n], c.stream));
   else WSL_TRY(wsl_conv2d_wgrad_partial(a, b, dy, dy_bs, dw, db, N, H, W, Co, ks, ws, need, &wb->items[wb->n], c.stream));
   wb->n += 1, wb->off += need;
   return WSL_OK;
@@ -296,6 +302,9 @@ static const uint32_t* sp_wmax(const Ctx& c, const ConvRef& cv) { return reinter
 static uint32_t* sp_dymax(const Ctx& c, const BnRef& bn) {
   return c.P.sp ? reinterpret_cast<uint32_t*>(c.ws + c.P.sp_dymax) + (size_t)bn.nbt * WSL_SP_AMAX_SLOTS : nullptr;
 }
+static uint32_t* sp_upmax(const Ctx& c, int k, int i) {
+  return c.P.sp ? reinterpret_cast<uint32_t*>(c.ws + c.P.sp_upmax) + (size_t)(k * 4 + i) * WSL_SP_AMAX_SLOTS : nullptr;
+}
 static bool sp_takes(const Ctx& c, const ConvRef& cv, const WslSrc* a, const WslSrc* b, const float* y, int64_t y_bs, int H, int W,
                      int Co) {
   return c.P.sp && cv.ks == 3 && wsl_sp_conv2d_ok(a, b, y, y_bs, c.P.d.N, H, W, Co, 3);
@@ -307,8 +316,9 @@ static bool sp_takes(const Ctx& c, const ConvRef& cv, const WslSrc* a, const Wsl
 static int conv_any(const Ctx& c, const ConvRef& cv, int dgrad, const WslSrc* a, const WslSrc* b, const float* bias,
                     float* y, int64_t y_bs, int H, int W, float* stp, float* stc, const uint32_t* in_amax = nullptr) {
   const int N = c.P.d.N, Co = dgrad ? cv.Ci : cv.Co;
+  // (in_amax: a data-gradient launch's max |dy| slots, or a forward launch's max of its RAW source -- the decoder blocks' upsampled tensor)
   if ((!dgrad || in_amax) && sp_takes(c, cv, a, b, y, y_bs, H, W, Co))
-    return wsl_sp_conv2d_fwd(a, b, c.ws + (dgrad ? c.P.spd : c.P.spf) + sp_img_off(cv), sp_wmax(c, cv), dgrad ? in_amax : nullptr, bias,
+    return wsl_sp_conv2d_fwd(a, b, c.ws + (dgrad ? c.P.spd : c.P.spf) + sp_img_off(cv), sp_wmax(c, cv), in_amax, bias,
                              y, y_bs, N, H, W, Co, stp, stc, c.stream);
   if (wsl_conv2d_fast_ok(a, b, y, y_bs, W)) {
     if (wsl_conv2d_wino_ok(N, H, W, a->C, b ? b->C : 0, Co, cv.ks))
@@ -400,12 +410,12 @@ static int pack_all(const Ctx& c, int with_dgrad) {
 
 // conv + (train: batch statistics -> BN coefficients | eval: running statistics)
 static int conv_bn_fwd(const Ctx& c, const ConvRef& cv, const BnRef& bn, const WslSrc* a, const WslSrc* b, size_t y,
-                       size_t st, int H, int W) {
+                       size_t st, int H, int W, const uint32_t* raw_amax = nullptr) {
   const Plan& P = c.P;
   const int N = P.d.N, C = cv.Co;
   float* stp = c.training ? c.ws + c.S().stat_part : nullptr;
   float* stc = c.training ? c.ws + c.S().stat_cnt : nullptr;
-  WSL_TRY(conv_any(c, cv, 0, a, b, c.params + cv.b, c.ws + y, (int64_t)C * H * W, H, W, stp, stc));
+  WSL_TRY(conv_any(c, cv, 0, a, b, c.params + cv.b, c.ws + y, (int64_t)C * H * W, H, W, stp, stc, raw_amax));
   float* s = c.ws + st;
   if (c.training) {
     const int nblk = sp_takes(c, cv, a, b, c.ws + y, (int64_t)C * H * W, H, W, C) ? wsl_sp_conv2d_stat_blocks(N, H, W, cv.Ci, C)
@@ -419,9 +429,9 @@ static int conv_bn_fwd(const Ctx& c, const ConvRef& cv, const BnRef& bn, const W
 }
 
 static int block_fwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslSrc* a, const WslSrc* b, int l,
-                     const uint8_t* emask, float es) {
+                     const uint8_t* emask, float es, const uint32_t* raw_amax = nullptr) {
   const int H = c.P.H[l], W = c.P.W[l], C = k.c1.Co;
-  WSL_TRY(conv_bn_fwd(c, k.c1, k.b1, a, b, w.y1, w.st1, H, W));
+  WSL_TRY(conv_bn_fwd(c, k.c1, k.b1, a, b, w.y1, w.st1, H, W, raw_amax));
   const WslSrc mid = act_src(c, w.y1, w.st1, C, H * W, c.training ? emask : nullptr, es, nullptr);
   return conv_bn_fwd(c, k.c2, k.b2, &mid, nullptr, w.y2, w.st2, H, W);
 }
@@ -430,7 +440,8 @@ static int block_fwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslS
 // BatchNorm's backward when the producer of g emitted them).  Writes parameter grads; if dgrad_out != NULL also d(block input)
 // (all Ci channels, dense).
 static int block_bwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslSrc* a, const WslSrc* b, int l,
-                     const uint8_t* emask, float es, const float* g, int64_t g_bs, const GStats& gs, float* dgrad_out) {
+                     const uint8_t* emask, float es, const float* g, int64_t g_bs, const GStats& gs, float* dgrad_out,
+                     const uint32_t* raw_amax = nullptr) {
   const Plan& P = c.P;
   const int H = P.H[l], W = P.W[l], C = k.c1.Co;
   const int64_t CHW = (int64_t)C * H * W;
@@ -444,7 +455,7 @@ static int block_bwd(const Ctx& c, const BlockRef& k, const BlkWs& w, const WslS
   GStats g1s;
   WSL_TRY(conv_dgrad_bn(c, k.c2, dy, g1, H, W, w.y1, w.st1, emask, es, &g1s, sp_dymax(c, k.b2)));
   WSL_TRY(bn_bwd(c, g1, CHW, w.y1, w.st1, k.b1, emask, es, dy, H, W, g1s));
-  WSL_TRY(wgrad_layer(c, a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, H, W, C, 3, sp_dymax(c, k.b1)));
+  WSL_TRY(wgrad_layer(c, a, b, dy, CHW, c.grads + k.c1.w, c.grads + k.c1.b, H, W, C, 3, sp_dymax(c, k.b1), raw_amax));
   if (dgrad_out) {
     const WslSrc dys1 = raw_src(dy, C, CHW);
     WSL_TRY(conv_any(c, k.c1, 1, &dys1, nullptr, nullptr, dgrad_out, (int64_t)k.c1.Ci * H * W, H, W, nullptr, nullptr,
@@ -468,10 +479,13 @@ static int decoder_fwd(const Ctx& c, int k, const float* const* cmasks, float* l
     const ConvRef& cv = P.dec[k].c1x1[i];
     WSL_TRY(conv_any(c, cv, 0, &low, nullptr, c.params + cv.b, c.ws + P.wdec[k].u[i], (int64_t)c2 * h * w, h, w, nullptr,
                      nullptr));
-    WSL_TRY(wsl_bilinear_up2_fwd(c.ws + P.wdec[k].u[i], c.ws + P.wdec[k].up[i], (int64_t)c2 * H * W, N, c2, h, w, c.stream));
+    // (split path: the upsampling pass also leaves max |u| -- the bound of its raw output, the block's second source -- in the stage's slots;
+    //  the partial maxima use the scratch set's BatchNorm-backward coefficient area, idle in the forward)
+    WSL_TRY(wsl_bilinear_up2_fwd_amax(c.ws + P.wdec[k].u[i], c.ws + P.wdec[k].up[i], (int64_t)c2 * H * W, N, c2, h, w,
+                                      c.ws + c.S().bn_coef, P.bn_coef_bytes, sp_upmax(c, k, i), c.stream));
     const WslSrc skip = feat_src(c, l, cmasks ? cmasks[l] : nullptr);
     const WslSrc up = raw_src(c.ws + P.wdec[k].up[i], c2, (int64_t)c2 * H * W);
-    WSL_TRY(block_fwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f));
+    WSL_TRY(block_fwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f, sp_upmax(c, k, i)));
   }
   const WslSrc last = act_src(c, P.wdec[k].blk[3].y2, P.wdec[k].blk[3].st2, kFt[0], P.H[0] * P.W[0], nullptr, 1.f, nullptr);
   const ConvRef& oc = P.dec[k].out;
@@ -495,7 +509,7 @@ static int decoder_bwd(const Ctx& c, int k, const float* const* cmasks, const fl
     const WslSrc skip = feat_src(c, l, cmasks ? cmasks[l] : nullptr);
     const WslSrc up = raw_src(c.ws + P.wdec[k].up[i], c2, (int64_t)c2 * H * W);
     float* dcat = c.ws + P.wdec[k].dcat[i];
-    WSL_TRY(block_bwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f, g, (int64_t)c2 * H * W, gs, dcat));
+    WSL_TRY(block_bwd(c, P.dec[k].blk[i], P.wdec[k].blk[i], &skip, &up, l, nullptr, 1.f, g, (int64_t)c2 * H * W, gs, dcat, sp_upmax(c, k, i)));
     // d(up) = dcat[:, c2:]  ->  d(u)  ->  conv1x1 backward
     float* du = c.ws + c.S().tmp_du;
     WSL_TRY(wsl_bilinear_up2_bwd(dcat + (int64_t)c2 * H * W, (int64_t)2 * c2 * H * W, du, N, c2, h, w, c.stream));
