@@ -82,8 +82,11 @@ def test_kernels_of_the_step_do_not_spill_beyond_the_known_few():
     """scratch (private segment) per kernel, read from the code objects' metadata.  Round 4 removed the
     scratch of the loss head (address-taken per-class arrays) and of the narrow-K convolution (register cap 3 -> 2: classifier data
     gradient 134 -> 97 us).  What is left is listed here with its size, so that a change that makes a hot kernel spill fails:
-    a handful of registers in kernels that sit exactly at a register cap which was MEASURED faster with the cap (conv_sp 16-channel
-    blocks: 3 workgroups per CU; the 128-tile Winograd form: 256 registers), and the generic fallbacks no step of the networks launches."""
+    a handful of registers in kernels that sit exactly at a register cap which was MEASURED faster with the cap (the 128-tile Winograd
+    form: 256 registers), and the generic fallbacks no step of the networks launches.  The split-precision conv kernels must not
+    spill at all: a spill reload inside their tile loop is a vector-memory load, and vmcnt being in-order it waits for every prefetch
+    in flight (they were made spill-free by one epilogue per instantiation, per-item operand offsets and a scheduling fence in the
+    64-wide form)."""
     import subprocess
     import sys
     import tempfile
@@ -94,7 +97,7 @@ def test_kernels_of_the_step_do_not_spill_beyond_the_known_few():
         pytest.skip("llvm-objdump of the ROCm toolchain not found")
     readelf = os.path.join(os.path.dirname(scan_vop3p.OBJDUMP), "llvm-readelf")
     allowed = {   # kernel-name fragment -> bytes of scratch tolerated
-        "conv_sp_kernelILi8ELi32ELi16ELb1": 16, "conv_sp_kernelILi8ELi32ELi16ELb0": 24, "conv_sp_kernelILi8ELi32ELi64ELb0": 32,
+        "conv_sp_kernelILi8ELi16ELi16ELb0ELi2": 32,   # a shape no layer of the networks has (16-wide block of > 64 input channels)
         "conv_wino2_kernelILi8ELi64ELi1": 16, "conv_wino2r_kernelILi8ELi64ELi1": 16,
         "conv_mfma2_kernel": 64,            # generic direct fallback (odd shapes in tests; not launched by a 16-aligned network)
         "head_reduce_kernelILi0": 176,      # generic class count (C != 4): per-class arrays indexed at run time

@@ -29,19 +29,27 @@ DEC = [(256, 128, 32), (128, 64, 64), (64, 32, 128), (32, 16, 256)]
 SHAPES = ENC + (DEC if "--dec" in sys.argv else [])
 if "--few" in sys.argv:
     SHAPES = [(16, 16, 256), (32, 16, 256), (64, 64, 64), (128, 128, 32)]
+if "--mid" in sys.argv:
+    SHAPES = [(32, 32, 128), (64, 64, 64), (128, 128, 32), (128, 64, 64), (256, 256, 16)]
+REPS = int(os.environ.get("SWEEP_REPS", "20"))
 only_sp = "--only-sp" in sys.argv
 
 
-def timed(fn, reps=20):
+def timed(fn, reps=None):
+    """microseconds per launch: the best of SWEEP_BEST (default 1) rounds of `reps` back-to-back launches"""
+    reps = reps or REPS
     for _ in range(3):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    best = float("inf")
+    for _ in range(int(os.environ.get("SWEEP_BEST", "1"))):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
 
 
 def src(x, Cn, HW, scale=None, shift=None):

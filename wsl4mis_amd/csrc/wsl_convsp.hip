@@ -128,12 +128,21 @@ __device__ __forceinline__ float sp_f4(const float4& v, int i) { return i == 0 ?
 // profiles/r4_sp_root_cause.md; xform_bn_leaky now detaches its scalars, so either source of coefficients is safe.)  cml: this sample's channel multipliers (global
 // memory), indexed by the channel inside the concatenated input (tc0 = index of channel chb).  `zero_fill`: tasks outside the
 // image write zero slots.
-template <typename I>
+// CMSH: the multipliers are not read from `cml` but from `cm_lane` -- lane l of every wave holds the multiplier of channel (l & 15) of the
+// 16-channel chunk (requested with the tile data: a load issued HERE would have to wait for every store and prefetch in flight).
+template <typename I, bool CMSH = false>
 __device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const SpCoef<I::NR>& cf,
                                           float cmul, const float* cml, int tc0, bool has_scale, bool has_mask, bool has_cm, float es, bool has_mul,
-                                          float mul, bool zero_fill) {
+                                          float mul, bool zero_fill, float cm_lane = 1.f) {
 #pragma unroll
   for (int r = 0; r < I::NR; ++r) {
+    float cmv[8];
+    if constexpr (CMSH) {
+      if (has_cm) {   // (uniform; every lane takes part in the shuffles)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cmv[c] = __shfl(cm_lane, t.oct[r] * 8 + c);
+      }
+    }
     if (g.valid[r]) {
       wsl_v2f a[8], b[8];   // a[c] = pixels 0, 1 of channel c; b[c] = pixels 2, 3
 #pragma unroll
@@ -145,7 +154,9 @@ __device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<
         }
         if (has_mask) xform_mask(a[c], b[c], g.m[r][c], es);
         if (has_cm) {
-          const float cm = cml[ch];
+          float cm;
+          if constexpr (CMSH) cm = cmv[c];
+          else cm = cml[ch];
           a[c] = a[c] * cm, b[c] = b[c] * cm;
         }
         if (has_mul) a[c] = a[c] * mul, b[c] = b[c] * mul;
@@ -259,11 +270,18 @@ int sp_pack_table(const PackTable& t, const int64_t* img_off_bytes, const float*
 
 // ------------------------------------------------------------------------------------------------ conv forward / data gradient
 // Persistent workgroups: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and, inside a tile, the 16-channel
-// chunks of the input; the raw data of the NEXT (tile, chunk) is requested before the MFMA loop of the current one, so loads are
-// in flight during the matrix work, the epilogue's stores and the statistics -- the full-resolution layers are HBM-bound by a wide
-// margin (16 -> 16 @ 256 x 256: 107 us of traffic at 5 TB/s against 40 us of matrix + staging work) and a workgroup that loads,
-// waits, computes and stores in sequence leaves the memory system idle most of its life.  BRES: the weight image of the block fits
-// LDS for all chunks (Ci * CO_T <= 1024: the two full-resolution levels) and is staged once per workgroup.
+// chunks of the input.  Everything a (tile, chunk) item needs from memory is requested one item ahead and NOTHING inside the loop waits
+// for anything younger (round 4; vmcnt is one in-order counter for loads, stores and LDS DMAs of a wave, so one wait for a young
+// instruction drains the whole queue -- profiles/r4_conv_sp_where_the_time_goes.md section 5):
+//   * the raw tile data of the NEXT item is requested (into registers) before the MFMA loop of the current one;
+//   * the weight block of the next chunk goes straight into LDS (global_load_lds, issued from inline assembly so that hipcc places no
+//     wait in front of the MFMA loop's LDS reads): into the OTHER of two buffers before the MFMA loop where LDS has room for two (DB:
+//     blocks of <= 32 output channels), else into the one buffer right after the MFMA loop, in front of the epilogue;
+//   * BatchNorm coefficients come from an LDS table filled once per workgroup, the bias from registers loaded once;
+//   * barriers publish LDS only (WSL_LDS_BARRIER): the output stores of a finished tile stay in flight across them, and the one
+//     explicit wait before the barrier that publishes a weight block leaves exactly those stores outstanding.
+// BRES: the weight image of the block fits LDS for all chunks (Ci * CO_T <= 1024: the two full-resolution levels) and is staged once per
+// workgroup.
 struct ConvSpP {
   SpSrc a, b;
   const wsl_u4* img;        // this layer's weight image
@@ -277,7 +295,7 @@ struct ConvSpP {
   float* stat_cnt;
   BnBwdEpi bn;              // data-gradient launches: BatchNorm-backward statistics of the consumer of y
   int ablate;               // EXPERIMENTS build (env WSL_SP_ABLATE; results are WRONG by design): 1 no MFMA, 2 no transform / split /
-                            // LDS writes after the first commit, 4 no output stores, 8 no global loads after the first request
+                            // LDS writes after the first commit, 4 no output stores, 8 no global loads after the first request, 16 no weight DMA after the first
 };
 
 template <int TH, int TW, int CO_T>
@@ -292,19 +310,42 @@ struct ConvSpCfg {
 #define WSL_SP_MINW16 3   // (A / B: 2 = no register cap for the 16-channel blocks: no spills, one workgroup per CU fewer)
 #endif
   static constexpr int MINW = (NT == 1 && Img::NR == 1) ? WSL_SP_MINW16 : 2;
-  static size_t smem(int Ci, bool bres) { return Img::BYTES + (size_t)(bres ? Ci / 16 : 1) * B_BYTES + RED_BYTES; }
+#ifndef WSL_SP_DB
+#define WSL_SP_DB 1       // (A / B: 0 = one streamed weight buffer for every block width)
+#endif
+  // streamed weight blocks double-buffered where two workgroups per CU still fit: 32 KB image + 2 x 20 KB + table <= 80 KB
+  static constexpr bool DB = WSL_SP_DB && CO_T <= 32;
+  static constexpr int COEF_BYTES_PER_CH = 8;                      // {scale, shift} x operand scale, [octet][scale x 8 | shift x 8]
+  // Resident-weight kernels (<= 64 input channels = 8 octets) keep the table in the tail padding of the image planes (ROWS * ROWB = 8000 of
+  // 8192 bytes used: three 64-byte octet entries per plane, four planes): the 16-wide blocks sit exactly at three workgroups per CU
+  // (42 LDS allocation units of 1280 bytes each; 256 more bytes are a 43rd unit and the third workgroup is gone: measured +21 %)
+  static constexpr int PLANE_USED = Img::ROWS * Img::ROWB, SLACK_OCTETS = (Img::PLANE - PLANE_USED) / 64;
+  static_assert(PLANE_USED % 16 == 0 && 4 * SLACK_OCTETS >= 8, "coefficient table of <= 64 channels fits the planes' padding");
+  static size_t smem(int Ci, bool bres) {
+    return Img::BYTES + (size_t)(bres ? Ci / 16 : (DB ? 2 : 1)) * B_BYTES + RED_BYTES + (bres ? 0 : (size_t)Ci * COEF_BYTES_PER_CH);
+  }
   static_assert(MT_TOTAL % 4 == 0 && MT % SEGS == 0 && MT % 2 == 0, "tile shape");
 };
 
-template <int TH, int TW, int CO_T, bool BRES>
+// EPI: what the epilogue of a tile emits besides the tile -- 0 nothing, 1 BatchNorm partial statistics of the output (forward launches),
+// 2 BatchNorm-backward statistics of the layer that consumes this gradient (data-gradient launches; blocks of <= 32 accumulator
+// registers).  One epilogue per instantiation: with all three in one kernel the register allocator spilled inside the tile loop, and a
+// spill reload is a vector-memory load that waits for every prefetch in flight.
+template <int TH, int TW, int CO_T, bool BRES, int EPI>
 __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_kernel(ConvSpP p) {
   using C = ConvSpCfg<TH, TW, CO_T>;
   using I = typename C::Img;
+  constexpr bool DB = !BRES && C::DB;
   WSL_DYN_SMEM(smem);
   const int Ci = p.Ci, Co = p.Co, H = p.H, W = p.W, HW = H * W;
   unsigned char* a_img = smem;
   unsigned char* b_img = smem + I::BYTES;
-  float* red = reinterpret_cast<float*>(b_img + (size_t)(BRES ? Ci / 16 : 1) * C::B_BYTES);
+  float* red = reinterpret_cast<float*>(b_img + (size_t)(BRES ? Ci / 16 : (DB ? 2 : 1)) * C::B_BYTES);
+  // coefficient entry of octet q (64 bytes: scale x 8 | shift x 8)
+  auto ctab_octet = [&](int q) __attribute__((always_inline)) -> float* {
+    if constexpr (BRES) return reinterpret_cast<float*>(a_img + (q / C::SLACK_OCTETS) * I::PLANE + C::PLANE_USED + (q % C::SLACK_OCTETS) * 64);
+    else return red + C::RED_BYTES / 4 + q * 16;
+  };
   const int tid = threadIdx.x, lane = tid & 63, wave = WSL_WAVE_UNIFORM(tid >> 6);
   const int co0 = blockIdx.y * CO_T;
   const int nb = p.ntiles;
@@ -321,16 +362,30 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
   const float in_mul = sp_pow2(e_in);
   const float u1 = sp_pow2(-e_w), u2 = sp_pow2(-e_in);
 
-  // weight pieces of a chunk: LDS piece u = ((hl * 5 + s) * 4 + g) * CO_T + col  <-  image piece ((hl * 5 + s) * 4 + g) * Co + co0 + col
-  uint32_t woff[C::NBW];
-#pragma unroll
-  for (int i = 0; i < C::NBW; ++i) {
-    const int u = tid + i * kThreads;
-    const int col = u % CO_T, rest = u / CO_T;
-    woff[i] = u < C::B_PIECES ? (uint32_t)(rest * Co + co0 + col) : 0u;
+  // loader coefficients of every input channel (concatenated index), operand scale folded in (exact: a power of two)
+  for (int c = tid; c < Ci; c += kThreads) {
+    const bool ina = c < p.a.C;
+    const SpSrc& s = ina ? p.a : p.b;
+    const int cc = ina ? c : c - p.a.C;
+    float* q = ctab_octet(c >> 3) + (c & 7);
+    q[0] = s.scale ? s.scale[cc] * in_mul : 0.f;
+    q[8] = s.scale ? s.shift[cc] * in_mul : 0.f;
   }
+  // bias of this lane's output columns
+  float biasv[C::NT];
+#pragma unroll
+  for (int j = 0; j < C::NT; ++j) biasv[j] = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
+
+  // weight pieces of a chunk: LDS piece u = ((hl * 5 + s) * 4 + g) * CO_T + col  <-  image piece ((hl * 5 + s) * 4 + g) * Co + co0 + col
   const int64_t chunk_pieces = (int64_t)40 * Co;
   if constexpr (BRES) {   // every chunk's weights, once
+    uint32_t woff[C::NBW];
+#pragma unroll
+    for (int i = 0; i < C::NBW; ++i) {
+      const int u = tid + i * kThreads;
+      const int col = u % CO_T, rest = u / CO_T;
+      woff[i] = u < C::B_PIECES ? (uint32_t)(rest * Co + co0 + col) : 0u;
+    }
     for (int ch = 0; ch < Ci / 16; ++ch) {
       const wsl_u4* wb = p.img + (int64_t)ch * chunk_pieces;
 #pragma unroll
@@ -339,18 +394,30 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
           reinterpret_cast<wsl_u4*>(b_img + (size_t)ch * C::B_BYTES)[tid + i * kThreads] = wb[woff[i]];
     }
   }
-  // A operand of K-step s: pixel m = lane & 15 of the row tile, octet (lane >> 4) & 1, tap 2 s + (lane >> 5)
-  int aoff[5];
+  // A operand of K-step s: pixel m = l & 15 of the row tile, octet (l >> 4) & 1, tap 2 s + (l >> 5); B operand: k-group l >> 4, column l & 15
+  int aoff[5], bbase = 0;
+  auto operand_offsets = [&](int l) __attribute__((always_inline)) {
 #pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int tap = 2 * s + (lane >> 5) < 9 ? 2 * s + (lane >> 5) : 8;   // (the tenth tap meets a zero weight block)
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    aoff[s] = ((lane >> 4) & 1) * I::PLANE + ky * I::ROWB + sp_slot<I>(3 + (lane & 15) + kx);
-  }
-  const int bbase = ((lane >> 4) * CO_T + (lane & 15)) * 16;
+    for (int s = 0; s < 5; ++s) {
+      const int tap = 2 * s + (l >> 5) < 9 ? 2 * s + (l >> 5) : 8;   // (the tenth tap meets a zero weight block)
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      aoff[s] = ((l >> 4) & 1) * I::PLANE + ky * I::ROWB + sp_slot<I>(3 + (l & 15) + kx);
+    }
+    bbase = ((l >> 4) * CO_T + (l & 15)) * 16;
+  };
+  // The 64-wide block with the statistics epilogue is the one instantiation whose register file is full: it recomputes the six offsets
+  // per item (a dozen instructions in front of 240 MFMAs) from a lane index hipcc cannot trace back to threadIdx -- kept across the tile
+  // loop they are live through the staging code -- and fences the scheduler between K-steps (below); without both it spills
+#ifndef WSL_SP_TIGHT
+#define WSL_SP_TIGHT 1    // (A / B: 0 = never, 2 = every 64-wide instantiation)
+#endif
+  constexpr bool kTightRegs = C::NT == 4 && (WSL_SP_TIGHT == 2 || (WSL_SP_TIGHT == 1 && EPI == 1));
+  constexpr bool kOffsetsPerItem = kTightRegs;
+  if constexpr (!kOffsetsPerItem) operand_offsets(lane);
 
   SpTasks<I::NR> tk;
   SpRegs<I::NR> pre;
+  float pre_cm = 1.f;
   // Tile order: workgroup b runs on XCD b % 8 (observed dispatch; speed only) -- give every XCD one contiguous eighth of the tiles and
   // let its workgroups walk it side by side, so the halo lines two neighbouring tiles share meet in ONE L2 instead of being fetched
   // over the fabric by three (measured: the loads alone of 16 -> 16 @ 256 x 256 took 118 us with tiles dealt round-robin)
@@ -371,52 +438,78 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
     const SpSrc& s = ina ? p.a : p.b;
     const int chb = ina ? nc0 : nc0 - p.a.C;
     sp_issue<I>(tk, pre, s.x + n_n * s.bs, s.emask ? s.emask + (int64_t)n_n * s.C * HW : nullptr, chb, HW);
+    // channel multipliers of the chunk (Dropout2d of a skip feature): lane l holds channel (l & 15); the commit fetches its eight by shuffle
+    if (s.cmask) pre_cm = s.cmask[(int64_t)n_n * s.C + chb + (lane & 15)];
   };
 
-  // streamed weights: one chunk's block goes straight into LDS (global_load_lds: lane-linear pieces, no registers, no ds_write);
-  // requested when the MFMA loop that read the previous block is over, awaited behind the next tile image's staging arithmetic
-  auto dma_weights = [&](int c0) __attribute__((always_inline)) {
-    const wsl_u4* wb = p.img + (int64_t)(c0 >> 4) * chunk_pieces;
+  // streamed weights: one chunk's block goes straight into LDS buffer `buf` (lane-linear pieces, no registers, no ds_write, and
+  // invisible to hipcc's wait insertion: the wait is vm_wait_weights() below)
+  auto dma_weights = [&](int c0, int buf) __attribute__((always_inline)) {
+    const wsl_u4* wb = p.img + (int64_t)(c0 >> 4) * chunk_pieces + co0;
+    unsigned char* dst = b_img + (size_t)buf * C::B_BYTES;
+    // piece offsets recomputed here (a shift, a mask, a multiply-add each) from a thread index hipcc cannot trace back to threadIdx:
+    // hoisted out of the tile loop they would be NBW more registers live across everything
+    int tv = tid;
+    WSL_DETACH32(tv);
 #pragma unroll
     for (int i = 0; i < C::NBW; ++i)
-      if ((i + 1) * kThreads <= C::B_PIECES || (i * kThreads + wave * 64) < C::B_PIECES)   // whole waves (B_PIECES % 64 == 0)
-        WSL_LDS_DMA16(wb + woff[i], b_img + (size_t)(i * kThreads + wave * 64) * 16);
+      if ((i + 1) * kThreads <= C::B_PIECES || (i * kThreads + wave * 64) < C::B_PIECES) {   // whole waves (B_PIECES % 64 == 0)
+        const int u = tv + i * kThreads;
+        WSL_LDS_DMA16_UNTRACKED(wb + ((u / CO_T) * Co + (u % CO_T)), dst + (size_t)(i * kThreads + wave * 64) * 16);
+      }
   };
 
   v4f acc[C::MT][C::NT];
+  int buf = 0;            // streamed weights: the buffer of the current chunk
+  bool stored = false;    // a tile's output stores were issued AFTER the weight DMA now awaited (uniform)
   if (nt < tend) {
     issue();
-    if constexpr (!BRES) dma_weights(0);
+    if constexpr (!BRES) dma_weights(0, 0);
   }
-  __syncthreads();   // resident weights visible
+  __syncthreads();   // resident weights and the coefficient table visible
 
   while (nt < tend) {
     const int t = nt, c0 = nc0, n = n_n;
     {   // ---- raw data -> hi / lo images
       const bool ina = c0 < p.a.C;
       const SpSrc& s = ina ? p.a : p.b;
-      // this chunk's BatchNorm coefficients: an L1 hit, requested here rather than with the tile data so that its 16 registers
-      // are not live across the MFMA loop
       SpCoef<I::NR> coef;
-      if (s.scale) sp_coef_issue<I>(tk, coef, s.scale, s.shift, ina ? c0 : c0 - p.a.C);
-      const float* cmn = s.cmask ? s.cmask + (int64_t)n * s.C - (ina ? 0 : p.a.C) : nullptr;   // indexed by the table channel
+      if (s.scale) {
+#pragma unroll
+        for (int r = 0; r < I::NR; ++r) {
+          const float4* q = reinterpret_cast<const float4*>(ctab_octet((c0 >> 3) + tk.oct[r]));
+          coef.s[r][0] = q[0], coef.s[r][1] = q[1], coef.h[r][0] = q[2], coef.h[r][1] = q[3];
+        }
+      }
       if (!WSL_ABLATED(p, 2) || (t == t_first && c0 == 0))
-        sp_commit<I>(tk, pre, a_img, coef, in_mul, cmn, c0, s.scale != nullptr, s.emask != nullptr, s.cmask != nullptr, s.es,
-                     s.scale == nullptr, in_mul, true);
-      WSL_WAIT_ALL();   // this chunk's streamed weight block has landed; every LDS store of this wave is complete
+        sp_commit<I, true>(tk, pre, a_img, coef, 1.f, nullptr, c0, s.scale != nullptr, s.emask != nullptr, s.cmask != nullptr, s.es,
+                     s.scale == nullptr, in_mul, true, pre_cm);
+      if constexpr (!BRES) {
+        // this chunk's weight block has landed: everything of this wave but the output stores issued after its DMA is complete
+        // (C::MT * C::NT float4 stores per wave and tile, all unconditional; stores of single lanes that follow them are younger still)
+        if (stored) WSL_VM_WAIT(C::MT * C::NT);
+        else WSL_VM_WAIT(0);
+        stored = false;
+      }
     }
-    __syncthreads();
+    WSL_LDS_BARRIER();
     // ---- request the next (tile, chunk)
     if (c0 + 16 < Ci) nc0 = c0 + 16;
     else nc0 = 0, nt = t + tstep;
     if (nt < tend && !WSL_ABLATED(p, 8)) issue();   // in flight during the MFMA loop, the epilogue's stores and the statistics
+    if constexpr (DB) if (nt < tend && !WSL_ABLATED(p, 16)) dma_weights(nc0, buf ^ 1);
     if (c0 == 0) {
 #pragma unroll
       for (int i = 0; i < C::MT; ++i)
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
     }
-    const unsigned char* b_c = b_img + (BRES ? (size_t)(c0 >> 4) * C::B_BYTES : 0);
+    const unsigned char* b_c = b_img + (BRES ? (size_t)(c0 >> 4) * C::B_BYTES : (size_t)buf * C::B_BYTES);
+    if constexpr (kOffsetsPerItem) {
+      int lv = lane;
+      WSL_DETACH32(lv);
+      operand_offsets(lv);
+    }
     if (!WSL_ABLATED(p, 1))
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -448,36 +541,35 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
           }
         }
       }
+      // keep the scheduler from pulling the next K-steps' operand reads (40 registers) up into this one -- with them that kernel spills
+      // inside the tile loop, and a spill reload is a vector-memory load that waits for every prefetch in flight
+      if constexpr (kTightRegs) WSL_SCHED_BARRIER();
     }
+    WSL_LDS_BARRIER();   // the tile image and this chunk's weight block are free again
+    if constexpr (!BRES && !DB) if (nt < tend && !WSL_ABLATED(p, 16)) dma_weights(nc0, 0);
+    if constexpr (DB) buf ^= 1;
     if (c0 + 16 >= Ci) {
-      // ---- epilogue of tile t: undo the operand scales, bias, float4 stores, statistics (tiles and channel blocks are full)
+      // ---- epilogue of tile t: undo the operand scales, bias, statistics, float4 stores (tiles and channel blocks are full).  Loads
+      // first, stores last: a load waits for every older store of the wave.
       const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y;
       const int y0 = ty * TH, x0 = tx * TW;
       float bsum[C::NT];
       constexpr int RPW = C::MT / C::SEGS;   // output rows per wave
-      {
-        float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
 #pragma unroll
-        for (int j = 0; j < C::NT; ++j) {
-          const float bias = p.bias ? p.bias[co0 + j * 16 + (lane & 15)] : 0.f;
-          float* yj = yb + (int64_t)j * 16 * HW;
-          float bs = 0.f;
+      for (int j = 0; j < C::NT; ++j) {
+        float bs = 0.f;
 #pragma unroll
-          for (int i = 0; i < C::MT; ++i) {
-            v4f v = acc[i][j];
+        for (int i = 0; i < C::MT; ++i) {
+          v4f v = acc[i][j];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (v[r] * u1) * u2 + bias;
-            acc[i][j] = v;
-            if (!WSL_ABLATED(p, 4) || v[0] == 123.456f)
-              *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16) = make_float4(v[0], v[1], v[2], v[3]);
-            bs += (v[0] + v[1]) + (v[2] + v[3]);
-          }
-          bsum[j] = bs;
+          for (int r = 0; r < 4; ++r) v[r] = (v[r] * u1) * u2 + biasv[j];
+          acc[i][j] = v;
+          bs += (v[0] + v[1]) + (v[2] + v[3]);
         }
+        bsum[j] = bs;
       }
-      bool bn_done = false;
-      if constexpr (C::MT * C::NT * 4 <= 32) if (p.bn.part) {
-        float s1[C::NT], s2[C::NT];
+      float s1[C::NT], s2[C::NT];
+      if constexpr (EPI == 2) {
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) {
           const int co = co0 + j * 16 + (lane & 15);
@@ -491,10 +583,23 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
           }
           bn_bwd_fold(ba, s1[j], s2[j]);
         }
-        bn_bwd_store<C::NT, CO_T>(p.bn, s1, s2, red, co0, Co, t, nb);
-        bn_done = true;
       }
-      if (!bn_done && p.stat_part) {
+      {
+        float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+          float* yj = yb + (int64_t)j * 16 * HW;
+#pragma unroll
+          for (int i = 0; i < C::MT; ++i) {
+            const v4f v = acc[i][j];
+            if (!WSL_ABLATED(p, 4) || v[0] == 123.456f)
+              *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+        stored = true;
+      }
+      if constexpr (EPI == 2) bn_bwd_store<C::NT, CO_T, true>(p.bn, s1, s2, red, co0, Co, t, nb);
+      if constexpr (EPI == 1) {
         float* red1 = red;
         float* red2 = red + 4 * CO_T;
         constexpr float cnt = (float)(TH * TW);
@@ -505,7 +610,7 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
           s += __shfl_xor(s, 32);
           if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
         }
-        __syncthreads();
+        WSL_LDS_BARRIER();
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) {
           const int col = j * 16 + (lane & 15);
@@ -522,7 +627,7 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
           q += __shfl_xor(q, 32);
           if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
         }
-        __syncthreads();
+        WSL_LDS_BARRIER();
         if (wave == 0 && lane < 16) {
 #pragma unroll
           for (int j = 0; j < C::NT; ++j) {
@@ -535,8 +640,6 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
         }
       }
     }
-    __syncthreads();   // the images (and `red`) are free again
-    if constexpr (!BRES) if (nt < tend) dma_weights(nc0);
   }
 }
 
@@ -563,10 +666,10 @@ static SpPlan sp_plan(int N, int H, int W, int Ci, int Co) {
   return f;
 }
 
-template <int TH, int TW, int CO_T, bool BRES>
+template <int TH, int TW, int CO_T, bool BRES, int EPI>
 static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
   using C = ConvSpCfg<TH, TW, CO_T>;
-  auto kern = conv_sp_kernel<TH, TW, CO_T, BRES>;
+  auto kern = conv_sp_kernel<TH, TW, CO_T, BRES, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)WSL_SET_MAX_DYN_SMEM(kern, C::smem(BRES ? 1024 / CO_T : kSpMaxC, BRES) + 4096);
@@ -574,7 +677,8 @@ static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
   }
   const size_t smem = C::smem(p.Ci, BRES);
   // persistent: as many workgroups as stay resident (registers: MINW per SIMD; LDS), spread over the output-channel blocks
-  int per_cu = (int)((size_t)160 * 1024 / smem);
+  // (LDS is handed out in units of 1280 bytes -- inferred: 42 units x 3 workgroups ran three per CU, 43 x 3 did not)
+  int per_cu = (int)((size_t)160 * 1024 / (((smem + 1279) / 1280) * 1280));
   if (per_cu > C::MINW) per_cu = C::MINW;
   static const int percu_env = WSL_TUNE("WSL_SP_PERCU", 0);   // (experiments build)
   if (percu_env > 0) per_cu = percu_env;
@@ -592,6 +696,14 @@ static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
   WSL_LAUNCH(kern, grid, dim3(kThreads), smem, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_sp_kernel");
+}
+
+template <int TH, int TW, int CO_T, bool BRES>
+static int launch_conv_sp_epi(ConvSpP& p, int epi, int is_dgrad, void* stream) {
+  if constexpr (TH * TW * CO_T <= 8192)   // instantiations with <= 32 accumulator registers
+    if (epi == 2) return launch_conv_sp<TH, TW, CO_T, BRES, 2>(p, is_dgrad, stream);
+  if (epi == 1) return launch_conv_sp<TH, TW, CO_T, BRES, 1>(p, is_dgrad, stream);
+  return launch_conv_sp<TH, TW, CO_T, BRES, 0>(p, is_dgrad, stream);
 }
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -617,9 +729,10 @@ static int sp_conv_launch(const WslSrc& a, const WslSrc* b, const void* image, c
   if (bn && bn->part && f.th * f.tw * f.co_t <= 8192) p.bn = *bn;   // instantiations with <= 32 accumulator registers
   if (bn_done) *bn_done = p.bn.part ? 1 : 0;
   const bool bres = p.Ci * f.co_t <= 1024;   // the block's weight image of every chunk stays in LDS (<= 40 KB)
+  const int epi = p.bn.part ? 2 : (p.stat_part ? 1 : 0);
 #define WSL_CASE(TH_, TW_, CO_)                                                    \
   if (f.th == TH_ && f.tw == TW_ && f.co_t == CO_)                                 \
-    return bres ? launch_conv_sp<TH_, TW_, CO_, true>(p, is_dgrad, stream) : launch_conv_sp<TH_, TW_, CO_, false>(p, is_dgrad, stream);
+    return bres ? launch_conv_sp_epi<TH_, TW_, CO_, true>(p, epi, is_dgrad, stream) : launch_conv_sp_epi<TH_, TW_, CO_, false>(p, epi, is_dgrad, stream);
   WSL_CASE(8, 32, 16) WSL_CASE(8, 32, 32) WSL_CASE(8, 32, 64) WSL_CASE(8, 16, 16) WSL_CASE(8, 16, 32)
 #undef WSL_CASE
   set_error("sp_conv: no kernel for tile %dx%d co_t %d", f.th, f.tw, f.co_t);

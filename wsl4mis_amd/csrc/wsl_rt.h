@@ -19,6 +19,9 @@ typedef wsl_v4f v4f;
 #define WSL_MFMA4(a, b, c) wsl_emu_mfma4(a, b, c)
 #define WSL_LDS_DMA16(gsrc, lds_wave_base) wsl_emu_lds_dma16(gsrc, lds_wave_base)
 #define WSL_WAIT_ALL()
+#define WSL_LDS_BARRIER() __syncthreads()
+#define WSL_LDS_DMA16_UNTRACKED(gsrc, lds_wave_base) wsl_emu_lds_dma16(gsrc, lds_wave_base)
+#define WSL_VM_WAIT(n)
 #define WSL_SCHED_BARRIER()
 typedef wsl_emu_u4 wsl_u4;
 typedef wsl_emu_u2 wsl_u2;
@@ -44,6 +47,27 @@ typedef float v4f __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(gsrc),              \
                                    (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #define WSL_WAIT_ALL() __builtin_amdgcn_s_waitcnt(0)
+// Workgroup barrier that publishes LDS contents ONLY: every LDS access of the wave is complete, then s_barrier.  __syncthreads() also
+// waits for every global store and load of the wave (s_waitcnt vmcnt(0)): in a persistent kernel that drains the output stores of the
+// tile just finished and the prefetch of the next one at every barrier.  Nothing written to GLOBAL memory before this barrier may be
+// read by another wave of the workgroup after it.
+#define WSL_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// The same LDS DMA issued from inline assembly (M0 = LDS base of the wave, restored afterwards): hipcc does not know the instruction
+// is in flight, so it places no wait in front of later LDS reads or barriers -- with the builtin it must assume that ANY later LDS read
+// aliases the destination and waits for the DMA (and, vmcnt being an in-order counter, for everything older) right there.  The caller
+// owns the wait: WSL_VM_WAIT(n) = at most n vector-memory instructions of this wave still in flight (issue order; loads, stores and
+// DMAs count alike) before the barrier that publishes the block.  hipcc's own vmcnt waits stay correct: it only under-counts the
+// instructions in flight, so it waits longer than needed, never shorter.
+__device__ __forceinline__ void wsl_lds_dma16_untracked(const void* gsrc, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+#define WSL_LDS_DMA16_UNTRACKED(gsrc, lds_wave_base) wsl_lds_dma16_untracked(gsrc, lds_wave_base)
+#define WSL_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // keeps the instruction scheduler from moving LDS reads / MFMAs across a software-pipeline stage boundary
 #define WSL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8 (l >> 4) + e], B[k = 8 (l >> 4) + e][j = l & 15] (8 halves = 4 VGPRs each, passed as
@@ -355,7 +379,8 @@ __device__ __forceinline__ void bn_bwd_fold(const BnBwdAcc& a, float& s1, float&
 
 // merge the per-lane sums of a 4-wave workgroup whose lanes (l & 15) own channel column col = j * 16 + (l & 15): lane groups
 // (l >> 4), then waves (through `red`, >= 8 * CO_T floats), then one store per channel into part[C][nb][2]
-template <int NT, int CO_T>
+// (LDS_ONLY: the barrier publishes `red` without waiting for the caller's global stores and prefetches -- WSL_LDS_BARRIER)
+template <int NT, int CO_T, bool LDS_ONLY = false>
 __device__ __forceinline__ void bn_bwd_store(const BnBwdEpi& e, float (&s1)[NT], float (&s2)[NT], float* red, int co0, int Co,
                                              int tile_id, int nb) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -368,7 +393,8 @@ __device__ __forceinline__ void bn_bwd_store(const BnBwdEpi& e, float (&s1)[NT],
     a += __shfl_xor(a, 32), b += __shfl_xor(b, 32);
     if (lane < 16) r1[wave * CO_T + j * 16 + lane] = a, r2[wave * CO_T + j * 16 + lane] = b;
   }
-  __syncthreads();
+  if constexpr (LDS_ONLY) WSL_LDS_BARRIER();
+  else __syncthreads();
   if (wave == 0 && lane < 16) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
