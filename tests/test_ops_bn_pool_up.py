@@ -244,3 +244,40 @@ def test_fan_in_with_bn_backward_statistics_equals_the_two_pass_form(be, shape, 
             be.ptr(slots), be.stream)
     assert np.array_equal(be.np(dy2), outs[1][1])
     assert be.np(slots).view(np.uint32).max() == np.abs(outs[1][1]).max().view(np.uint32)
+
+
+@pytest.mark.parametrize("nblk", [37, 2048 + 37])
+def test_bn_stats_finalize_four_and_sixteen_waves(be, nblk):
+    """wsl_bn_stats_finalize merges per-tile (sum, M2, count) partials, one workgroup per channel; from 2048 partials per channel on it
+    runs 16 waves instead of 4 (the kernel is a chain of memory round trips).  Both forms against a numpy fp64 Chan merge, with empty
+    slots (count 0, garbage data) in between."""
+    C = 5
+    rng = np.random.default_rng(nblk)
+    cnt = rng.integers(100, 400, nblk).astype(np.float32)
+    dead = rng.random(nblk) < 0.1
+    cnt[dead] = 0
+    mean_b = rng.standard_normal((C, nblk)) * 0.5 + np.linspace(-3, 3, C)[:, None]
+    var_b = rng.random((C, nblk)) + 0.1
+    part = np.empty((C, nblk, 2), np.float32)
+    part[..., 0] = mean_b * cnt
+    part[..., 1] = var_b * cnt
+    part[:, dead] = 1e30                                                     # must be ignored
+    live = ~dead
+    n = cnt[live].astype(np.float64).sum()
+    s = part[:, live, 0].astype(np.float64).sum(1)
+    mean = s / n
+    mb = part[:, live, 0].astype(np.float64) / cnt[live]
+    m2 = (part[:, live, 1].astype(np.float64) + cnt[live] * (mb - mean[:, None]) ** 2).sum(1)
+    gamma, beta = rng.random(C).astype(np.float32) + 0.5, rng.standard_normal(C).astype(np.float32)
+    d = [be.arr(a) for a in (part, cnt, gamma, beta)]
+    rm, rv = be.arr(np.zeros(C, np.float32)), be.arr(np.ones(C, np.float32))
+    o = [be.zeros((C,)) for _ in range(4)]
+    be.call("wsl_bn_stats_finalize", be.ptr(d[0]), be.ptr(d[1]), nblk, C, be.ptr(d[2]), be.ptr(d[3]), 1e-5, 0.1, be.ptr(rm), be.ptr(rv),
+            None, *[be.ptr(a) for a in o], be.stream)
+    invstd = 1 / np.sqrt(m2 / n + 1e-5)
+    assert rel_err(be.np(o[0]), mean) < 1e-6
+    assert rel_err(be.np(o[1]), invstd) < 1e-6
+    assert rel_err(be.np(o[2]), gamma * invstd) < 1e-6
+    assert rel_err(be.np(o[3]), beta - mean * gamma * invstd) < 1e-5
+    assert rel_err(be.np(rm), 0.1 * mean) < 1e-6
+    assert rel_err(be.np(rv), 0.9 + 0.1 * m2 / (n - 1)) < 1e-6

@@ -11,40 +11,61 @@ constexpr int kChunk = 4096;  // elements of one (n, c) plane handled by one wor
 
 // ------------------------------------------------------------------------------------------------ BN forward stats
 // One workgroup per channel: Chan-merge the conv epilogue's per-block (sum, M2, count) partials in fp64.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, const float* cnt, int nblk, int C,
-                                                          const float* gamma, const float* beta, float eps,
-                                                          float momentum, float* rmean, float* rvar, int64_t* nbt,
-                                                          float* mean_o, float* invstd_o, float* scale_o,
-                                                          float* shift_o) {
-  __shared__ double red[3 * 4];
+// The kernel is a chain of memory round trips (16 .. 256 workgroups, each walking up to 16 384 partials of ITS channel): 4 or 16 waves per
+// workgroup (kFinalizeWide) -- with 16 the full-resolution layers need two batches of eight loads per thread instead of eight.
+constexpr int kFinalizeWideFrom = 2048;   // partials per channel from which the 16-wave form is launched
+static inline int finalize_threads(int nblk) { return nblk >= kFinalizeWideFrom ? 1024 : kThreads; }
+// fixed-order merge of per-wave values through LDS: adjacent pairs, level by level ((w0 + w1) + (w2 + w3) for four waves); every thread
+// gets the total.  red: >= 16 doubles per value.
+template <int NV>
+__device__ __forceinline__ void finalize_merge_waves(double (&v)[NV], double* red) {
+  const int nw = blockDim.x >> 6, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] += __shfl_xor(v[k], m);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[k * 16 + w] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = i < nw ? red[k * 16 + i] : 0.0;
+#pragma unroll
+    for (int span = 1; span < 16; span <<= 1)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2 * span) t[i] = t[i] + t[i + span];   // (absent waves add an exact 0.0)
+    v[k] = t[0];
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, const float* cnt, int nblk, int C,
+                                                           const float* gamma, const float* beta, float eps,
+                                                           float momentum, float* rmean, float* rvar, int64_t* nbt,
+                                                           float* mean_o, float* invstd_o, float* scale_o,
+                                                           float* shift_o) {
+  __shared__ double red[3 * 16];
   const int c = blockIdx.x;
   // ONE pass: n = sum of counts, s = sum of block sums, q = sum of (M2_b + sum_b^2 / n_b); then M2 = q - s^2 / n, the same
   // Chan merge sum of [M2_b + n_b (mean_b - mean)^2] with the square expanded -- in fp64 the cancellation costs nothing here
   // (q / M2 = 1 + mean^2 / var).  (Loads are unconditional and the empty-slot test is a select: a branch on cnt[b]
   // serialised one memory round trip per iteration.)
-  double n = 0, s = 0, q = 0;
+  double acc[3] = {0, 0, 0};   // n, s, q
   const float* pc = part + (int64_t)c * nblk * 2;
 #pragma unroll 8
-  for (int b = threadIdx.x; b < nblk; b += kThreads) {
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
     const float cb = cnt[b];
     const float2 v = *reinterpret_cast<const float2*>(pc + 2 * (int64_t)b);
     const bool live = cb > 0.f;   // empty slots (count 0) carry no data
     const double nbk = live ? (double)cb : 1.0;
-    n += live ? (double)cb : 0.0;
-    s += live ? (double)v.x : 0.0;
-    q += live ? (double)v.y + (double)v.x * (double)v.x / nbk : 0.0;
+    acc[0] += live ? (double)cb : 0.0;
+    acc[1] += live ? (double)v.x : 0.0;
+    acc[2] += live ? (double)v.y + (double)v.x * (double)v.x / nbk : 0.0;
   }
-  // fixed-order merge: lanes (xor butterfly), then the four waves
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m), s += __shfl_xor(s, m), q += __shfl_xor(q, m);
-  if ((threadIdx.x & 63) == 0) {
-    const int w = threadIdx.x >> 6;
-    red[w] = n, red[4 + w] = s, red[8 + w] = q;
-  }
-  __syncthreads();
-  n = (red[0] + red[1]) + (red[2] + red[3]);
-  s = (red[4] + red[5]) + (red[6] + red[7]);
-  q = (red[8] + red[9]) + (red[10] + red[11]);
+  finalize_merge_waves<3>(acc, red);
+  const double n = acc[0], s = acc[1], q = acc[2];
   const double mean = s / n;
   double m2 = q - s * s / n;
   if (m2 < 0.0) m2 = 0.0;
@@ -408,24 +429,19 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply4_kernel(BnBwdP p, const f
 
 // part: [nblk][C][2] (sb = C, sc = 1: the stand-alone reduction pass and the fan-in kernel) or [C][nblk][2] (sb = 1, sc = nblk:
 // the convolution epilogues)
-__global__ __launch_bounds__(256) void bnact_bwd_finalize_kernel(const float* part, int nblk, int C, int64_t sb, int64_t sc,
-                                                                 double count, float* dgamma, float* dbeta, float* coef) {
-  __shared__ double red[2 * 4];
+__global__ __launch_bounds__(1024) void bnact_bwd_finalize_kernel(const float* part, int nblk, int C, int64_t sb, int64_t sc,
+                                                                  double count, float* dgamma, float* dbeta, float* coef) {
+  __shared__ double red[2 * 16];
   const int c = blockIdx.x;
-  double s1 = 0, s2 = 0;
-#pragma unroll 4
-  for (int b = threadIdx.x; b < nblk; b += kThreads) {
+  double acc[2] = {0, 0};
+#pragma unroll 8
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
     const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)b * sb + (int64_t)c * sc) * 2);
-    s1 += v.x;
-    s2 += v.y;
+    acc[0] += v.x;
+    acc[1] += v.y;
   }
-  // fixed-order merge: lanes (xor butterfly), then the four waves
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m), s2 += __shfl_xor(s2, m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s1, red[4 + (threadIdx.x >> 6)] = s2;
-  __syncthreads();
-  s1 = (red[0] + red[1]) + (red[2] + red[3]);
-  s2 = (red[4] + red[5]) + (red[6] + red[7]);
+  finalize_merge_waves<2>(acc, red);   // (4 or 16 waves: bn_finalize_kernel)
+  const double s1 = acc[0], s2 = acc[1];
   if (threadIdx.x == 0) {
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
@@ -725,7 +741,7 @@ extern "C" int wsl_bn_stats_finalize(const float* stat_part, const float* stat_c
   WSL_REQUIRE(stat_part && stat_cnt && gamma && beta && mean && invstd && scale && shift, "bn_stats_finalize: null");
   WSL_REQUIRE(nblk > 0 && C > 0, "bn_stats_finalize: bad sizes");
   ProfScope ps(PF_BN_FINALIZE, 0.0, 4.0 * (3.0 * nblk * C + 8.0 * C), stream);
-  WSL_LAUNCH(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, stat_part, stat_cnt, nblk, C, gamma, beta, eps,
+  WSL_LAUNCH(bn_finalize_kernel, dim3(C), dim3(finalize_threads(nblk)), 0, stream, stat_part, stat_cnt, nblk, C, gamma, beta, eps,
              momentum, running_mean, running_var, nbt, mean, invstd, scale, shift);
   return check_launch("bn_finalize_kernel");
 }
@@ -792,7 +808,7 @@ extern "C" int wsl_bnact_bwd_amax(const float* g, int64_t g_bs, const float* y, 
                    (!emask || (reinterpret_cast<uintptr_t>(emask) & 3) == 0);
   if (vec) WSL_LAUNCH(bnact_bwd_reduce4_kernel, grid, dim3(kThreads), 0, stream, p, part);
   else WSL_LAUNCH(bnact_bwd_reduce_kernel, grid, dim3(kThreads), 0, stream, p, part);
-  WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, N * p.chunks, C, (int64_t)C, (int64_t)1,
+  WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(finalize_threads(N * p.chunks)), 0, stream, part, N * p.chunks, C, (int64_t)C, (int64_t)1,
              (double)N * H * W, dgamma, dbeta, coef);
   // (the partial sums were consumed by the finalize kernel: their area now takes the apply pass' partial maxima)
   uint32_t* pmax = dy_amax ? reinterpret_cast<uint32_t*>(part) : nullptr;
@@ -835,7 +851,7 @@ extern "C" int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const flo
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool vec = (H * W) % 4 == 0 && (g_bs % 4) == 0 && al16(g) && al16(y) && al16(dy) &&
                    (!emask || (reinterpret_cast<uintptr_t>(emask) & 3) == 0);
-  WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, stream, part, nblk, C,
+  WSL_LAUNCH(bnact_bwd_finalize_kernel, dim3(C), dim3(finalize_threads(nblk)), 0, stream, part, nblk, C,
              channel_major ? (int64_t)1 : (int64_t)C, channel_major ? (int64_t)nblk : (int64_t)1, (double)N * H * W, dgamma, dbeta,
              coef);
   uint32_t* pmax = dy_amax ? reinterpret_cast<uint32_t*>(coef + 2 * (size_t)C) : nullptr;

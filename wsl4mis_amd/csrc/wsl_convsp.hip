@@ -294,6 +294,7 @@ struct ConvSpP {
   float* stat_part;
   float* stat_cnt;
   BnBwdEpi bn;              // data-gradient launches: BatchNorm-backward statistics of the consumer of y
+  int stagger;              // EXPERIMENTS build (env WSL_SP_STAGGER): the second half of the workgroups starts that many x 8128 clocks late
   int ablate;               // EXPERIMENTS build (env WSL_SP_ABLATE; results are WRONG by design): 1 no MFMA, 2 no transform / split /
                             // LDS writes after the first commit, 4 no output stores, 8 no global loads after the first request, 16 no weight DMA after the first
 };
@@ -459,6 +460,10 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
       }
   };
 
+#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
+  if (p.stagger > 0 && blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   v4f acc[C::MT][C::NT];
   int buf = 0;            // streamed weights: the buffer of the current chunk
   bool stored = false;    // a tile's output stores were issued AFTER the weight DMA now awaited (uniform)
@@ -725,6 +730,8 @@ static int sp_conv_launch(const WslSrc& a, const WslSrc* b, const void* image, c
   p.tiles_x = W / f.tw, p.tiles_y = H / f.th, p.ntiles = N * p.tiles_x * p.tiles_y;
   static const int ablate = WSL_TUNE("WSL_SP_ABLATE", 0);
   p.ablate = ablate;
+  static const int stagger = WSL_TUNE("WSL_SP_STAGGER", 0);
+  p.stagger = stagger;
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
   if (bn && bn->part && f.th * f.tw * f.co_t <= 8192) p.bn = *bn;   // instantiations with <= 32 accumulator registers
   if (bn_done) *bn_done = p.bn.part ? 1 : 0;
