@@ -294,7 +294,10 @@ struct ConvSpP {
   float* stat_part;
   float* stat_cnt;
   BnBwdEpi bn;              // data-gradient launches: BatchNorm-backward statistics of the consumer of y
-  int stagger;              // EXPERIMENTS build (env WSL_SP_STAGGER): the second half of the workgroups starts that many x 8128 clocks late
+  int stagger;              // EXPERIMENTS build (env WSL_SP_STAGGER = k, WSL_SP_STAGGER_MODE): k x ~1 us of s_sleep before the tile loop for
+                            // mode 0 the second half of the grid, mode 1 every second workgroup to ARRIVE on a CU (ticket per CU from HW_ID)
+  int stagger_mode;
+  int* cu_tickets;
   int ablate;               // EXPERIMENTS build (env WSL_SP_ABLATE; results are WRONG by design): 1 no MFMA, 2 no transform / split /
                             // LDS writes after the first commit, 4 no output stores, 8 no global loads after the first request, 16 no weight DMA after the first
 };
@@ -461,8 +464,23 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
   };
 
 #if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
-  if (p.stagger > 0 && blockIdx.x >= gridDim.x / 2)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  if (p.stagger > 0) {
+    bool late = blockIdx.x >= gridDim.x / 2;
+    if (p.stagger_mode == 1) {
+      // HW_ID (hwreg 4): CU_ID [11:8], SH_ID [12], SE_ID [15:13]; XCC_ID (hwreg 20) [3:0]
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
+      int ticket = 0;
+      if (tid == 0) ticket = atomicAdd(p.cu_tickets + key, 1);
+      int* flag = reinterpret_cast<int*>(red);   // (free until the first epilogue; no static LDS: the 16-wide blocks sit at an allocation-unit edge)
+      if (tid == 0) *flag = ticket & 1;
+      __syncthreads();
+      late = *flag != 0;
+      __syncthreads();
+    }
+    if (late)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  }
 #endif
   v4f acc[C::MT][C::NT];
   int buf = 0;            // streamed weights: the buffer of the current chunk
@@ -730,8 +748,18 @@ static int sp_conv_launch(const WslSrc& a, const WslSrc* b, const void* image, c
   p.tiles_x = W / f.tw, p.tiles_y = H / f.th, p.ntiles = N * p.tiles_x * p.tiles_y;
   static const int ablate = WSL_TUNE("WSL_SP_ABLATE", 0);
   p.ablate = ablate;
-  static const int stagger = WSL_TUNE("WSL_SP_STAGGER", 0);
-  p.stagger = stagger;
+  static const int stagger = WSL_TUNE("WSL_SP_STAGGER", 0), stagger_mode = WSL_TUNE("WSL_SP_STAGGER_MODE", 0);
+  p.stagger = stagger, p.stagger_mode = stagger_mode, p.cu_tickets = nullptr;
+#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
+  if (stagger > 0 && stagger_mode == 1) {
+    static int* tickets = nullptr;
+    if (!tickets) {
+      (void)hipMalloc(&tickets, 4096 * sizeof(int));
+      (void)hipMemset(tickets, 0, 4096 * sizeof(int));
+    }
+    p.cu_tickets = tickets;
+  }
+#endif
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
   if (bn && bn->part && f.th * f.tw * f.co_t <= 8192) p.bn = *bn;   // instantiations with <= 32 accumulator registers
   if (bn_done) *bn_done = p.bn.part ? 1 : 0;
