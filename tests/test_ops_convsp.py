@@ -22,6 +22,7 @@ CASES = [  # N, H, W, Ca, Cb, Co, transforms on a
     (1, 16, 16, 64, 0, 16, False),
     (3, 8, 32, 16, 16, 128, True),
     (1, 8, 128, 16, 16, 16, True),        # more than one tile per row at 16 output channels
+    (2, 16, 16, 32, 0, 64, "bn"),        # 16-column tiles with a 64-wide output block (the 16 x 16 level's form)
 ]
 # sizes at which the GPU launches take the shapes of the full-size step: 64-channel output blocks with streamed weight blocks,
 # several tiles per persistent workgroup, weight-gradient runs of several tiles per split (the emulator reaches the same code with
@@ -32,6 +33,7 @@ BIG = [
     (48, 32, 32, 128, 0, 128, "bn"),
     (8, 128, 128, 32, 0, 32, True),
     (8, 256, 256, 16, 16, 16, True),      # the full-resolution decoder layer: wide tiles, persistent workgroups over many tiles
+    (64, 16, 16, 128, 0, 256, "bn"),     # the deepest encoder layer as the step runs it: 8 x 16 tiles, 64-wide blocks
 ]
 
 

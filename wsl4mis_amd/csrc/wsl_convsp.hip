@@ -88,16 +88,19 @@ __device__ __forceinline__ void sp_tasks_init(SpTasks<I::NR>& t, int tid, int y0
 template <typename I>
 __device__ __forceinline__ void sp_issue(const SpTasks<I::NR>& t, SpRegs<I::NR>& g, const float* xs, const uint8_t* ms, int chb,
                                          int HW) {
+  // address = uniform base of the channel (scalar registers) + the thread's 32-bit element offset: one vector register per task instead of
+  // a 64-bit vector add per load (the kernels are short of vector issue slots)
+  const float* xc = xs + (int64_t)chb * HW;
+  const uint8_t* mc = ms ? ms + (int64_t)chb * HW : nullptr;
 #pragma unroll
   for (int r = 0; r < I::NR; ++r) {
     g.valid[r] = t.valid[r];
-    const float* xb = xs + (int64_t)(chb + t.oct[r] * 8) * HW + t.toff[r];
+    const uint32_t off = (uint32_t)(t.oct[r] * 8 * HW) + t.toff[r];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) g.v[r][c] = *reinterpret_cast<const float4*>(xb + (int64_t)c * HW);
+    for (int c = 0; c < 8; ++c) g.v[r][c] = *reinterpret_cast<const float4*>(xc + (int64_t)c * HW + off);
     if (ms) {
-      const uint8_t* mb = ms + (int64_t)(chb + t.oct[r] * 8) * HW + t.toff[r];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) g.m[r][c] = *reinterpret_cast<const uint32_t*>(mb + (int64_t)c * HW);
+      for (int c = 0; c < 8; ++c) g.m[r][c] = *reinterpret_cast<const uint32_t*>(mc + (int64_t)c * HW + off);
     }
   }
 }
@@ -130,10 +133,17 @@ __device__ __forceinline__ float sp_f4(const float4& v, int i) { return i == 0 ?
 // image write zero slots.
 // CMSH: the multipliers are not read from `cml` but from `cm_lane` -- lane l of every wave holds the multiplier of channel (l & 15) of the
 // 16-channel chunk (requested with the tile data: a load issued HERE would have to wait for every store and prefetch in flight).
-template <typename I, bool CMSH = false>
-__device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const SpCoef<I::NR>& cf,
-                                          float cmul, const float* cml, int tc0, bool has_scale, bool has_mask, bool has_cm, float es, bool has_mul,
-                                          float mul, bool zero_fill, float cm_lane = 1.f) {
+// MODE: the four loader switches as compile-time constants (bit 0 has_scale, 1 has_mask, 2 has_cm, 3 has_mul) or -1 = the run-time
+// arguments.  With run-time switches hipcc if-converts the per-channel `if (has_...)` blocks: it computes EVERY transform for every value
+// and selects (2 v_cndmask per value pair and switch) -- ~530 vector instructions per task where a BatchNorm source needs ~300 and a
+// gradient ~120, in a kernel that is bound by its vector + matrix issue slots (profiles/r4_conv_sp_where_the_time_goes.md section 5).
+// sp_commit() branches ONCE per task on the (uniform) switches to the three forms the networks use and keeps the generic one for the rest.
+template <typename I, bool CMSH, int MODE>
+__device__ __forceinline__ void sp_commit_mode(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const SpCoef<I::NR>& cf,
+                                               float cmul, const float* cml, int tc0, bool has_scale_, bool has_mask_, bool has_cm_, float es,
+                                               bool has_mul_, float mul, bool zero_fill, float cm_lane) {
+  const bool has_scale = MODE < 0 ? has_scale_ : (MODE & 1) != 0, has_mask = MODE < 0 ? has_mask_ : (MODE & 2) != 0;
+  const bool has_cm = MODE < 0 ? has_cm_ : (MODE & 4) != 0, has_mul = MODE < 0 ? has_mul_ : (MODE & 8) != 0;
 #pragma unroll
   for (int r = 0; r < I::NR; ++r) {
     float cmv[8];
@@ -184,6 +194,19 @@ __device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<
       }
     }
   }
+}
+
+template <typename I, bool CMSH = false>
+__device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const SpCoef<I::NR>& cf,
+                                          float cmul, const float* cml, int tc0, bool has_scale, bool has_mask, bool has_cm, float es, bool has_mul,
+                                          float mul, bool zero_fill, float cm_lane = 1.f) {
+#define WSL_SP_COMMIT(MODE_) sp_commit_mode<I, CMSH, MODE_>(t, g, img, cf, cmul, cml, tc0, has_scale, has_mask, has_cm, es, has_mul, mul, zero_fill, cm_lane)
+  const int mode = (has_scale ? 1 : 0) | (has_mask ? 2 : 0) | (has_cm ? 4 : 0) | (has_mul ? 8 : 0);   // uniform
+  if (mode == 1) WSL_SP_COMMIT(1);         // BatchNorm source
+  else if (mode == 3) WSL_SP_COMMIT(3);    // BatchNorm source with the keep mask of its Dropout
+  else if (mode == 8) WSL_SP_COMMIT(8);    // plain source scaled to the operand range: gradients, the upsampled tensor
+  else WSL_SP_COMMIT(-1);
+#undef WSL_SP_COMMIT
 }
 
 // byte offset of staged column c inside a row
@@ -608,7 +631,9 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
         }
       }
       {
-        float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + wave * RPW) * W + x0 + (lane >> 4) * 4;
+        // (uniform base per store + one 32-bit lane offset: see sp_issue)
+        float* yb = p.y + n * p.y_bs + (int64_t)co0 * HW + (int64_t)(y0 + wave * RPW) * W + x0;
+        const uint32_t lane_off = (uint32_t)((lane & 15) * HW + (lane >> 4) * 4);
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) {
           float* yj = yb + (int64_t)j * 16 * HW;
@@ -616,7 +641,7 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
           for (int i = 0; i < C::MT; ++i) {
             const v4f v = acc[i][j];
             if (!WSL_ABLATED(p, 4) || v[0] == 123.456f)
-              *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16 + lane_off) = make_float4(v[0], v[1], v[2], v[3]);
           }
         }
         stored = true;
@@ -672,7 +697,7 @@ struct SpPlan {
 };
 // tile shape per layer: 8 x 32 pixels (8 x 16 below 32 columns), the widest output-channel block that still leaves >= 2
 // workgroups per CU
-static SpPlan sp_plan(int N, int H, int W, int Ci, int Co) {
+static SpPlan sp_plan(int N, int H, int W, int Ci, int Co, bool want_bn_epilogue = false) {
   SpPlan f{0, 0, 0, false};
   if (Ci <= 0 || Co <= 0 || (Ci % 16) || (Co % 16) || Ci > kSpMaxC) return f;
   // (4 x 128 tiles for the 16-channel layers -- 544-byte instead of 160-byte runs per halo row, 3.7 against 2.5 TB/s of pure tile fetch in
@@ -684,7 +709,11 @@ static SpPlan sp_plan(int N, int H, int W, int Ci, int Co) {
   const int64_t tiles = (int64_t)N * (H / f.th) * (W / f.tw);
   f.co_t = 16;
   if (Co % 32 == 0) f.co_t = 32;
-  if (Co % 64 == 0 && f.tw == 32 && tiles * (Co / 64) >= 2 * device_cu_count()) f.co_t = 64;   // (8 x 16 x 64 spills)
+  // 64-wide blocks wherever they still fill the chip twice: a staged tile (its ~250 vector instructions per thread and chunk are what the
+  // kernel is short of) then feeds 240 / 120 MFMAs per wave instead of 120 / 60
+  // (16-column tiles: not where the caller wants the BatchNorm-backward statistics from the epilogue -- only blocks of <= 2 column tiles
+  //  have the registers for them, and at 16 x 16 the stand-alone reduction pass costs more than the wider block saves)
+  if (Co % 64 == 0 && tiles * (Co / 64) >= 2 * device_cu_count() && !(want_bn_epilogue && f.tw == 16)) f.co_t = 64;
   f.ok = true;
   return f;
 }
@@ -723,7 +752,7 @@ static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
 
 template <int TH, int TW, int CO_T, bool BRES>
 static int launch_conv_sp_epi(ConvSpP& p, int epi, int is_dgrad, void* stream) {
-  if constexpr (TH * TW * CO_T <= 8192)   // instantiations with <= 32 accumulator registers
+  if constexpr (TH * TW * CO_T <= 8192 && CO_T <= 32)   // instantiations with <= 32 accumulator registers in <= 2 column tiles
     if (epi == 2) return launch_conv_sp<TH, TW, CO_T, BRES, 2>(p, is_dgrad, stream);
   if (epi == 1) return launch_conv_sp<TH, TW, CO_T, BRES, 1>(p, is_dgrad, stream);
   return launch_conv_sp<TH, TW, CO_T, BRES, 0>(p, is_dgrad, stream);
@@ -744,7 +773,7 @@ static int sp_conv_launch(const WslSrc& a, const WslSrc* b, const void* image, c
   p.b = (b && b->C > 0) ? to_spsrc(*b) : SpSrc{};
   p.img = static_cast<const wsl_u4*>(image), p.w_amax = w_amax, p.in_amax = in_amax;
   p.bias = bias, p.y = y, p.y_bs = y_bs, p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
-  const SpPlan f = sp_plan(N, H, W, p.Ci, Co);
+  const SpPlan f = sp_plan(N, H, W, p.Ci, Co, bn && bn->part);
   p.tiles_x = W / f.tw, p.tiles_y = H / f.th, p.ntiles = N * p.tiles_x * p.tiles_y;
   static const int ablate = WSL_TUNE("WSL_SP_ABLATE", 0);
   p.ablate = ablate;
@@ -761,14 +790,14 @@ static int sp_conv_launch(const WslSrc& a, const WslSrc* b, const void* image, c
   }
 #endif
   p.stat_part = stat_part, p.stat_cnt = stat_cnt;
-  if (bn && bn->part && f.th * f.tw * f.co_t <= 8192) p.bn = *bn;   // instantiations with <= 32 accumulator registers
+  if (bn && bn->part && f.th * f.tw * f.co_t <= 8192 && f.co_t <= 32) p.bn = *bn;   // instantiations with <= 32 accumulator registers in <= 2 column tiles
   if (bn_done) *bn_done = p.bn.part ? 1 : 0;
   const bool bres = p.Ci * f.co_t <= 1024;   // the block's weight image of every chunk stays in LDS (<= 40 KB)
   const int epi = p.bn.part ? 2 : (p.stat_part ? 1 : 0);
 #define WSL_CASE(TH_, TW_, CO_)                                                    \
   if (f.th == TH_ && f.tw == TW_ && f.co_t == CO_)                                 \
     return bres ? launch_conv_sp_epi<TH_, TW_, CO_, true>(p, epi, is_dgrad, stream) : launch_conv_sp_epi<TH_, TW_, CO_, false>(p, epi, is_dgrad, stream);
-  WSL_CASE(8, 32, 16) WSL_CASE(8, 32, 32) WSL_CASE(8, 32, 64) WSL_CASE(8, 16, 16) WSL_CASE(8, 16, 32)
+  WSL_CASE(8, 32, 16) WSL_CASE(8, 32, 32) WSL_CASE(8, 32, 64) WSL_CASE(8, 16, 16) WSL_CASE(8, 16, 32) WSL_CASE(8, 16, 64)
 #undef WSL_CASE
   set_error("sp_conv: no kernel for tile %dx%d co_t %d", f.th, f.tw, f.co_t);
   return WSL_EUNSUPPORTED;
