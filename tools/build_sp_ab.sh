@@ -8,6 +8,6 @@ name="$1"; shift
 [ -f "$src/libwslhip.so" ] || "$src/build.sh" > /dev/null
 mkdir -p "$root/tools/exp/build"
 objs=$(ls "$src"/build/*.o | grep -v "wsl_convsp.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize "$@" -c "$src/wsl_convsp.hip" -o "$root/tools/exp/build/wsl_convsp_$name.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$src/wsl_convsp.hip" -o "$root/tools/exp/build/wsl_convsp_$name.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs "$root/tools/exp/build/wsl_convsp_$name.o" -o "$root/tools/exp/libwslhip_$name.so"
 echo "built tools/exp/libwslhip_$name.so"

@@ -23,9 +23,7 @@ for s in "${srcs[@]}"; do
     # the Winograd kernels are bound by their vector-instruction count: the SLP vectoriser packs the output transforms into
     # v_pk_add_f32 and then pays more v_mov_b32 to un-interleave the results than it saved (-8 % vector instructions without)
     [ "$s" = "wsl_conv5" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
-    # the split-precision kernels are bound by their vector + matrix issue slots too: the SLP vectoriser turns the two remainder
-    # subtractions of an operand pair into one v_pk_add_f32 (two issue slots, like the two v_sub_f32) plus two v_mov_b32 to pair the operands
-    [ "$s" = "wsl_convsp" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
+    # (wsl_convsp: measured neutral there -- it removes 24 v_mov_b32 per staged task and costs the 16-wide data-gradient kernel a spill)
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra -c "$here/$s.hip" -o "$o" &
     pids+=($!)
   fi
@@ -45,7 +43,7 @@ if [ "${1:-}" = "exp" ] || [ "${2:-}" = "exp" ]; then
     xobjs+=("$o")
     if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$here/wsl_debug.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
       extra=""
-      { [ "$s" = "wsl_conv5" ] || [ "$s" = "wsl_convsp" ]; } && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
+      [ "$s" = "wsl_conv5" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
       "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DWSL_EXPERIMENTS $extra -c "$here/$s.hip" -o "$o" &
       pids+=($!)
     fi

@@ -633,7 +633,9 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
       {
         // (uniform base per store + one 32-bit lane offset: see sp_issue)
         float* yb = p.y + n * p.y_bs + (int64_t)co0 * HW + (int64_t)(y0 + wave * RPW) * W + x0;
-        const uint32_t lane_off = (uint32_t)((lane & 15) * HW + (lane >> 4) * 4);
+        int lv = lane;
+        WSL_DETACH32(lv);   // (recomputed per tile: hoisted out of the tile loop it is one more register live across everything)
+        const uint32_t lane_off = (uint32_t)((lv & 15) * HW + (lv >> 4) * 4);
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) {
           float* yj = yb + (int64_t)j * 16 * HW;
