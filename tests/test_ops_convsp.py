@@ -23,6 +23,7 @@ CASES = [  # N, H, W, Ca, Cb, Co, transforms on a
     (3, 8, 32, 16, 16, 128, True),
     (1, 8, 128, 16, 16, 16, True),        # more than one tile per row at 16 output channels
     (2, 16, 16, 32, 0, 64, "bn"),        # 16-column tiles with a 64-wide output block (the 16 x 16 level's form)
+    (1, 8, 32, 32, 16, 32, "bn_cm"),     # loader switches outside the four specialised staging forms
 ]
 # sizes at which the GPU launches take the shapes of the full-size step: 64-channel output blocks with streamed weight blocks,
 # several tiles per persistent workgroup, weight-gradient runs of several tiles per split (the emulator reaches the same code with
@@ -73,6 +74,8 @@ def test_sp_conv_fwd_dgrad_wgrad(be, case):
     if tr is True:
         emask = (rng.random((N, Ca, H, W)) > 0.3).astype(np.uint8)
         es = float(np.float32(1 / 0.7))
+        cmask = ((rng.random((N, Ca)) > 0.5) * 2.0).astype(np.float32)
+    if tr == "bn_cm":      # BatchNorm source with channel multipliers but no keep mask: no network has it -- the staging code's generic form
         cmask = ((rng.random((N, Ca)) > 0.5) * 2.0).astype(np.float32)
     va = virt_input(xa, scale, shift, emask, es, cmask)
     vin = (torch.cat([va, torch.from_numpy(xb)], 1) if Cb else va).requires_grad_()

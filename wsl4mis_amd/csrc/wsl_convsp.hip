@@ -137,7 +137,7 @@ __device__ __forceinline__ float sp_f4(const float4& v, int i) { return i == 0 ?
 // arguments.  With run-time switches hipcc if-converts the per-channel `if (has_...)` blocks: it computes EVERY transform for every value
 // and selects (2 v_cndmask per value pair and switch) -- ~530 vector instructions per task where a BatchNorm source needs ~300 and a
 // gradient ~120, in a kernel that is bound by its vector + matrix issue slots (profiles/r4_conv_sp_where_the_time_goes.md section 5).
-// sp_commit() branches ONCE per task on the (uniform) switches to the three forms the networks use and keeps the generic one for the rest.
+// sp_commit() branches ONCE per task on the (uniform) switches to the four forms the networks use and keeps the generic one for the rest.
 template <typename I, bool CMSH, int MODE>
 __device__ __forceinline__ void sp_commit_mode(const SpTasks<I::NR>& t, const SpRegs<I::NR>& g, unsigned char* img, const SpCoef<I::NR>& cf,
                                                float cmul, const float* cml, int tc0, bool has_scale_, bool has_mask_, bool has_cm_, float es,
@@ -204,6 +204,7 @@ __device__ __forceinline__ void sp_commit(const SpTasks<I::NR>& t, const SpRegs<
   const int mode = (has_scale ? 1 : 0) | (has_mask ? 2 : 0) | (has_cm ? 4 : 0) | (has_mul ? 8 : 0);   // uniform
   if (mode == 1) WSL_SP_COMMIT(1);         // BatchNorm source
   else if (mode == 3) WSL_SP_COMMIT(3);    // BatchNorm source with the keep mask of its Dropout
+  else if (mode == 7) WSL_SP_COMMIT(7);    // ... and the channel multipliers of a Dropout2d on top (the auxiliary decoder's skip features)
   else if (mode == 8) WSL_SP_COMMIT(8);    // plain source scaled to the operand range: gradients, the upsampled tensor
   else WSL_SP_COMMIT(-1);
 #undef WSL_SP_COMMIT
