@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-split-record", action="store_true",
                     help="by default an f32 run is followed by the SAME workload on the split-precision conv path (own engine, own "
                          "warm-up, >= 20 timed steps, own serialised roofline segment), nested as \"split_f16x3\" in the one JSON line")
+    ap.add_argument("--lib", default=None, help="A/B timing only: another hipcc build of libwslhip.so (e.g. tools/exp/libwslhip_prev.so) instead "
+                    "of the in-tree product library; the line says so in config.library")
     ap.add_argument("--batch", type=int, default=64, help="slices per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--loss", default="pce_gatedcrf", choices=["pce_gatedcrf", "ours_proposed", "pce", "mean_teacher", "ustm", "pce_tv", "pce_ms", "pce_entropy", "ce_dice"])
@@ -179,6 +181,8 @@ def main():
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                 device_id=torch.device("cuda", local))
     from wsl4mis_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     from wsl4mis_amd.engine import TrainEngine
     from wsl4mis_amd.synthetic import batch
     dev = torch.device("cuda", local)
@@ -474,7 +478,7 @@ def main():
                "config": {"workload": f"{args.net} {args.loss}" + (f" r={args.crf_radius}" if args.loss == "pce_gatedcrf" else "")
                           + f", {args.size}x{args.size}x1 4-class synthetic scribble slices, batch {args.batch}/GPU, SGD+poly LR",
                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "crf_radius": args.crf_radius,
-                          "conv_precision": args.conv_precision},
+                          "conv_precision": args.conv_precision, **({"library": args.lib} if args.lib else {})},
                "whole_step_conv_mfma_frac": round(value / world * gflop * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
                "roofline": roof, "kernels": fams, "last_losses": {k: round(v, 5) for k, v in losses.items()}}
         if split_rec:
