@@ -475,16 +475,18 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
   auto dma_weights = [&](int c0, int buf) __attribute__((always_inline)) {
     const wsl_u4* wb = p.img + (int64_t)(c0 >> 4) * chunk_pieces + co0;
     unsigned char* dst = b_img + (size_t)buf * C::B_BYTES;
-    // piece offsets recomputed here (a shift, a mask, a multiply-add each) from a thread index hipcc cannot trace back to threadIdx:
-    // hoisted out of the tile loop they would be NBW more registers live across everything
-    int tv = tid;
+    // piece u = tid + 256 i of the block lies (u / CO_T) * Co + u % CO_T pieces into the image chunk; 256 % CO_T == 0, so piece i of a
+    // thread is its piece 0 plus i * (256 / CO_T) * Co -- a UNIFORM step that goes into the scalar base.  One vector offset per item (four
+    // instructions, from a thread index hipcc cannot trace back to threadIdx: hoisted out of the tile loop it would be one more register
+    // live across everything) instead of ten 64-bit vector address computations: the kernel is short of vector issue slots.
+    unsigned tv = (unsigned)tid;
     WSL_DETACH32(tv);
+    const uint32_t off0 = ((tv / (unsigned)CO_T) * (unsigned)Co + (tv % (unsigned)CO_T)) * 16u;
+    static_assert(kThreads % CO_T == 0, "piece step is uniform");
 #pragma unroll
     for (int i = 0; i < C::NBW; ++i)
-      if ((i + 1) * kThreads <= C::B_PIECES || (i * kThreads + wave * 64) < C::B_PIECES) {   // whole waves (B_PIECES % 64 == 0)
-        const int u = tv + i * kThreads;
-        WSL_LDS_DMA16_UNTRACKED(wb + ((u / CO_T) * Co + (u % CO_T)), dst + (size_t)(i * kThreads + wave * 64) * 16);
-      }
+      if ((i + 1) * kThreads <= C::B_PIECES || (i * kThreads + wave * 64) < C::B_PIECES)   // whole waves (B_PIECES % 64 == 0)
+        WSL_LDS_DMA16_UNTRACKED_SO(wb + (int64_t)i * (kThreads / CO_T) * Co, off0, dst + (size_t)(i * kThreads + wave * 64) * 16);
   };
 
 #if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
@@ -716,7 +718,10 @@ static SpPlan sp_plan(int N, int H, int W, int Ci, int Co, bool want_bn_epilogue
   // kernel is short of) then feeds 240 / 120 MFMAs per wave instead of 120 / 60
   // (16-column tiles: not where the caller wants the BatchNorm-backward statistics from the epilogue -- only blocks of <= 2 column tiles
   //  have the registers for them, and at 16 x 16 the stand-alone reduction pass costs more than the wider block saves)
-  if (Co % 64 == 0 && tiles * (Co / 64) >= 2 * device_cu_count() && !(want_bn_epilogue && f.tw == 16)) f.co_t = 64;
+#ifndef WSL_SP_BN_CAP32
+#define WSL_SP_BN_CAP32 0   // (A / B: 1 = never a 64-wide block where the BatchNorm-backward statistics are wanted from the epilogue)
+#endif
+  if (Co % 64 == 0 && tiles * (Co / 64) >= 2 * device_cu_count() && !(want_bn_epilogue && (f.tw == 16 || WSL_SP_BN_CAP32))) f.co_t = 64;
   f.ok = true;
   return f;
 }

@@ -21,6 +21,8 @@ typedef wsl_v4f v4f;
 #define WSL_WAIT_ALL()
 #define WSL_LDS_BARRIER() __syncthreads()
 #define WSL_LDS_DMA16_UNTRACKED(gsrc, lds_wave_base) wsl_emu_lds_dma16(gsrc, lds_wave_base)
+#define WSL_LDS_DMA16_UNTRACKED_SO(base_uniform, byte_off, lds_wave_base) \
+  wsl_emu_lds_dma16(reinterpret_cast<const unsigned char*>(base_uniform) + (byte_off), lds_wave_base)
 #define WSL_VM_WAIT(n)
 #define WSL_SCHED_BARRIER()
 typedef wsl_emu_u4 wsl_u4;
@@ -67,6 +69,18 @@ __device__ __forceinline__ void wsl_lds_dma16_untracked(const void* gsrc, void* 
                : "memory");
 }
 #define WSL_LDS_DMA16_UNTRACKED(gsrc, lds_wave_base) wsl_lds_dma16_untracked(gsrc, lds_wave_base)
+// ... with the source as a wave-uniform base (scalar registers) + a 32-bit byte offset per lane: no 64-bit vector address arithmetic
+__device__ __forceinline__ void wsl_lds_dma16_untracked_so(const void* base_uniform, uint32_t byte_off, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  const uint64_t b = (uint64_t)(size_t)base_uniform;
+  const uint64_t bs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(byte_off), "s"(bs), "s"(dst)
+               : "memory");
+}
+#define WSL_LDS_DMA16_UNTRACKED_SO(base_uniform, byte_off, lds_wave_base) wsl_lds_dma16_untracked_so(base_uniform, byte_off, lds_wave_base)
 #define WSL_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // keeps the instruction scheduler from moving LDS reads / MFMAs across a software-pipeline stage boundary
 #define WSL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
