@@ -17,6 +17,9 @@
 // (conflict-free ds_write_b128), and the 16 pixels of an MFMA row tile still fall into 16 different 16-byte bank groups.
 #include "wsl_rt.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace wsl {
 
 struct SpSrc {           // one source, device view
@@ -326,6 +329,11 @@ struct ConvSpP {
                             // LDS writes after the first commit, 4 no output stores, 8 no global loads after the first request, 16 no weight DMA after the first
 };
 
+template <typename F, int... Is>
+__device__ __forceinline__ void sp_for_each_index(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
 template <int TH, int TW, int CO_T>
 struct ConvSpCfg {
   using Img = SpImg<TH + 2, (TW + 8) / 4, 2>;
@@ -559,6 +567,69 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
       WSL_DETACH32(lv);
       operand_offsets(lv);
     }
+#ifndef WSL_SP_PIPE
+#define WSL_SP_PIPE 0     // (EXPERIMENT, not in the product: 1 = operands of the next group of MFMAs read while the current group issues, the
+                          //  order pinned with sched_group_barrier; profiles/r4_conv_sp_where_the_time_goes.md section 5 (a))
+#endif
+#if WSL_SP_PIPE && !defined(WSL_HOST_EMUL)
+#define WSL_SP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#else
+#define WSL_SP_SGB(mask, n)
+#endif
+    constexpr bool kPipe = WSL_SP_PIPE && C::NT <= 2;
+    if constexpr (kPipe) {
+      // groups g = (K-step s, row-tile pair i0): A operands double-buffered per group, B operands per K-step
+      constexpr int GPS = C::MT / 2, G = 5 * GPS;
+      wsl_u4 Ah[2][2], Al[2][2], Bh[2][C::NT], Bl[2][C::NT];
+      auto load_b = [&](int s, int bb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+          const unsigned char* q = b_c + bbase + (s * 4 * CO_T + j * 16) * 16;
+          Bh[bb][j] = *reinterpret_cast<const wsl_u4*>(q);
+          Bl[bb][j] = *reinterpret_cast<const wsl_u4*>(q + 5 * 4 * CO_T * 16);
+        }
+      };
+      auto load_a = [&](int g, int ab) __attribute__((always_inline)) {
+        const int s = g / GPS, i0 = 2 * (g % GPS);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int mt = wave * C::MT + i0 + d;
+          const unsigned char* q = a_img + aoff[s] + (mt / C::SEGS) * I::ROWB + (mt % C::SEGS) * 64;
+          Ah[ab][d] = *reinterpret_cast<const wsl_u4*>(q), Al[ab][d] = *reinterpret_cast<const wsl_u4*>(q + I::HL);
+        }
+      };
+      auto group = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value, s = g / GPS, i0 = 2 * (g % GPS);
+        constexpr bool more = g + 1 < G, new_step = more && (g + 1) % GPS == 0;
+        constexpr int nload = (more ? 4 : 0) + (new_step ? 2 * C::NT : 0), NM = 6 * C::NT, il = nload < NM ? nload : NM;
+        if constexpr (new_step) load_b(s + 1, (s + 1) & 1);
+        if constexpr (more) load_a(g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int i = i0 + d;
+#pragma unroll
+          for (int j = 0; j < C::NT; ++j) {
+            acc[i][j] = WSL_MFMA_F16(Ah[g & 1][d], Bl[s & 1][j], acc[i][j]);
+            acc[i][j] = WSL_MFMA_F16(Al[g & 1][d], Bh[s & 1][j], acc[i][j]);
+            acc[i][j] = WSL_MFMA_F16(Ah[g & 1][d], Bh[s & 1][j], acc[i][j]);
+          }
+        }
+        // issue order of this group: one operand read of the NEXT group behind each of the first MFMAs, the remaining MFMAs after
+#pragma unroll
+        for (int k = 0; k < il; ++k) {
+          WSL_SP_SGB(0x008, 1);
+          WSL_SP_SGB(0x100, 1);
+        }
+        if constexpr (nload > il) WSL_SP_SGB(0x100, nload - il);
+        if constexpr (NM > il) WSL_SP_SGB(0x008, NM - il);
+      };
+      if (!WSL_ABLATED(p, 1)) {
+        load_b(0, 0);
+        load_a(0, 0);
+        WSL_SP_SGB(0x100, 2 * C::NT + 4);
+        sp_for_each_index(std::make_integer_sequence<int, G>{}, group);
+      }
+    } else
     if (!WSL_ABLATED(p, 1))
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
