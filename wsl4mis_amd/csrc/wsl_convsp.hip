@@ -576,6 +576,12 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
 #else
 #define WSL_SP_SGB(mask, n)
 #endif
+#ifndef WSL_SP_PRIO
+#define WSL_SP_PRIO 0     // (EXPERIMENT, not in the product: issue priority of a wave raised to this value for the duration of its MFMA loop)
+#endif
+#if WSL_SP_PRIO && !defined(WSL_HOST_EMUL)
+    __builtin_amdgcn_s_setprio(WSL_SP_PRIO);
+#endif
     constexpr bool kPipe = WSL_SP_PIPE && C::NT <= 2;
     if constexpr (kPipe) {
       // groups g = (K-step s, row-tile pair i0): A operands double-buffered per group, B operands per K-step
@@ -665,6 +671,9 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
       // inside the tile loop, and a spill reload is a vector-memory load that waits for every prefetch in flight
       if constexpr (kTightRegs) WSL_SCHED_BARRIER();
     }
+#if WSL_SP_PRIO && !defined(WSL_HOST_EMUL)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     WSL_LDS_BARRIER();   // the tile image and this chunk's weight block are free again
     if constexpr (!BRES && !DB) if (nt < tend && !WSL_ABLATED(p, 16)) dma_weights(nc0, 0);
     if constexpr (DB) buf ^= 1;
