@@ -20,7 +20,6 @@ typedef wsl_v4f v4f;
 #define WSL_LDS_DMA16(gsrc, lds_wave_base) wsl_emu_lds_dma16(gsrc, lds_wave_base)
 #define WSL_WAIT_ALL()
 #define WSL_LDS_BARRIER() __syncthreads()
-#define WSL_LDS_DMA16_UNTRACKED(gsrc, lds_wave_base) wsl_emu_lds_dma16(gsrc, lds_wave_base)
 #define WSL_LDS_DMA16_UNTRACKED_SO(base_uniform, byte_off, lds_wave_base) \
   wsl_emu_lds_dma16(reinterpret_cast<const unsigned char*>(base_uniform) + (byte_off), lds_wave_base)
 #define WSL_VM_WAIT(n)
@@ -60,16 +59,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // owns the wait: WSL_VM_WAIT(n) = at most n vector-memory instructions of this wave still in flight (issue order; loads, stores and
 // DMAs count alike) before the barrier that publishes the block.  hipcc's own vmcnt waits stay correct: it only under-counts the
 // instructions in flight, so it waits longer than needed, never shorter.
-__device__ __forceinline__ void wsl_lds_dma16_untracked(const void* gsrc, void* lds_wave_base) {
-  unsigned keep;
-  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(dst)
-               : "memory");
-}
-#define WSL_LDS_DMA16_UNTRACKED(gsrc, lds_wave_base) wsl_lds_dma16_untracked(gsrc, lds_wave_base)
-// ... with the source as a wave-uniform base (scalar registers) + a 32-bit byte offset per lane: no 64-bit vector address arithmetic
+// The source is a wave-uniform base (scalar registers) + a 32-bit byte offset per lane: no 64-bit vector address arithmetic.
 __device__ __forceinline__ void wsl_lds_dma16_untracked_so(const void* base_uniform, uint32_t byte_off, void* lds_wave_base) {
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
