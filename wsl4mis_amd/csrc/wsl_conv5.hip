@@ -455,6 +455,20 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     const int chb = ina ? c0 : c0 - p.a.C;
     const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
     float* dst = in_b + bsel * C::IN_FLOATS + wave * 256;          // wave-uniform: lane l lands at dst + 4 * l floats
+#ifndef WSL_WINO2R_UNTRACKED
+#define WSL_WINO2R_UNTRACKED 0   // (EXPERIMENT, not in the product: the DMAs issued from inline assembly, so that hipcc does not wait for them
+                                 //  -- vmcnt(0) -- in front of this chunk's first LDS reads; the wait before the barrier is WSL_WAIT_ALL)
+#endif
+#if WSL_WINO2R_UNTRACKED
+    if (pvalid) {
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) WSL_LDS_DMA16_UNTRACKED_SO(xb + i * gstride, (uint32_t)toff * 4u, dst + i * (C::G * C::PLANE));
+    }
+    const float* wb = p.u + (int64_t)cby * C::W_FLOATS + (c0 / KC) * w_cstride;
+    float* wdst = w_b + bsel * C::W_FLOATS + wave * 256;
+#pragma unroll
+    for (int i = 0; i < C::NWL; ++i) WSL_LDS_DMA16_UNTRACKED_SO(wb + i * (4 * kThreads), (uint32_t)tid * 16u, wdst + i * (4 * kThreads));
+#else
     if (pvalid) {
 #pragma unroll
       for (int i = 0; i < C::NLD; ++i) WSL_LDS_DMA16(xb + i * gstride + toff, dst + i * (C::G * C::PLANE));
@@ -463,6 +477,7 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     float* wdst = w_b + bsel * C::W_FLOATS + wave * 256;
 #pragma unroll
     for (int i = 0; i < C::NWL; ++i) WSL_LDS_DMA16(wb + i * (4 * kThreads), wdst + i * (4 * kThreads));
+#endif
   };
 
   issue(0, 0);
