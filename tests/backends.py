@@ -11,6 +11,7 @@ from wsl4mis_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMUL_PATH = os.path.join(ROOT, "tests", "emul", "libwslhip_emul.so")
+EMUL_NEXT_PATH = os.path.join(ROOT, "tests", "emul", "libwslhip_emul_next.so")   # the kernel switches measured but not yet shipped, ON
 
 
 class _Base:
@@ -40,10 +41,10 @@ class EmulBackend(_Base):
     name = "emul"
     stream = None
 
-    def __init__(self):
-        if not os.path.exists(EMUL_PATH):
-            raise FileNotFoundError(EMUL_PATH)
-        self.lib = C.CDLL(EMUL_PATH)
+    def __init__(self, path=EMUL_PATH):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
         _lib.bind(self.lib, strict=False)
 
     def arr(self, a, dtype=None):

@@ -219,3 +219,12 @@ def test_sp_not_eligible(be):
     with pytest.raises(Exception, match="eligible"):
         be.call("wsl_sp_conv2d_fwd", s, be.src(), be.ptr(x), be.ptr(x), None, None, be.ptr(x), 16 * 8 * 32, 1, 8, 32, 16, None, None,
                 be.stream)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[-2]])
+def test_split_conv_with_the_next_rounds_operand_pipelining(case):
+    """The split conv kernels with the MFMA operand reads pipelined by hand (-DWSL_SP_PIPE=1: measured +0.45 % on the split step,
+    profiles/r4_conv_sp_pipelined_operands_experiment.log, not yet in the product): the double-buffered operand indexing stays checked on
+    the emulator (tests/emul/libwslhip_emul_next.so) until a round turns it on."""
+    from conftest import get_backend
+    test_sp_conv_fwd_dgrad_wgrad(get_backend("emul_next"), case)
