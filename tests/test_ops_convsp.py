@@ -223,8 +223,9 @@ def test_sp_not_eligible(be):
 
 @pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[-2]])
 def test_split_conv_with_the_next_rounds_operand_pipelining(case):
-    """The split conv kernels with the MFMA operand reads pipelined by hand (-DWSL_SP_PIPE=1: measured +0.45 % on the split step,
-    profiles/r4_conv_sp_pipelined_operands_experiment.log, not yet in the product): the double-buffered operand indexing stays checked on
-    the emulator (tests/emul/libwslhip_emul_next.so) until a round turns it on."""
+    """The split conv kernels with the MFMA operand reads pipelined by hand (-DWSL_SP_PIPE=1: +0.45 % on the split step,
+    profiles/r4_conv_sp_pipelined_operands_experiment.log).  Checked here, on the emulator library built with the pending kernel switches
+    forced on (tests/emul/libwslhip_emul_next.so), before it became the default at the end of round 4; the mechanism stays for the next
+    pending switch (today both emulator libraries run the same code)."""
     from conftest import get_backend
     test_sp_conv_fwd_dgrad_wgrad(get_backend("emul_next"), case)

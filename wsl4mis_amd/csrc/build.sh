@@ -74,8 +74,9 @@ if [ "${1:-}" = "emul" ] || [ "${2:-}" = "emul" ]; then
   for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
   "$CXX" -shared -fPIC -pthread "${eobjs[@]}" "$em/build/hip_emul.o" -o "$em/libwslhip_emul.so"
   echo "built $em/libwslhip_emul.so"
-  # the same library with the measured-but-not-yet-shipped kernel switches ON (profiles/r4_*_experiment.log): their logic stays checked
-  # on the CPU (tests: backend "emul_next") until a round turns them on in the product
+  # the same library with PENDING kernel switches forced on -- switches measured as off-by-default experiments whose logic stays checked
+  # on the CPU (tests: backend "emul_next") until a round turns them on in the product.  (The two it was built for, WSL_SP_PIPE and
+  # WSL_WINO2R_UNTRACKED, became defaults at the end of round 4: the flags below are no-ops until the next pending switch is added.)
   nobjs=()
   pids=()
   for s in "${srcs[@]}"; do

@@ -456,8 +456,10 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
     float* dst = in_b + bsel * C::IN_FLOATS + wave * 256;          // wave-uniform: lane l lands at dst + 4 * l floats
 #ifndef WSL_WINO2R_UNTRACKED
-#define WSL_WINO2R_UNTRACKED 0   // (EXPERIMENT, not in the product: the DMAs issued from inline assembly, so that hipcc does not wait for them
-                                 //  -- vmcnt(0) -- in front of this chunk's first LDS reads; the wait before the barrier is WSL_WAIT_ALL)
+#define WSL_WINO2R_UNTRACKED 1   // the DMAs are issued from inline assembly (wsl_rt.h), so that hipcc does not wait for them -- vmcnt(0): it must
+                                 // assume that any later LDS read aliases their destination -- in front of THIS chunk's first LDS reads: with the
+                                 // builtin (0) the double buffering never overlapped (+0.7 % on the f32 step).  The wait before the barrier is
+                                 // WSL_WAIT_ALL.
 #endif
 #if WSL_WINO2R_UNTRACKED
     if (pvalid) {

@@ -568,8 +568,9 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
       operand_offsets(lv);
     }
 #ifndef WSL_SP_PIPE
-#define WSL_SP_PIPE 0     // (EXPERIMENT, not in the product: 1 = operands of the next group of MFMAs read while the current group issues, the
-                          //  order pinned with sched_group_barrier; profiles/r4_conv_sp_where_the_time_goes.md section 5 (a))
+#define WSL_SP_PIPE 1     // blocks of <= 32 output channels: operands of the next group of MFMAs read while the current group issues, the order
+                          // pinned with sched_group_barrier (+0.45 % on the split step; 0 = hipcc's own placement;
+                          // profiles/r4_conv_sp_where_the_time_goes.md section 7)
 #endif
 #if WSL_SP_PIPE && !defined(WSL_HOST_EMUL)
 #define WSL_SP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
