@@ -229,3 +229,33 @@ def test_split_conv_with_the_next_rounds_operand_pipelining(case):
     pending switch (today both emulator libraries run the same code)."""
     from conftest import get_backend
     test_sp_conv_fwd_dgrad_wgrad(get_backend("emul_next"), case)
+
+
+def test_lds_residency_of_the_steps_layer_shapes(be):
+    """LDS is handed out in units of 1280 bytes on gfx950 (round 4: a 256-byte table took the 16-wide blocks of 32 input channels from 42
+    to 43 units and with that from three workgroups per CU to two: +21 % on that layer).  The layer shapes of the benchmark step that sit at
+    such an edge, through the library's own residency computation: 16-wide blocks three per CU, everything else two; and nothing the step
+    launches is left with ONE workgroup per CU."""
+    import ctypes as C
+    f = be.lib.wsl_debug_sp_conv_residency
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_int)] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+
+    def residency(N, H, W, Ci, Co, bn=0):
+        th, tw, cot, per = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lds = C.c_size_t()
+        assert f(N, H, W, Ci, Co, bn, C.byref(th), C.byref(tw), C.byref(cot), C.byref(lds), C.byref(per)) == 0
+        return th.value, tw.value, cot.value, lds.value, per.value
+
+    # the full-resolution 16-wide blocks: exactly 42 units with 32 input channels (the coefficient table lives in the image planes' padding)
+    assert residency(64, 256, 256, 16, 16)[2:] == (16, 43520, 3)
+    th, tw, cot, lds, per = residency(64, 256, 256, 32, 16)
+    assert (cot, lds, per) == (16, 42 * 1280, 3), (cot, lds, per)
+    enc = [(16, 32, 128), (32, 32, 128), (32, 64, 64), (64, 64, 64), (64, 128, 32), (128, 128, 32), (128, 256, 16), (256, 256, 16)]
+    dec = [(256, 128, 32), (128, 64, 64), (64, 32, 128)]
+    for Ci, Co, S in enc + dec:
+        for ci, co in ((Ci, Co), (Co, Ci)):                      # forward and data-gradient launch of the layer
+            for bn in (0, 1):
+                cot, lds, per = residency(64, S, S, ci, co, bn)[2:]
+                assert per >= 2 and per * ((lds + 1279) // 1280) * 1280 <= 160 * 1024, (ci, co, S, bn, cot, lds, per)
+    assert f(64, 256, 256, 20, 16, 0, None, None, None, None, None) == 1      # no split kernel for this shape

@@ -807,6 +807,14 @@ static SpPlan sp_plan(int N, int H, int W, int Ci, int Co, bool want_bn_epilogue
   return f;
 }
 
+// workgroups of `smem` bytes of LDS that stay resident on one CU, capped by the register budget (`minw` waves per SIMD).  LDS is handed
+// out in units of 1280 bytes (inferred: 42 units x 3 workgroups ran three per CU, 43 x 3 did not; tests/test_ops_convsp.py pins the
+// layer shapes that sit at such an edge through wsl_debug_sp_conv_residency)
+static int sp_resident_per_cu(size_t smem, int minw) {
+  const int by_lds = (int)((size_t)160 * 1024 / (((smem + 1279) / 1280) * 1280));
+  return by_lds < minw ? by_lds : minw;
+}
+
 template <int TH, int TW, int CO_T, bool BRES, int EPI>
 static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
   using C = ConvSpCfg<TH, TW, CO_T>;
@@ -818,9 +826,7 @@ static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
   }
   const size_t smem = C::smem(p.Ci, BRES);
   // persistent: as many workgroups as stay resident (registers: MINW per SIMD; LDS), spread over the output-channel blocks
-  // (LDS is handed out in units of 1280 bytes -- inferred: 42 units x 3 workgroups ran three per CU, 43 x 3 did not)
-  int per_cu = (int)((size_t)160 * 1024 / (((smem + 1279) / 1280) * 1280));
-  if (per_cu > C::MINW) per_cu = C::MINW;
+  int per_cu = sp_resident_per_cu(smem, C::MINW);
   static const int percu_env = WSL_TUNE("WSL_SP_PERCU", 0);   // (experiments build)
   if (percu_env > 0) per_cu = percu_env;
   if (per_cu < 1) per_cu = 1;
@@ -1153,6 +1159,27 @@ extern "C" int wsl_sp_pack_weights(const float* w, void* image, uint32_t* w_amax
   WSL_LAUNCH(sp_pack_table_kernel, dim3(16, 1, 1), dim3(kThreads), 0, stream, t, io, w, static_cast<unsigned char*>(image),
              static_cast<unsigned char*>(image), w_amax, dgrad ? 1 : 0);
   return check_launch("sp_pack_table_kernel");
+}
+
+// (wsl_debug.h) what a launch of this layer shape would use: tile, block width, LDS bytes per workgroup, resident workgroups per CU
+extern "C" int wsl_debug_sp_conv_residency(int N, int H, int W, int Ci, int Co, int want_bn_epilogue, int* tile_h, int* tile_w, int* co_t,
+                                           size_t* lds_bytes, int* per_cu) {
+  const SpPlan f = sp_plan(N, H, W, Ci, Co, want_bn_epilogue != 0);
+  if (!f.ok) return 1;
+  const bool bres = Ci * f.co_t <= 1024;
+  size_t smem = 0;
+  int minw = 0;
+#define WSL_CASE(TH_, TW_, CO_)                                   \
+  if (f.th == TH_ && f.tw == TW_ && f.co_t == CO_) smem = ConvSpCfg<TH_, TW_, CO_>::smem(Ci, bres), minw = ConvSpCfg<TH_, TW_, CO_>::MINW;
+  WSL_CASE(8, 32, 16) WSL_CASE(8, 32, 32) WSL_CASE(8, 32, 64) WSL_CASE(8, 16, 16) WSL_CASE(8, 16, 32) WSL_CASE(8, 16, 64)
+#undef WSL_CASE
+  if (!smem) return 1;
+  if (tile_h) *tile_h = f.th;
+  if (tile_w) *tile_w = f.tw;
+  if (co_t) *co_t = f.co_t;
+  if (lds_bytes) *lds_bytes = smem;
+  if (per_cu) *per_cu = sp_resident_per_cu(smem, minw);
+  return 0;
 }
 
 extern "C" int wsl_sp_conv2d_stat_blocks(int N, int H, int W, int Ci, int Co) {

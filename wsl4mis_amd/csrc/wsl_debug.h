@@ -29,6 +29,12 @@ int wsl_debug_net_decisions(const struct WslNetDesc* d, const void* ws, size_t w
  * (tools/diff_runs_split.py). */
 int wsl_debug_net_ws_region(const struct WslNetDesc* d, int index, char* name, size_t name_len, size_t* off_floats, size_t* n_floats);
 
+/* What a split-precision conv launch of this layer shape would use: output tile, block width, LDS bytes per workgroup and the number of
+ * workgroups that stay resident per CU (LDS in units of 1280 bytes, register cap).  Returns 1 when the shape has no split kernel.  For the
+ * test that pins the shapes sitting exactly at an LDS allocation-unit edge (tests/test_ops_convsp.py). */
+int wsl_debug_sp_conv_residency(int N, int H, int W, int Ci, int Co, int want_bn_epilogue, int* tile_h, int* tile_w, int* co_t,
+                                size_t* lds_bytes, int* per_cu);
+
 /* Only in the EXPERIMENTS build (-DWSL_EXPERIMENTS: `build.sh exp` -> tools/exp/libwslhip_exp.so, and the host emulator):
  * ablation switches (env WSL_CONV_ABLATE / WSL_WGRAD_ABLATE: they skip
  * work, results are WRONG by design), ~20 env tuning knobs (WSL_TUNE in wsl_rt.h) and three machine probes. */
