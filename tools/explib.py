@@ -7,7 +7,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # WSL_EXP_LIB=old: tools/exp/libwslhip_exp_old.so, a build of another source revision kept next to it for A/B timing
-EXP = os.path.join(ROOT, "tools", "exp", "libwslhip_exp_old.so" if os.environ.get("WSL_EXP_LIB") == "old" else "libwslhip_exp.so")
+_sel = os.environ.get("WSL_EXP_LIB")   # "old" or any other tag: tools/exp/libwslhip_exp_<tag>.so
+EXP = os.path.join(ROOT, "tools", "exp", f"libwslhip_exp_{_sel}.so" if _sel else "libwslhip_exp.so")
 
 
 def use():

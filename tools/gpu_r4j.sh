@@ -2,7 +2,7 @@
 # in-step A / B on ONE box: the split-precision step with the product library against the build before the staging specialisation
 # (tools/exp/libwslhip_prev.so), alternating, three rounds
 O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd "$R"
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
   for v in ${VARIANTS:-product prev}; do
     lib=""; [ "$v" != product ] && lib="--lib tools/exp/libwslhip_$v.so"
     python bench.py --conv-precision ${PREC:-split_f16x3} --steps 40 --warmup 10 --no-split-record --no-cpu-baseline $lib 2>/dev/null | tail -1 > "$O/bench_${v}_$rep.json"

@@ -20,10 +20,13 @@ st = torch.cuda.current_stream().cuda_stream
 N = int(os.environ.get("SWEEP_N", "64"))
 SHAPES = [(16, 16, 256), (32, 16, 256), (32, 32, 128), (64, 32, 128), (64, 64, 64), (128, 64, 64), (128, 128, 32),
           (256, 128, 32), (256, 256, 16)]
+if os.environ.get("SWEEP_SHAPES"):   # e.g. SWEEP_SHAPES="64,64,64;128,64,64" (Ci,Co,S per layer): one layer under a counter pass
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["SWEEP_SHAPES"].split(";")]
+REPS = int(os.environ.get("SWEEP_REPS", "20"))
 L.wsl_conv2d_wgrad_ws_bytes.restype = C.c_size_t
 
 
-def timed(fn, reps=20):
+def timed(fn, reps=REPS):
     for _ in range(3):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -53,12 +53,36 @@ struct WinoP {
 // LDS, no transform pass, two barriers per chunk instead of three, 24 instead of 64 LDS reads + 16 writes per chunk.
 // A wave owns MTW row-groups of 16 tiles and NT channel tiles (MTW * NT = 2: 64 tiles x 32 channels, or -- for the
 // 16-channel layers -- 128 tiles = 8 x 64 pixels x 16 channels).
+// one aligned 8-byte LDS read that the load/store optimiser must not fuse with its neighbour into ds_read2_b64 (that form takes twice
+// the LDS cycles of two ds_read_b64: profiles/r5_probe_lds5.md) -- hence volatile
+// (volatile on a GENERIC pointer would turn the read into flat_load_dwordx2: the address-space inference pass leaves volatile accesses
+//  alone -- so the pointer is cast to the LDS address space first)
+__device__ __forceinline__ wsl_v2f wino_read_pair(const float* p) {
+#ifdef WSL_HOST_EMUL
+  return *reinterpret_cast<const wsl_v2f*>(p);
+#else
+  return *(const volatile __attribute__((address_space(3))) wsl_v2f*)(p);
+#endif
+}
+// a staged float4 goes one float to the right of its 16-byte slot (the shifted image): 4 + 8 + 4 bytes
+__device__ __forceinline__ void wino_store_shifted(float* slot, float a, float b, float c, float d) {
+  slot[1] = a;
+  *reinterpret_cast<float2*>(slot + 2) = make_float2(b, c);
+  slot[4] = d;
+}
+
 template <int TH, int TW, int NT>
 struct Wino2Cfg {
   static constexpr int KC = 8, PADL = 4, CO_T = 16 * NT;
   static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4;
-  static constexpr int G = 256 / POS, NLD = KC / G;
-  static constexpr int PLANE = ((ROWS * ROWP - 16 + 31) / 32) * 32 + 16;   // == 16 (mod 32)
+  static constexpr int G = 256 / POS, NLD = KC / G;   // staging: thread t = float4 position t % POS of plane t / POS of a pass of G planes
+  // LDS image of one channel: ROWS x ROWP floats SHIFTED BY ONE FLOAT (column c of the image holds global column x0 - PADL - 1 + c), so
+  // that a tile's 4 x 4 patch starts at the EVEN offset PADL + 2 * txx and is read as aligned ds_read_b64; planes 32 (mod 64) floats
+  // apart: the two channels of a 32-lane group (lanes = 16 tiles x 2 channels, 8 bytes each) cover the 64 banks exactly once.
+  // (Rounds 1-4: unshifted image, ds_read2_b32 at odd offsets, planes 16 (mod 32): all 32 lanes of a group on the 16 even -- then
+  // the 16 odd -- banks = 2-way conflicts on every patch read and 4x the LDS cycles; profiles/r5_probe_lds5.md.)
+  static constexpr int SHIFT = 1;
+  static constexpr int PLANE = ((ROWS * ROWP + SHIFT - 32 + 63) / 64) * 64 + 32;   // == 32 (mod 64), >= ROWS * ROWP + SHIFT
   static constexpr int TTY = TH / 2, TTX = TW / 2, TILES = TTY * TTX, MTW = TILES / 64, NA = MTW * NT;
   static constexpr int IN_FLOATS = KC * PLANE, W_FLOATS = 16 * KC * CO_T;
   static constexpr int WF4 = W_FLOATS / 4, NWL = WF4 / 256;
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2_
   constexpr int KC = C::KC, CO_T = C::CO_T, MTW = C::MTW;
   WSL_DYN_SMEM(smem);
   float* in_t = reinterpret_cast<float*>(smem);                 // raw (transformed-on-load) halo tile [KC][PLANE]
-  float* w_t = in_t + C::IN_FLOATS;                             // U chunk, operand order: [16 xi][4 k][16 col][2 kg][NT j]
+  float* w_t = in_t + C::IN_FLOATS;                             // U chunk, operand order: [16 xi][2 kg][4 k][16 col][NT j]
   float2* tab = reinterpret_cast<float2*>(w_t + C::W_FLOATS);   // [Ci] {scale, shift}
   float* cm_l = w_t + C::W_FLOATS + 2 * C::MAXC;                // [Ci] channel multiplier of this sample
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -284,7 +308,10 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2_
         if (has_scale) xform_bn_leaky(lo, hi, tb[i].x, tb[i].y);
         if (has_mask) xform_mask(lo, hi, prm[i], es);
         lo = lo * cmv[i], hi = hi * cmv[i];   // (1.0 without a channel mask: exact, and cheaper than selecting)
-        *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(lo[0], lo[1], hi[0], hi[1]);
+        // (4 + 8 + 4 bytes, one float right of the 16-byte slot.  These stores keep 2- / 4-way bank conflicts; the conflict-free form -- one
+        //  aligned ds_write_b128 of {previous lane's last element (v_mov_b32_dpp wave_shr:1), own first three} -- costs more vector and
+        //  branch instructions than the conflicts cost LDS cycles: measured 3-7 % slower per layer here, profiles/r5_wino_lds_layout.md)
+        wino_store_shifted(in_t + i * (C::G * C::PLANE) + loff, lo[0], lo[1], hi[0], hi[1]);
       }
     }
 #pragma unroll
@@ -299,11 +326,6 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2_
     tab[c] = s.scale ? make_float2(s.scale[ch], s.shift[ch]) : make_float2(1.f, 0.f);
     cm_l[c] = s.cmask ? s.cmask[(int64_t)n * s.C + ch] : 1.f;
   }
-  if (owner && !pvalid) {   // positions outside the image stay zero for good
-#pragma unroll
-    for (int i = 0; i < C::NLD; ++i)
-      *reinterpret_cast<float4*>(in_t + i * (C::G * C::PLANE) + loff) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
 
   v4f acc[16][C::NA];   // [xi][m * NT + j]
 #pragma unroll
@@ -315,9 +337,14 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2_
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
     const int t = (wave * MTW + m) * 16 + (lane & 15), tyy = t / C::TTX, txx = t - tyy * C::TTX;
-    poff[m] = (lane >> 4) * C::PLANE + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
+    poff[m] = (lane >> 4) * C::PLANE + (2 * tyy) * C::ROWP + (C::PADL - 1 + C::SHIFT) + 2 * txx;   // even
   }
-  const int b_off = lane * (2 * NT);   // ((k = lane >> 4) * 16 + (col = lane & 15)) * (2 kg * NT j)
+  const int b_off = lane * NT;   // ((k = lane >> 4) * 16 + (col = lane & 15)) * NT j: lanes 2 * NT bytes apart -- a 32-lane group covers
+                                 // every LDS bank exactly once (round 4's [k][col][kg][j] order put lanes l and l + 16 on the same banks)
+  if (owner && !pvalid) {   // positions outside the image stay zero for good
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) wino_store_shifted(in_t + i * (C::G * C::PLANE) + loff, 0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();   // tables visible
 
   // (peeling the first chunk to skip the accumulator clear, as the raw-source kernel does, costs 23 VGPRs here: spills)
@@ -336,11 +363,11 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float* r = in_t + kg * (4 * C::PLANE) + poff[m] + i * C::ROWP;
-          if constexpr (PK) {   // (odd float offset: two ds_read2_b32, each into an aligned register pair)
-            rlo[m][i] = wsl_v2f{r[0], r[1]}, rhi[m][i] = wsl_v2f{r[2], r[3]};
+          const wsl_v2f p0 = wino_read_pair(r), p1 = wino_read_pair(r + 2);   // two ds_read_b64 (even offsets), conflict-free
+          if constexpr (PK) {
+            rlo[m][i] = p0, rhi[m][i] = p1;
           } else {
-            const float2 mm = *reinterpret_cast<const float2*>(r + 1);
-            rd[m][i] = v4f{r[0], mm.x, mm.y, r[3]};
+            rd[m][i] = v4f{p0[0], p0[1], p1[0], p1[1]};
           }
         }
     };
@@ -367,10 +394,10 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2_
       constexpr int BD = NT == 2 ? 4 : 2, BR = BD + 1;   // (the 128-tile variant has no registers to spare)
       float bv[BR][NT];
       auto loadb = [&](int xi, int buf) __attribute__((always_inline)) {
-        const float* bp = w_t + xi * (4 * 16 * 2 * NT) + b_off + kg * NT;
+        const float* bp = w_t + xi * (4 * 16 * 2 * NT) + kg * (4 * 16 * NT) + b_off;
         if constexpr (NT == 2) {
-          const float2 b2 = *reinterpret_cast<const float2*>(bp);
-          bv[buf][0] = b2.x, bv[buf][1] = b2.y;
+          const wsl_v2f b2 = wino_read_pair(bp);   // (never fused into ds_read2st64_b64)
+          bv[buf][0] = b2[0], bv[buf][1] = b2[1];
         } else {
           bv[buf][0] = bp[0];
         }
@@ -397,13 +424,14 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2_
 // filter block need no VGPR round trip -- global_load_lds_dwordx4 streams both into LDS (lane-contiguous layouts: a thread's
 // tile slot is 16 * tid bytes into its plane group, the filter block is linear), double-buffered, so a chunk costs the
 // input transform + MFMAs and ONE barrier: no staging VALU, no LDS writes, no prefetch registers.
+// Same shifted image and plane pitch as Wino2Cfg (the DMA lands 4 bytes past a 16-byte boundary: tools/probe_lds5.hip, probe 2).  A DMA
+// instruction writes lane l of a wave at the wave's base + 16 l bytes, so a plane must start at a wave boundary to have its own pitch:
+// with two planes per pass (G == 2) waves 0-1 stage the first and waves 2-3 the second (positions 64 (wave & 1) + lane < POS).
 template <int TH, int TW, int NT>
 struct Wino2RCfg : Wino2Cfg<TH, TW, NT> {
   using B = Wino2Cfg<TH, TW, NT>;
-  static constexpr int PLANE = B::ROWS * B::ROWP;            // unpadded: slot of thread t = 4 * t floats into the plane group
-  static constexpr int IN_FLOATS = B::KC * PLANE;
-  static constexpr size_t SMEM = sizeof(float) * (2 * IN_FLOATS + 2 * B::W_FLOATS);
-  static_assert(PLANE == 4 * B::POS && 8 * B::CO_T <= IN_FLOATS, "lane-contiguous tile layout");
+  static constexpr size_t SMEM = sizeof(float) * (2 * B::IN_FLOATS + 2 * B::W_FLOATS);
+  static_assert((B::G == 1 || (B::G == 2 && B::POS <= 128)) && 8 * B::CO_T <= B::IN_FLOATS, "lane-contiguous tile layout");
 };
 
 // (ABL: compile-time phase ablations of the experiments build, env WSL_WINO2R_ABLATE -- 1 no MFMAs, 2 no DMA after the first
@@ -430,10 +458,10 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co;
   const int HW = H * W;
 
-  const int grp = tid / C::POS, pos = tid - grp * C::POS;
+  const int grp = C::G == 2 ? (wave >> 1) : 0, pos = C::G == 2 ? ((wave & 1) * 64 + lane) : tid;   // (plane of the pass, float4 position)
   const int pty = pos / C::ROWP4, ptx4 = pos - pty * C::ROWP4;
   const int gy = y0 + pty - 1, gx = x0 + ptx4 * 4 - C::PADL;
-  const bool owner = grp < C::G;
+  const bool owner = pos < C::POS;
   const bool pvalid = owner && gy >= 0 && gy < H && gx >= 0 && gx < W;
   const uint32_t toff = pvalid ? (uint32_t)(grp * HW + gy * W + gx) : 0u;
   const int64_t gstride = (int64_t)C::G * HW;
@@ -441,6 +469,8 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
   const float* w_n = p.u + (int64_t)cby * C::W_FLOATS + 4 * tid;
   const int64_t w_cstride = (int64_t)(Co / CO_T) * C::W_FLOATS;
+  // this wave's slots of a pass: lane l at wslot + 4 l floats (the image is shifted by one float)
+  const int wslot = grp * C::PLANE + (pos - lane) * 4 + C::SHIFT;
 
   // slots of positions outside the image stay zero in both buffers for the whole kernel: the DMA never touches them
   if (owner && !pvalid) {
@@ -448,13 +478,13 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     for (int bsel = 0; bsel < 2; ++bsel)
 #pragma unroll
       for (int i = 0; i < C::NLD; ++i)
-        *reinterpret_cast<float4*>(in_b + bsel * C::IN_FLOATS + i * (C::G * C::PLANE) + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+        wino_store_shifted(in_b + bsel * C::IN_FLOATS + i * (C::G * C::PLANE) + wslot - C::SHIFT + 4 * lane, 0.f, 0.f, 0.f, 0.f);
   }
   auto issue = [&](int c0, int bsel) __attribute__((always_inline)) {
     const bool ina = c0 < p.a.C;                                   // uniform
     const int chb = ina ? c0 : c0 - p.a.C;
     const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
-    float* dst = in_b + bsel * C::IN_FLOATS + wave * 256;          // wave-uniform: lane l lands at dst + 4 * l floats
+    float* dst = in_b + bsel * C::IN_FLOATS + wslot;               // wave-uniform: lane l lands at dst + 4 * l floats
 #ifndef WSL_WINO2R_UNTRACKED
 #define WSL_WINO2R_UNTRACKED 1   // the DMAs are issued from inline assembly (wsl_rt.h), so that hipcc does not wait for them -- vmcnt(0): it must
                                  // assume that any later LDS read aliases their destination -- in front of THIS chunk's first LDS reads: with the
@@ -501,9 +531,9 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
     const int t = (wave * MTW + m) * 16 + (lane & 15), tyy = t / C::TTX, txx = t - tyy * C::TTX;
-    poff[m] = (lane >> 4) * C::PLANE + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
+    poff[m] = (lane >> 4) * C::PLANE + (2 * tyy) * C::ROWP + (C::PADL - 1 + C::SHIFT) + 2 * txx;   // even
   }
-  const int b_off = lane * (2 * NT);
+  const int b_off = lane * NT;
   WSL_WAIT_ALL();
   __syncthreads();   // first chunk landed, zero slots visible
 
@@ -520,9 +550,9 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {   // (odd float offset: two ds_read2_b32, each into an aligned register pair)
+        for (int i = 0; i < 4; ++i) {   // (even float offset: two ds_read_b64, conflict-free -- see Wino2Cfg::PLANE)
           const float* r = in_t + kg * (4 * C::PLANE) + poff[m] + i * C::ROWP;
-          rlo[m][i] = wsl_v2f{r[0], r[1]}, rhi[m][i] = wsl_v2f{r[2], r[3]};
+          rlo[m][i] = wino_read_pair(r), rhi[m][i] = wino_read_pair(r + 2);
         }
     };
     if constexpr ((ABL & 8) == 0 || FIRST) {
@@ -544,10 +574,10 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
       constexpr int BD = NT == 2 ? 4 : 2, BR = BD + 1;
       float bv[BR][NT];
       auto loadb = [&](int xi, int buf) __attribute__((always_inline)) {
-        const float* bp = w_t + xi * (4 * 16 * 2 * NT) + b_off + kg * NT;
+        const float* bp = w_t + xi * (4 * 16 * 2 * NT) + kg * (4 * 16 * NT) + b_off;
         if constexpr (NT == 2) {
-          const float2 b2 = *reinterpret_cast<const float2*>(bp);
-          bv[buf][0] = b2.x, bv[buf][1] = b2.y;
+          const wsl_v2f b2 = wino_read_pair(bp);   // (never fused into ds_read2st64_b64)
+          bv[buf][0] = b2[0], bv[buf][1] = b2[1];
         } else {
           bv[buf][0] = bp[0];
         }
@@ -605,11 +635,11 @@ __device__ __forceinline__ void wino_filter(const float* w, float* u, int Co, in
     t[2][c] = 0.5f * ((g[c] - g[3 + c]) + g[6 + c]);
     t[3][c] = g[6 + c];
   }
-  // operand order of the conv kernels: [chunk = ci / 8][channel block = co / co_t][xi][k = ci % 4][col = co % 16]
-  //                                     [kg = (ci / 4) % 2][j = (co % co_t) / 16], co_t = 32 (16 when Co % 32 != 0)
+  // operand order of the conv kernels: [chunk = ci / 8][channel block = co / co_t][xi][kg = (ci / 4) % 2][k = ci % 4]
+  //                                     [col = co % 16][j = (co % co_t) / 16], co_t = 32 (16 when Co % 32 != 0)
   const int co_t = (Co % 32 == 0) ? 32 : 16, nt = co_t / 16;
   const int chunk = ci >> 3, kg = (ci >> 2) & 1, k = ci & 3, cob = co / co_t, j = (co % co_t) >> 4, col = co & 15;
-  float* dst = u + ((int64_t)chunk * (Co / co_t) + cob) * (16 * 8 * co_t) + (k * 16 + col) * (2 * nt) + kg * nt + j;
+  float* dst = u + ((int64_t)chunk * (Co / co_t) + cob) * (16 * 8 * co_t) + kg * (64 * nt) + (k * 16 + col) * nt + j;
   const int xs = 4 * 16 * 2 * nt;   // floats per transform position
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -754,20 +784,6 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
   const bool bn_ok = bn && bn->part;
   if (bn_ok) p.bn = *bn;
   if (bn_done) *bn_done = bn_ok ? 1 : 0;
-#ifdef WSL_EXPERIMENTS
-  {   // A / B: WIDE tiles (same pixels and tile count per workgroup, so the same BatchNorm-partial blocks): halo rows are fetched in
-      // 544-byte instead of 288- / 160-byte runs (tools/probe_tile_loads.hip: 3.7 against 3.1 / 2.5 TB/s of pure tile fetch at 256 x 256)
-    static const int wide = WSL_TUNE("WSL_WINO_WIDE", 0);
-    if ((wide & 1) && tw == 64 && W % 128 == 0 && H % 4 == 0) {
-      p.tiles_x = W / 128, p.tiles_y = H / 4;
-      return launch_wino2<4, 128, 1>(p, is_dgrad, stream);
-    }
-    if ((wide & 2) && th == 8 && tw == 32 && !narrow16 && W % 64 == 0 && H % 4 == 0) {
-      p.tiles_x = W / 64, p.tiles_y = H / 4;
-      return launch_wino2<4, 64, 2>(p, is_dgrad, stream);
-    }
-  }
-#endif
   if (tw == 64) return launch_wino2<8, 64, 1>(p, is_dgrad, stream);
   if (narrow16) return launch_wino2<8, 32, 1>(p, is_dgrad, stream);
   if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);
@@ -797,10 +813,16 @@ struct WgWinoP {
 template <int TH, int TW, int NCO, int NCI, int NW>   // NCO dY channel tiles per wave, NCI input-channel tiles and NW waves per workgroup
 struct WgWinoCfg {
   static constexpr int THREADS = 64 * NW, CB = 16 * NCO, IB = 16 * NCI, NSUB = NW / NCI, PADL = 4;
-  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4, PA = ROWS * ROWP4, GA = THREADS / PA, NA = IB / GA;
+  static constexpr int ROWP = TW + 2 * PADL, ROWS = TH + 2, ROWP4 = ROWP / 4;
+  // input staging map as Wino2Cfg: whole rows per wave (RW), WPP waves per plane, GA planes per pass, NA passes
+  static constexpr int RW = 64 / ROWP4, WPP = (ROWS + RW - 1) / RW, GA = NW / WPP, NA = IB / GA;
   static constexpr int SD = TH * TW, PD = SD / 4, GD = THREADS / PD, ND = CB / GD;
-  static constexpr int PLD = ((SD - 2 + 31) / 32) * 32 + 2;             // == 2 (mod 32)
-  static constexpr int PLA = ((ROWS * ROWP - 2 + 31) / 32) * 32 + 2;    // == 2 (mod 32); (== 8 (mod 64) measured 4-7 % slower)
+  // Plane pitches == 4 (mod 64) floats: a 32-lane group = 16 channels x 2 tiles reads 8 bytes per lane at 16 c + 8 t bytes (mod 256):
+  // every bank once (rounds 1-4: == 2 (mod 32) and, for the input patches, ds_read2_b32 at odd offsets: 2-way conflicts on every operand
+  // read; profiles/r5_probe_lds5.md).  The input image is shifted by one float like the conv kernels' (Wino2Cfg::SHIFT).
+  static constexpr int SHIFT = 1;
+  static constexpr int PLD = ((SD - 4 + 63) / 64) * 64 + 4;
+  static constexpr int PLA = ((ROWS * ROWP + SHIFT - 4 + 63) / 64) * 64 + 4;
   static constexpr int TTX = TW / 2, TILES = (TH / 2) * TTX, GROUPS = TILES / 4;
   static constexpr int DY_FLOATS = CB * PLD, A_FLOATS = IB * PLA, BUF_FLOATS = DY_FLOATS + A_FLOATS;
   // NW == 8: one 8-wave workgroup per CU with TWO tile buffers -- the next tile's loads are issued before the compute phase
@@ -811,7 +833,7 @@ struct WgWinoCfg {
   static constexpr int RED_FLOATS = (NSUB - 1) * NCI * 64 * PER;
   static constexpr int MAIN_FLOATS = NBUF * BUF_FLOATS > RED_FLOATS ? NBUF * BUF_FLOATS : RED_FLOATS;
   static constexpr size_t SMEM = sizeof(float) * (MAIN_FLOATS + 2 * IB);
-  static_assert(PA <= THREADS && PD <= THREADS && IB % GA == 0 && CB % GD == 0 && GROUPS % NSUB == 0 && TTX % 4 == 0 &&
+  static_assert(NW % WPP == 0 && PD <= THREADS && IB % GA == 0 && CB % GD == 0 && GROUPS % NSUB == 0 && TTX % 4 == 0 &&
                     (NCI == 1 || NCI == 2) && (NW == 4 || NW == 8), "tile shape");
 };
 
@@ -840,9 +862,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
   const int dty = (pd * 4) / TW, dtx = (pd * 4) - dty * TW;
   const int tdconst = gd * HW + dty * W + dtx;
   const int dloff = gd * C::PLD + pd * 4;
-  const int ga = tid / C::PA, pa = tid - ga * C::PA;             // input: float4 #pa of the (TH+2) x (TW+8) halo tile
-  const int aty = pa / C::ROWP4, atx4 = pa - aty * C::ROWP4;
-  const bool owner_a = ga < C::GA;
+  const int ga = wave / C::WPP, arl = lane / C::ROWP4;           // input: plane ga of the pass, row aty, float4 atx4 of the halo tile
+  const int atx4 = lane - arl * C::ROWP4, aty = (wave % C::WPP) * C::RW + arl;
+  const bool owner_a = arl < C::RW && aty < C::ROWS;
   const int aloff = ga * C::PLA + aty * C::ROWP + atx4 * 4;
   const int64_t dstride = (int64_t)C::GD * HW, astride = (int64_t)C::GA * HW;
 
@@ -905,12 +927,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
   };
   auto commit = [&](float* dy_t, float* a_t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < C::ND; ++i) {   // plane stride == 2 (mod 32): 8-byte aligned, not 16
-      float* dst = dy_t + i * (C::GD * C::PLD) + dloff;
-      *reinterpret_cast<float2*>(dst) = make_float2(prd[i].x, prd[i].y);
-      *reinterpret_cast<float2*>(dst + 2) = make_float2(prd[i].z, prd[i].w);
-    }
-    if (owner_a) {
+    for (int i = 0; i < C::ND; ++i)   // (element-wise: a whole-struct copy of prd[i] keeps the array on the stack -- scratch round trip)
+      *reinterpret_cast<v4f*>(dy_t + i * (C::GD * C::PLD) + dloff) = v4f{prd[i].x, prd[i].y, prd[i].z, prd[i].w};
+    {   // (every lane: the lane shift below wants whole waves)
 #pragma unroll
       for (int i = 0; i < C::NA; ++i) {
         wsl_v2f lo = {pra[i].x, pra[i].y}, hi = {pra[i].z, pra[i].w};
@@ -920,9 +939,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
         }
         if (has_mask) xform_mask(lo, hi, prm[i], es);
         lo = lo * prc[i], hi = hi * prc[i];
-        float* dst = a_t + i * (C::GA * C::PLA) + aloff;
-        *reinterpret_cast<float2*>(dst) = make_float2(lo[0], lo[1]);
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(hi[0], hi[1]);
+        // (the shifted image: previous lane's last element + this thread's first three, one aligned conflict-free 16-byte store; rows
+        //  never straddle waves in this kernel's staging map.  Equal within noise to three stores 4 + 8 + 4 bytes: profiles/r5_wino_lds_layout.md)
+        const float left = wsl_prev_lane(hi[1]);
+        if (owner_a) *reinterpret_cast<float4*>(a_t + i * (C::GA * C::PLA) + aloff) = make_float4(left, lo[0], lo[1], hi[0]);
       }
     }
   };
@@ -938,13 +958,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
 #pragma unroll
       for (int jc = 0; jc < NCO; ++jc) {
         const float* dp = dy_t + (jc * 16 + c16) * C::PLD + (2 * tyy) * TW + 2 * txx;
-        rdy[jc][0] = *reinterpret_cast<const wsl_v2f*>(dp), rdy[jc][1] = *reinterpret_cast<const wsl_v2f*>(dp + TW);
+        rdy[jc][0] = wino_read_pair(dp), rdy[jc][1] = wino_read_pair(dp + TW);
       }
-      const float* ap = a_t + (cit * 16 + c16) * C::PLA + (2 * tyy) * C::ROWP + (C::PADL - 1) + 2 * txx;
+      const float* ap = a_t + (cit * 16 + c16) * C::PLA + (2 * tyy) * C::ROWP + (C::PADL - 1 + C::SHIFT) + 2 * txx;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {   // (odd float offset: two ds_read2_b32, each into an aligned register pair)
+      for (int i = 0; i < 4; ++i) {   // (even float offset: two ds_read_b64, conflict-free)
         const float* r = ap + i * C::ROWP;
-        rlo[i] = wsl_v2f{r[0], r[1]}, rhi[i] = wsl_v2f{r[2], r[3]};
+        rlo[i] = wino_read_pair(r), rhi[i] = wino_read_pair(r + 2);
       }
     };
     constexpr int GN = C::GROUPS / C::NSUB;
@@ -969,6 +989,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
       if constexpr ((ABL & 8) == 0) {
         if (gi + 1 < GN) fetch(sub * GN + gi + 1);
       }
+      WSL_SCHED_BARRIER();   // the next group's operand reads stay IN FRONT of this group's MFMAs (the pair reads are volatile: the
+                             // scheduler would otherwise sink them behind the matrix block and wait for them right there)
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) {
         const int i = xi >> 2, c = xi & 3;

@@ -182,6 +182,17 @@ __device__ __forceinline__ void xform_mask(wsl_v2f& lo, wsl_v2f& hi, uint32_t m,
   lo = (lo * es) * m01, hi = (hi * es) * m23;
 }
 
+// the value the PREVIOUS lane of the wave holds (lane 0: unspecified) -- v_mov_b32_dpp wave_shr:1, one vector instruction, no LDS
+// (tools/probe_lds5.hip, probe 3).  Every lane that reads must have an active left neighbour.
+__device__ __forceinline__ float wsl_prev_lane(float v) {
+#ifdef WSL_HOST_EMUL
+  const int l = wsl_emu::lane();
+  return __shfl(v, l > 0 ? l - 1 : 0);
+#else
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+#endif
+}
+
 // Packed f32 adds whose two results take their operands from DIFFERENT halves of the source register pairs (VOP3P op_sel /
 // neg_hi), so the Winograd transforms run two outputs per vector instruction with every result already in the register an
 // MFMA operand wants -- the plain vector form needs v_mov_b32 to un-interleave and loses what it saved.  Same IEEE adds as
