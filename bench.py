@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
     ap.add_argument("--cpu-one-batch", action="store_true", help="CPU leg: only --cpu-batch, not batch 16 as well")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU leg and print its JSON")
+    ap.add_argument("--selftest-emulator", action="store_true",
+                    help="TEST HARNESS ONLY (tests/test_dp.py), never a measurement: the launch / rendezvous / timing / reporting logic of this "
+                         "script on the CPU -- ranks over gloo, the kernel sources in the test-only host emulator (tests/emul), value = null")
     return ap.parse_args()
 
 
@@ -161,31 +164,54 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, 127.0.0.1 rendezvous on a
+        # free port) -- the command the driver documents for N > 1, with this script's own arguments.  A rank that fails takes the
+        # others down (torch.distributed.run kills the group) and the exit status is passed on.
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    if not torch.cuda.is_available():
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
+    emu = args.selftest_emulator
+    from wsl4mis_amd import _lib
+    if emu:
+        # test harness: same control flow, CPU tensors, gloo, the test-only emulator library; nothing below measures anything
+        args.no_prof = args.no_split_record = args.no_cpu_baseline = True
+        torch.set_num_threads(1)
+        _lib.use_library_for_tests(C.CDLL(os.path.join(ROOT, "tests", "emul", "libwslhip_emul.so")))
+        torch.cuda.synchronize = lambda *a, **k: None
+        torch.cuda.empty_cache = lambda: None
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path in the product)")
-    torch.cuda.set_device(local)
+    else:
+        torch.cuda.set_device(local)
+    backend = "gloo" if emu else "nccl"
+    pg_kw = {} if emu else {"device_id": torch.device("cuda", local)}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group(backend, **pg_kw)
     elif args.force_dp:
         import socket
         s_ = socket.socket()
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
         s_.close()
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                device_id=torch.device("cuda", local))
-    from wsl4mis_amd import _lib
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **pg_kw)
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
     from wsl4mis_amd.engine import TrainEngine
     from wsl4mis_amd.synthetic import batch
-    dev = torch.device("cuda", local)
+    dev = torch.device("cpu") if emu else torch.device("cuda", local)
     L = _lib.lib()
     x, lab = batch(args.batch, args.size, args.size, 2022 + rank, dev)
     overlapped = (args.net == "unet_cct" or args.loss == "mean_teacher") and not args.serial_decoders
@@ -217,7 +243,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i_ in range(steps):
+            if emu and os.environ.get("WSL_SELFTEST_FAIL") == f"{rank}:{i_}":      # (test harness: tests/test_dp.py's rank-failure case)
+                raise RuntimeError(f"injected failure of rank {rank} in timed step {i_}")
             eng.step(x, lab, random.random() + 1e-10)
         torch.cuda.synchronize()
         dt_own = time.perf_counter() - t0                         # this rank's own time, before it waits for the others
@@ -471,10 +499,11 @@ def main():
         out = {"metric": ("training slices/sec (256x256, bs64, unet_cct pCE+GatedCRF)" if headline else
                           f"training slices/sec ({args.size}x{args.size}, bs{args.batch}, {args.net} {wl}) -- not BASELINE.json's headline workload")
                          + (" -- SPLIT-PRECISION RECORD" if split else ""),
-               "value": round(value, 2),
+               "value": None if emu else round(value, 2),
                "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32-split-f16x3" if split else "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f32-split-f16x3" if split else "f32",
+               "data": "SELFTEST on the host emulator: control flow only, NOT a measurement" if emu else "synthetic",
                "config": {"workload": f"{args.net} {args.loss}" + (f" r={args.crf_radius}" if args.loss == "pce_gatedcrf" else "")
                           + f", {args.size}x{args.size}x1 4-class synthetic scribble slices, batch {args.batch}/GPU, SGD+poly LR",
                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "crf_radius": args.crf_radius,

@@ -173,3 +173,59 @@ print("DP_ROUTE_OK")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "DP_ROUTE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---------------------------------------------------------------------------------------------- bench.py --gpus N launches itself
+def _bench_selftest(gpus, extra=(), env_extra=None, timeout=900, steps=2, warmup=0):
+    """`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): the script starts its own ranks.  Test
+    harness mode: gloo ranks on the CPU, kernels in the host emulator, 16 x 16 slices -- control flow only, the line's value is null."""
+    import json
+    get_backend("emul")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", **(env_extra or {}))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--selftest-emulator", "--batch", "2", "--size", "16",
+           "--steps", str(steps), "--warmup", str(warmup), "--loss", "ours_proposed"] + list(extra)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_launches_its_own_two_ranks():
+    r, docs = _bench_selftest(2)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len(docs) == 1, r.stdout                                  # rank 0 prints ONE line
+    d = docs[0]
+    assert d["n_gpus"] == 2 and d["value"] is None and "SELFTEST" in d["data"] and d["config"]["global_batch"] == 4
+    dp = d["dp"]
+    assert dp["backend"] == "gloo" and dp["world_size_seen_by_the_process_group"] == 2
+    assert dp["replicas_bit_identical_after_timed_region"] is True
+    assert len(dp["per_rank_last_loss"]) == 2 and dp["per_rank_last_loss"][0] != dp["per_rank_last_loss"][1]   # different shards
+
+
+def test_bench_four_ranks_stay_bit_identical():
+    """world size 4: both gradient buckets (decoders, then encoder) through four ranks whose shards have unequal numbers of labelled
+    pixels (per-rank loss normalisation), three timed steps, replicas bit-identical afterwards"""
+    r, docs = _bench_selftest(4, steps=3)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    dp = docs[0]["dp"]
+    assert dp["world_size_seen_by_the_process_group"] == 4 and dp["replicas_bit_identical_after_timed_region"] is True
+    assert len(set(dp["per_rank_last_loss"])) == 4
+    assert all(np.isfinite(v) for v in dp["per_rank_last_loss"])
+
+
+def test_bench_one_rank_through_the_force_dp_route():
+    r, docs = _bench_selftest(1, extra=["--force-dp"], steps=1)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert docs[0]["dp"]["world_size_seen_by_the_process_group"] == 1
+
+
+def test_bench_rank_failure_takes_the_job_down():
+    """SURVEY 5 (fail fast on any rank error): rank 1 raises in its second timed step (the first one ran: the process group, both buckets and the optimiser have been through); the other rank sits in an all-reduce -- the job
+    must end with a non-zero status well inside the timeout, without a result line"""
+    import time
+    t0 = time.time()
+    r, docs = _bench_selftest(2, env_extra={"WSL_SELFTEST_FAIL": "1:1"}, timeout=600)
+    assert r.returncode != 0
+    assert not docs
+    assert "injected failure of rank 1" in r.stderr
+    assert time.time() - t0 < 300

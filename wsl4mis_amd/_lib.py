@@ -221,7 +221,8 @@ _test_emul = False
 
 def use_library_for_tests(cdll):
     """TEST HOOK ONLY: make the Python layer talk to the host-emulation build (tests/emul) with CPU tensors so the
-    host logic can be exercised without a GPU.  Never called by the package, bench.py or __graft_entry__."""
+    host logic can be exercised without a GPU.  Never called by the package or __graft_entry__; bench.py calls it only under its
+    --selftest-emulator flag (the launch / rendezvous logic of `bench.py --gpus N` checked on the CPU by tests/test_dp.py: value null)."""
     global _lib, _test_emul
     bind(cdll, strict=False)
     if b"HOST-EMULATION" not in cdll.wsl_build_info():
