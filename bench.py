@@ -62,7 +62,9 @@ def parse():
     ap.add_argument("--net", default="unet_cct", choices=["unet_cct", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
-    ap.add_argument("--pmc-refresh", action="store_true", help="N=1: before the timed run, collect roofline.traffic IN THIS RUN -- two "
+    ap.add_argument("--no-pmc-refresh", action="store_true", help="do not collect roofline.traffic in this run (then the newest committed "
+                    "profiles/r*_pmc_traffic.json record is quoted, marked as such)")
+    ap.add_argument("--pmc-refresh", action="store_true", help="(the default since round 5 when N=1) collect roofline.traffic IN THIS RUN -- two "
                     "rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domain) of this same command at "
                     "--steps 2 --warmup 1, aggregated by tools/pmc_traffic.py (adds about a minute)")
     ap.add_argument("--prof-timed", action="store_true",
@@ -74,7 +76,7 @@ def parse():
                     "all-reduce in a 1-rank group on the comm stream) to measure its overhead on one GPU")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = sweep 16 / 32 / 64 / 128 / all host cores and report the best")
     ap.add_argument("--cpu-one-batch", action="store_true", help="CPU leg: only --cpu-batch, not batch 16 as well")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU leg and print its JSON")
     ap.add_argument("--selftest-emulator", action="store_true",
@@ -89,8 +91,7 @@ def cpu_baseline(args):
     unet_cct pce / pce_gatedcrf / ours_proposed, unet mean_teacher."""
     from oracle import torch_ref as R
     from wsl4mis_amd.synthetic import scribble_labels
-    n_thr = args.cpu_threads or min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(n_thr)
+    ncpu = os.cpu_count() or 1
     S = args.size
     if args.loss not in ("pce", "pce_gatedcrf", "ours_proposed", "mean_teacher") or (args.loss == "ours_proposed" and args.net != "unet_cct"):
         raise SystemExit(f"cpu baseline is not built for {args.net} {args.loss}")
@@ -121,22 +122,44 @@ def cpu_baseline(args):
             one = lambda: tr.step(x, lab, 0.4, em, cm, crf, kind="pce" if args.loss == "pce" else None)   # noqa: E731
         one()                                                  # warm-up (thread pool, oneDNN primitives)
         iters, t0 = 0, time.perf_counter()
-        while iters < max(2, args.cpu_iters) or (time.perf_counter() - t0 < budget_s and iters < 12):
+        while iters < 2 or (time.perf_counter() - t0 < budget_s and iters < 12):
             one()
             iters += 1
         dt = time.perf_counter() - t0
         return {"batch": B, "value": round(B * iters / dt, 3), "timed_steps": iters, "seconds": round(dt, 2)}
 
-    legs = [leg(args.cpu_batch, 12.0)] + ([leg(16, 10.0)] if args.cpu_batch != 16 and not args.cpu_one_batch else [])
+    # the host's best.  Thread sweep up to every core (torch's intra-op pool; oneDNN convolutions stop scaling long before
+    # 256 threads on these shapes, which is why the sweep exists) at the small batch; then batch 16 and -- if the budget allows -- the
+    # GPU line's own batch 64 at the best thread count.  About 30 s of CPU work on the GPU box's host.
+    if args.cpu_threads:
+        sweep = [args.cpu_threads]
+    else:
+        sweep = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} or {ncpu})
+    legs = []
+    t_start = time.perf_counter()
+    for t in sweep:
+        torch.set_num_threads(t)
+        r = leg(args.cpu_batch, 2.5)
+        r["threads"] = t
+        legs.append(r)
+    n_thr = max(legs, key=lambda r: r["value"])["threads"]
+    torch.set_num_threads(n_thr)
+    if not args.cpu_one_batch:
+        rate = max(r["value"] for r in legs)
+        for B in (16, 64):     # larger batches at the best thread count, while three steps of them fit what is left of ~60 s
+            if B != args.cpu_batch and (time.perf_counter() - t_start) + 3.0 * B / rate < 60.0:
+                r = leg(B, 3.0)
+                r["threads"] = n_thr
+                legs.append(r)
     best = max(legs, key=lambda r: r["value"])
-    return {"value": best["value"], "unit": "slices/s", "cores": n_thr, "kind": "port",
+    return {"value": best["value"], "unit": "slices/s", "cores": best["threads"], "kind": "port",
             "sample": f"oracle/torch_ref.py (stock torch CPU ops = what the reference's CPU path executes), {args.net} {args.loss}"
                       + (f" r={args.crf_radius}" if crf else "") + f", batch {best['batch']} at {S}x{S}, 1 warm-up + "
-                      f"{best['timed_steps']} timed steps ({best['seconds']} s), {n_thr} threads of {os.cpu_count()} host cores; the best "
-                      "of the batch sizes in `batches`"
+                      f"{best['timed_steps']} timed steps ({best['seconds']} s), {best['threads']} threads of {ncpu} host cores: the best of a "
+                      f"thread sweep {sweep} at batch {args.cpu_batch} and of the larger batches in `legs` at the best thread count"
                       + ("; GatedCRF in the oracle is a tap loop over shifted views, which is KINDER to the CPU than the reference's "
                          "two F.unfold materialisations (127 MB per slice each)" if crf else ""),
-            "batches": legs}
+            "host_cores": ncpu, "legs": legs}
 
 
 def cpu_baseline_subprocess(args):
@@ -309,14 +332,14 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import pmc_traffic as agg
         tmp = tempfile.mkdtemp(prefix="wsl_pmc_", dir="/tmp")
-        child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-prof", "--no-split-record",
+        child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-prof", "--no-split-record", "--no-pmc-refresh",
                  "--serial-decoders", "--conv-precision", args.conv_precision, "--loss", args.loss, "--net", args.net, "--batch", str(args.batch),
                  "--size", str(args.size), "--crf-radius", str(args.crf_radius)]
         try:
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, ctr), "--"] + child,
                                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                               timeout=600, check=True)
+                               timeout=150, check=True)
             fresh_traffic[0] = agg.aggregate(os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"))
         except (OSError, subprocess.SubprocessError, AssertionError) as e:
             print(f"[bench] --pmc-refresh failed ({e}); falling back to the committed record", file=sys.stderr)
@@ -348,7 +371,7 @@ def main():
             nl = sum(tj[k]["launches_sampled"] for k in keys if k in tj)
             return {"hbm_bytes_per_launch": sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["launches_sampled"] for k in keys if k in tj) / nl,
                     "algorithmic_bytes_per_launch": sum(r.bytes for r in grp) / calls,
-                    "source": ("collected in THIS run (--pmc-refresh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes, FETCH_SIZE x2 per "
+                    "source": ("collected in THIS run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command at --steps 2, FETCH_SIZE x2 per "
                                "MI355X_MICROARCH.md)") if fresh_traffic[0] is not None else
                               (f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc, FETCH_SIZE x2 per MI355X_MICROARCH.md; a committed "
                                "record of an earlier run of this command, not collected in this run)"),
@@ -356,6 +379,26 @@ def main():
                     "source_collected_utc": tdoc.get("collected_utc")}
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             return None
+
+    def sq_counters(split):
+        """SQ counters of the MFMA kernel families from the newest committed profiles/r*_pmc_sq_{f32,split}.md (rocprofv3 --pmc passes of
+        this command, tools/gpu_sq_f32.sh / record_round.sh): the matrix pipe's busy share is what `issued_frac` estimates from flops."""
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_sq_{'split' if split else 'f32'}.md")), key=os.path.basename)
+        if not cands:
+            return None
+        out = {}
+        try:
+            for line in open(cands[-1]):
+                c = [t.strip() for t in line.strip().strip("|").split("|")]
+                if len(c) >= 5 and c[0].startswith("`") and c[1] not in ("–", "-"):
+                    out[c[0].strip("`")] = {"mfma_pipe_busy": float(c[1]), "vector_instruction_active": None if c[2] == "–" else float(c[2]),
+                                            "lds_bank_conflict_share_of_lds_active": None if c[3] == "–" else float(c[3]),
+                                            "valu_instructions_per_mfma": None if c[4] == "–" else float(c[4])}
+        except (OSError, ValueError):
+            return None
+        return {"source": f"profiles/{os.path.basename(cands[-1])} (a committed record; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES etc. per kernel family)",
+                "kernels": out}
 
     def roofline_of(rows, nsteps, ms_per_step):
         byname = {r.name.decode(): r for r in rows if r.calls}
@@ -420,13 +463,17 @@ def main():
                                  "peak); whole_step_issued_frac: all MFMA kernels' issued flops / the peak of the instruction each issues, per "
                                  "step / the timed region's ms_per_step",
                 "kernels": per_kernel,
+                "sq_counters": sq_counters(any("_sp_kernel" in r.name.decode() for r in conv)),
                 "all_mfma_kernels_tflops": round(sum(r.flops for r in conv) / (sum(r.ms for r in conv) * 1e-3) / 1e12, 2),
                 "all_mfma_kernels_ms_per_step": round(sum(r.ms for r in conv) / nsteps, 3),
                 "hbm_roofline": {"peak_GBps": PEAK_HBM_GBS, "kernels": hbm,
                                  "all_hbm_kernels_ms_per_step": round(sum(v["ms_per_step"] for v in hbm.values()), 3)}}
 
-    if args.pmc_refresh and world == 1 and not args.no_prof:
-        pmc_refresh()                  # (after the timed region: the child processes share this GPU)
+    import shutil as _sh
+    # (the full default record only: the tuning scripts' `--no-cpu-baseline` lines, A/B builds and runs under a profiler skip it)
+    if (args.pmc_refresh or (world == 1 and not args.no_cpu_baseline and not args.lib)) and not args.no_prof and not emu \
+            and not args.no_pmc_refresh and _sh.which("rocprofv3"):
+        pmc_refresh()                  # (after the timed region: the child processes share this GPU; about 40 s, bounded by time-outs)
 
     def roofline_segment(eng, dt, steps):
         """(roofline object, per-family rows) of the engine that just ran a timed region of `steps` steps in `dt` seconds"""

@@ -11,7 +11,6 @@ from wsl4mis_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMUL_PATH = os.path.join(ROOT, "tests", "emul", "libwslhip_emul.so")
-EMUL_NEXT_PATH = os.path.join(ROOT, "tests", "emul", "libwslhip_emul_next.so")   # the kernel switches measured but not yet shipped, ON
 
 
 class _Base:

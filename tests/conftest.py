@@ -107,7 +107,7 @@ import subprocess
 
 def _emul_stale():
     so = os.path.join(ROOT, "tests", "emul", "libwslhip_emul.so")
-    if not os.path.exists(so) or not os.path.exists(os.path.join(ROOT, "tests", "emul", "libwslhip_emul_next.so")):
+    if not os.path.exists(so):
         return True
     t = os.path.getmtime(so)
     srcs = [os.path.join(ROOT, "include", "wsl_hip.h"), os.path.join(ROOT, "tests", "emul", "hip_emul.h"),
@@ -128,9 +128,6 @@ def get_backend(name):
                 subprocess.run([os.path.join(ROOT, "wsl4mis_amd", "csrc", "build.sh"), "emul"], check=True,
                                stdout=subprocess.DEVNULL)
             _BACKENDS[name] = backends.EmulBackend()
-        elif name == "emul_next":
-            get_backend("emul")           # (builds both emulator libraries when stale)
-            _BACKENDS[name] = backends.EmulBackend(backends.EMUL_NEXT_PATH)
         else:
             _BACKENDS[name] = backends.HipBackend()
     return _BACKENDS[name]

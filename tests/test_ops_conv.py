@@ -280,18 +280,3 @@ def test_every_lean_conv_instantiation(be, plan, ks):
         assert close(be.np(dx), ref2.detach().numpy(), TOL)
     finally:
         be.call("wsl_debug_conv_plan", 0, 0, 0)
-
-
-@pytest.mark.parametrize("case", [(2, 16, 16, 16, 16, 32, 3, True), (1, 16, 64, 24, 8, 32, 3, True), (2, 16, 16, 32, 32, 128, 3, True)])
-def test_winograd_data_gradient_with_the_next_rounds_dma_form(case):
-    """`conv_wino2r_kernel` with its LDS DMAs issued from inline assembly (scalar base + 32-bit lane offset; -DWSL_WINO2R_UNTRACKED=1:
-    +0.7 % on the f32 step, profiles/r4_conv_wino2r_untracked_dma_experiment.log).  It was checked here, on the emulator library built with
-    the pending kernel switches forced on (tests/emul/libwslhip_emul_next.so), before it became the default at the end of round 4; the
-    mechanism stays for the next pending switch (today both emulator libraries run the same code)."""
-    from conftest import get_backend
-    nb = get_backend("emul_next")
-    nb.call("wsl_debug_conv_wino", 2)
-    try:
-        test_conv_fwd_dgrad_wgrad_stats(nb, 2, case)
-    finally:
-        nb.call("wsl_debug_conv_wino", -1)

@@ -221,16 +221,6 @@ def test_sp_not_eligible(be):
                 be.stream)
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[-2]])
-def test_split_conv_with_the_next_rounds_operand_pipelining(case):
-    """The split conv kernels with the MFMA operand reads pipelined by hand (-DWSL_SP_PIPE=1: +0.45 % on the split step,
-    profiles/r4_conv_sp_pipelined_operands_experiment.log).  Checked here, on the emulator library built with the pending kernel switches
-    forced on (tests/emul/libwslhip_emul_next.so), before it became the default at the end of round 4; the mechanism stays for the next
-    pending switch (today both emulator libraries run the same code)."""
-    from conftest import get_backend
-    test_sp_conv_fwd_dgrad_wgrad(get_backend("emul_next"), case)
-
-
 def test_lds_residency_of_the_steps_layer_shapes(be):
     """LDS is handed out in units of 1280 bytes on gfx950 (round 4: a 256-byte table took the 16-wide blocks of 32 input channels from 42
     to 43 units and with that from three workgroups per CU to two: +21 % on that layer).  The layer shapes of the benchmark step that sit at

@@ -265,14 +265,23 @@ def test_fused_head_gatedcrf_equals_the_four_call_composition(be, dual):
         assert rel_err(be.np(b2), be.np(a2)) < 5e-7
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 40, 44), (52, 4, 256, 256)])
 @pytest.mark.parametrize("kind,teacher", [(1, False), (2, False), (3, False), (1, True)])
-def test_fused_regulariser_head_equals_the_chain_of_calls(be, kind, teacher):
+def test_fused_regulariser_head_equals_the_chain_of_calls(be, kind, teacher, shape):
     """wsl_head_reg_fwd_bwd == wsl_head_fwd_bwd + wsl_softmax_fwd + {tv | mumford_shah | entropy}_fwd_bwd + wsl_softmax_bwd + wsl_axpy
     (+ wsl_softmax_mse_fwd_bwd + wsl_axpy for the mean-teacher composition) to round-off: same kernels for the regulariser, ONE softmax
     backward of the summed gradient instead of one per term (ref: train_weakly_supervised_pCE_TV_2D.py:108-114,
     ..._pCE_MumfordShah_Loss_2D.py:97-107, ..._pCE_Entropy_Mini_2D.py:99-102, train_mean_teacher_2D.py:147-171)."""
     rng = np.random.default_rng(40 + kind)
-    N, C, H, W = 3, 4, 40, 44
+    N, C, H, W = shape
+    if N > 8:
+        # (52 x 4 x 256 x 256: 53 248 TV tiles -- more than the head's own partial region holds (kMaxBlocks * kMaxK = 49 152 floats), so the
+        #  regulariser's partials take the LARGE workspace layout, behind the Mumford-Shah moments: the layout of every full-size engine
+        #  step (bench.py --loss pce_tv ...), ADVICE r4.  Too many pixels for the host emulator.)
+        if be.name != "hip":
+            pytest.skip("the large workspace layout needs a full-size batch: GPU only")
+        if kind == 1 and teacher:
+            pytest.skip("one teacher case suffices")
     w = {1: 1e-2, 2: 1e-6, 3: 0.1}[kind]
     cw = 0.07
     z, zt = (rng.standard_normal((N, C, H, W)) * 2).astype(np.float32), (rng.standard_normal((N, C, H, W)) * 2).astype(np.float32)
@@ -300,11 +309,13 @@ def test_fused_regulariser_head_equals_the_chain_of_calls(be, kind, teacher):
         be.call("wsl_softmax_mse_fwd_bwd", be.ptr(d["z"]), be.ptr(d["zt"]), be.ptr(cons), be.ptr(dzx), cw, N, C, H * W, be.ptr(ws), n, be.stream)
         be.call("wsl_axpy", be.ptr(a), be.ptr(dzx), 1.0, N * C * H * W, be.stream)
     # one call
-    o2, b, s2, ds2 = be.zeros((8,)), be.zeros(z.shape), be.zeros(z.shape), be.zeros(z.shape)
+    o2, b, s2, ds2 = be.arr(np.full((8,), 7.0, np.float32)), be.zeros(z.shape), be.zeros(z.shape), be.zeros(z.shape)
     be.call("wsl_head_reg_fwd_bwd", be.ptr(d["z"]), be.ptr(d["lab"]), 4, 1.0, kind, w, be.ptr(d["img"]), be.ptr(d["zt"]) if teacher else None,
             cw, be.ptr(o2), be.ptr(b), be.ptr(s2), be.ptr(ds2), N, C, H, W, be.ptr(ws), n, be.stream)
     assert rel_err(be.np(s2), be.np(s1)) < 5e-7
     assert rel_err(be.np(o2)[:4], be.np(o1)[:4]) < 1e-6 and abs(be.np(o2)[4] - be.np(reg)[0]) <= 1e-6 * abs(be.np(reg)[0])
     if teacher:
         assert abs(be.np(o2)[5] - be.np(cons)[0]) <= 1e-6 * abs(be.np(cons)[0])
+    else:
+        assert be.np(o2)[5] == 0.0            # no teacher: the consistency slot is written (zero), not left stale
     assert rel_err(be.np(b), be.np(a)) < 2e-6, rel_err(be.np(b), be.np(a))

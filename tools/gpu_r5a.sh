@@ -7,4 +7,4 @@ O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd "$R"
 timeout 600 python -m pytest tests/test_ops_conv.py tests/test_net.py -x -q -m gpu 2>&1 | tail -5 | tee "$O/pytest_conv.log"
 WSL_EXP_LIB=old timeout 300 python tools/sweep_layers.py 2>&1 | tee "$O/sweep_old.log"
 timeout 300 python tools/sweep_layers.py 2>&1 | tee "$O/sweep_new.log"
-PREC=f32 VARIANTS="product r4" REPS="${REPS:-2}" bash tools/gpu_r4j.sh "$O"
+PREC=f32 VARIANTS="product r4" REPS="${REPS:-2}" bash tools/gpu_step_ab.sh "$O"

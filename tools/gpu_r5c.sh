@@ -10,4 +10,4 @@ for t in ${LIBS:-old new}; do
 done
 done
 unset WSL_EXP_LIB
-[ "${STEP:-1}" = 1 ] && PREC=f32 VARIANTS="product r4" REPS="${REPS:-2}" bash tools/gpu_r4j.sh "$O"
+[ "${STEP:-1}" = 1 ] && PREC=f32 VARIANTS="product r4" REPS="${REPS:-2}" bash tools/gpu_step_ab.sh "$O"

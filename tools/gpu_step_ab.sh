@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
-# in-step A / B on ONE box: the split-precision step with the product library against the build before the staging specialisation
-# (tools/exp/libwslhip_prev.so), alternating, three rounds
+# in-step A / B on ONE box: the step (PREC=f32 | split_f16x3) with the product library against other builds (VARIANTS="product r4": tools/exp/libwslhip_<tag>.so),
+# alternating, REPS rounds -- how a kernel change is priced when boxes differ by 1-3 %
 O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd "$R"
 for rep in $(seq 1 ${REPS:-3}); do
   for v in ${VARIANTS:-product prev}; do

@@ -6,7 +6,7 @@
 set -u
 O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd "$R"
 rm -f gpurun_out/labelmap_rates.jsonl gpurun_out/fullsize_error_budget.json
-(timeout 1500 python -m pytest tests -m gpu -q --tb=short -s 2>&1 | grep -v "^iteration" | tail -60) > "$O/pytest_gpu.log"
+(WSL_FP64_BUDGET=1 timeout 1500 python -m pytest tests -m gpu -q --tb=short -s 2>&1 | grep -v "^iteration" | tail -60) > "$O/pytest_gpu.log"
 cp gpurun_out/labelmap_rates.jsonl gpurun_out/fullsize_error_budget.json gpurun_out/fullsize_replayed_decisions*.json "$O"/ 2>/dev/null
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1) > "$O/smoke.log"
 (timeout 600 python bench.py 2>"$O/bench_stderr.log" | tail -1) > "$O/bench_default.json"

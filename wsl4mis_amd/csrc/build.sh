@@ -74,26 +74,4 @@ if [ "${1:-}" = "emul" ] || [ "${2:-}" = "emul" ]; then
   for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
   "$CXX" -shared -fPIC -pthread "${eobjs[@]}" "$em/build/hip_emul.o" -o "$em/libwslhip_emul.so"
   echo "built $em/libwslhip_emul.so"
-  # the same library with PENDING kernel switches forced on -- switches measured as off-by-default experiments whose logic stays checked
-  # on the CPU (tests: backend "emul_next") until a round turns them on in the product.  (The two it was built for, WSL_SP_PIPE and
-  # WSL_WINO2R_UNTRACKED, became defaults at the end of round 4: the flags below are no-ops until the next pending switch is added.)
-  nobjs=()
-  pids=()
-  for s in "${srcs[@]}"; do
-    [ -f "$here/$s.hip" ] || continue
-    if [ "$s" = "wsl_convsp" ] || [ "$s" = "wsl_conv5" ]; then
-      o="$em/build/${s}_next.o"
-      if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$em/hip_emul.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
-        "$CXX" -x c++ -std=c++17 -O2 -g -fPIC -ffp-contract=off -DWSL_HOST_EMUL -DWSL_EXPERIMENTS -DWSL_SP_PIPE=1 -DWSL_WINO2R_UNTRACKED=1 \
-          -I"$em" -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-pass-failed -c "$here/$s.hip" -o "$o" &
-        pids+=($!)
-      fi
-    else
-      o="$em/build/$s.o"
-    fi
-    nobjs+=("$o")
-  done
-  for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-  "$CXX" -shared -fPIC -pthread "${nobjs[@]}" "$em/build/hip_emul.o" -o "$em/libwslhip_emul_next.so"
-  echo "built $em/libwslhip_emul_next.so"
 fi

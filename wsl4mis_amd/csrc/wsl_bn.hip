@@ -366,16 +366,6 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce4_kernel(BnBwdP p, float*
 // raising 64 words with atomicMax cost 70 us per launch (bnact_bwd_apply4: 126 us against 56 without the maximum, 19 % of the
 // split step -- profiles/r3_rocprofv3_kernel_stats_split_asm_chains_atomic_amax.csv), with or without a pre-check load of the slot.
 __device__ __forceinline__ void amax_block_store(float m, uint32_t* pmax) {
-#ifdef WSL_AMAX_ATOMIC_AB   // A / B build (tools/ab_split_fullsize.py): the round's first form, pmax = the tensor's 64 slots (cleared by the caller)
-#pragma unroll
-  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-  if ((threadIdx.x & 63) == 0) {
-    uint32_t u;
-    memcpy(&u, &m, 4);
-    atomicMax(pmax + ((blockIdx.x * 4 + (threadIdx.x >> 6) + 5 * blockIdx.y + 11 * blockIdx.z) & (WSL_SP_AMAX_SLOTS - 1)), u);
-  }
-  return;
-#endif
   __shared__ float mred[4];
 #pragma unroll
   for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
@@ -812,14 +802,9 @@ extern "C" int wsl_bnact_bwd_amax(const float* g, int64_t g_bs, const float* y, 
              (double)N * H * W, dgamma, dbeta, coef);
   // (the partial sums were consumed by the finalize kernel: their area now takes the apply pass' partial maxima)
   uint32_t* pmax = dy_amax ? reinterpret_cast<uint32_t*>(part) : nullptr;
-#ifdef WSL_AMAX_ATOMIC_AB
-  pmax = dy_amax;
-#endif
   if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
   else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
-#ifndef WSL_AMAX_ATOMIC_AB
   if (dy_amax) WSL_LAUNCH(amax_fold_kernel, dim3(WSL_SP_AMAX_SLOTS), dim3(kThreads), 0, stream, pmax, N * p.chunks * C, dy_amax);
-#endif
   return check_launch("bnact_bwd");
 }
 
@@ -855,14 +840,9 @@ extern "C" int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const flo
              channel_major ? (int64_t)1 : (int64_t)C, channel_major ? (int64_t)nblk : (int64_t)1, (double)N * H * W, dgamma, dbeta,
              coef);
   uint32_t* pmax = dy_amax ? reinterpret_cast<uint32_t*>(coef + 2 * (size_t)C) : nullptr;
-#ifdef WSL_AMAX_ATOMIC_AB
-  pmax = dy_amax;
-#endif
   if (vec) WSL_LAUNCH(bnact_bwd_apply4_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
   else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
-#ifndef WSL_AMAX_ATOMIC_AB
   if (dy_amax) WSL_LAUNCH(amax_fold_kernel, dim3(WSL_SP_AMAX_SLOTS), dim3(kThreads), 0, stream, pmax, N * p.chunks * C, dy_amax);
-#endif
   return check_launch("bnact_bwd_finish");
 }
 

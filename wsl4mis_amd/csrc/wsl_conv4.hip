@@ -429,13 +429,11 @@ struct NkCfg {
 
 // (NHWC: layout probe of the experiments build -- the 16 output channels of a pixel stored contiguously, [N][H][W][16]; the
 //  result is not what any consumer reads, only the store pattern is of interest: tools/microbench_nk16.py)
-#ifndef WSL_NK16_MINW
-#define WSL_NK16_MINW 2   // waves per SIMD the register allocator leaves room for.  Round 3 had 3: a 168-register cap that put 56 (CI = 4) /
-                          // 12 (CI = 1) values into scratch; measured in round 4 (tools/build_minw_variants.sh, profiles/r4_minw_ab.log):
-                          // classifier data gradient 134 -> 97 us with 2, first convolution 79 -> 78 us
-#endif
+constexpr int kNk16MinW = 2;   // waves per SIMD the register allocator leaves room for.  Round 3 had 3: a 168-register cap that put 56 (CI = 4) /
+                               // 12 (CI = 1) values into scratch; measured in round 4 (profiles/r4_minw_ab.log): classifier data gradient
+                               // 134 -> 97 us with 2, first convolution 79 -> 78 us
 template <int CI, int TH = 8, int TW = 64, bool NHWC = false>
-__global__ __launch_bounds__(256, WSL_NK16_MINW) void conv_nk16_kernel(NkP p) {
+__global__ __launch_bounds__(256, kNk16MinW) void conv_nk16_kernel(NkP p) {
   using C = NkCfg<CI, TH, TW>;
   WSL_DYN_SMEM(smem);
   float* in_t = reinterpret_cast<float*>(smem);
@@ -587,7 +585,7 @@ static int launch_nk16(NkP& p, bool dgrad, void* stream) {
     (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
     attr_done = true;
   }
-  int wgs = WSL_NK16_MINW * device_cu_count();
+  int wgs = kNk16MinW * device_cu_count();
   if (wgs > p.items) wgs = p.items;
   const double px = (double)p.N * p.H * p.W;
   void* tok = prof_begin(dgrad ? PF_CONV_DGRAD : PF_CONV_FWD, 2.0 * px * CI * 16 * 9, 4.0 * px * (16 + CI), stream);
@@ -612,7 +610,7 @@ int conv_nk16_launch(const WslSrc& a, const float* wp, const float* bias, float*
   if (nhwc) {
     auto kern = a.C == 4 ? conv_nk16_kernel<4, 8, 64, true> : conv_nk16_kernel<1, 8, 64, true>;
     p.tiles_x = W / 64, p.tiles_y = H / 8;
-    int wgs = WSL_NK16_MINW * device_cu_count();
+    int wgs = kNk16MinW * device_cu_count();
     if (wgs > p.items) wgs = p.items;
     WSL_LAUNCH(kern, dim3(wgs), dim3(kThreads), (a.C == 4 ? NkCfg<4>::SMEM : NkCfg<1>::SMEM), stream, p);
     return check_launch("conv_nk16_kernel(nhwc probe)");

@@ -186,7 +186,7 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C:
       }
       bn_bwd_fold(ba, s1[j], s2[j]);
     }
-    bn_bwd_store<NT, CO_T>(p.bn, s1, s2, in_t, co0, p.Co, tile_id, nb);
+    bn_bwd_store<NT, CO_T, true>(p.bn, s1, s2, in_t, co0, p.Co, tile_id, nb);   // (LDS-only barrier: the tile's stores keep draining)
     return;
   }
   if (p.stat_part) {
@@ -200,7 +200,9 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C:
       s += __shfl_xor(s, 32);
       if (lane < 16) red1[wave * CO_T + j * 16 + lane] = s;
     }
-    __syncthreads();
+    // (LDS-only barriers: __syncthreads() would also wait -- vmcnt(0) -- until the 32 KB of output stores issued above are acknowledged,
+    //  two microseconds in which a full-resolution workgroup has nothing else to do; only the LDS scratch is shared here)
+    WSL_LDS_BARRIER();
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = j * 16 + (lane & 15);
@@ -217,7 +219,7 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C:
       q += __shfl_xor(q, 32);
       if (lane < 16) red2[wave * CO_T + j * 16 + lane] = q;
     }
-    __syncthreads();
+    WSL_LDS_BARRIER();
     if (wave == 0 && lane < 16) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -467,7 +469,6 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   const int64_t gstride = (int64_t)C::G * HW;
   const float* xa_n = p.a.x + n * p.a.bs;
   const float* xb_n = p.b.C ? p.b.x + n * p.b.bs : nullptr;
-  const float* w_n = p.u + (int64_t)cby * C::W_FLOATS + 4 * tid;
   const int64_t w_cstride = (int64_t)(Co / CO_T) * C::W_FLOATS;
   // this wave's slots of a pass: lane l at wslot + 4 l floats (the image is shifted by one float)
   const int wslot = grp * C::PLANE + (pos - lane) * 4 + C::SHIFT;
@@ -485,13 +486,9 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     const int chb = ina ? c0 : c0 - p.a.C;
     const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
     float* dst = in_b + bsel * C::IN_FLOATS + wslot;               // wave-uniform: lane l lands at dst + 4 * l floats
-#ifndef WSL_WINO2R_UNTRACKED
-#define WSL_WINO2R_UNTRACKED 1   // the DMAs are issued from inline assembly (wsl_rt.h), so that hipcc does not wait for them -- vmcnt(0): it must
-                                 // assume that any later LDS read aliases their destination -- in front of THIS chunk's first LDS reads: with the
-                                 // builtin (0) the double buffering never overlapped (+0.7 % on the f32 step).  The wait before the barrier is
-                                 // WSL_WAIT_ALL.
-#endif
-#if WSL_WINO2R_UNTRACKED
+    // (the DMAs are issued from inline assembly -- wsl_rt.h -- so that hipcc does not wait for them, vmcnt(0): it must assume that any later
+    //  LDS read aliases their destination, in front of THIS chunk's first LDS reads: with the builtin the double buffering never overlapped,
+    //  +0.7 % on the f32 step.  The wait before the barrier is WSL_WAIT_ALL)
     if (pvalid) {
 #pragma unroll
       for (int i = 0; i < C::NLD; ++i) WSL_LDS_DMA16_UNTRACKED_SO(xb + i * gstride, (uint32_t)toff * 4u, dst + i * (C::G * C::PLANE));
@@ -500,18 +497,16 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     float* wdst = w_b + bsel * C::W_FLOATS + wave * 256;
 #pragma unroll
     for (int i = 0; i < C::NWL; ++i) WSL_LDS_DMA16_UNTRACKED_SO(wb + i * (4 * kThreads), (uint32_t)tid * 16u, wdst + i * (4 * kThreads));
-#else
-    if (pvalid) {
-#pragma unroll
-      for (int i = 0; i < C::NLD; ++i) WSL_LDS_DMA16(xb + i * gstride + toff, dst + i * (C::G * C::PLANE));
-    }
-    const float* wb = w_n + (c0 / KC) * w_cstride;
-    float* wdst = w_b + bsel * C::W_FLOATS + wave * 256;
-#pragma unroll
-    for (int i = 0; i < C::NWL; ++i) WSL_LDS_DMA16(wb + i * (4 * kThreads), wdst + i * (4 * kThreads));
-#endif
   };
 
+#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
+  // (experiments build, env WSL_CONV_ABLATE & 128: per-workgroup timeline -- shader-clock stamps at entry / first chunk landed / channel
+  //  loop done / end, the 100 MHz real-time counter at entry and end, HW_ID and XCC_ID -- dumped over the BatchNorm partials;
+  //  tools/timeline_wino2r.py)
+  const bool tl = (p.ablate & 128) != 0 && p.stat_part != nullptr;
+  uint64_t tl_t[6] = {0, 0, 0, 0, 0, 0};
+  if (tl) tl_t[0] = __builtin_amdgcn_s_memtime(), tl_t[4] = __builtin_amdgcn_s_memrealtime();
+#endif
   issue(0, 0);
   // data-gradient launches with the BatchNorm-backward statistics epilogue: its y / keep-mask reads are issued HERE, a whole
   // channel loop ahead of their use (this kernel has the 40 registers; the epilogue would otherwise sit out their latency)
@@ -536,6 +531,9 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   const int b_off = lane * NT;
   WSL_WAIT_ALL();
   __syncthreads();   // first chunk landed, zero slots visible
+#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
+  if (tl) tl_t[1] = __builtin_amdgcn_s_memtime();
+#endif
 
   // one chunk; FIRST: the accumulators start from the MFMA's zero C operand (no 128-register clear)
   auto chunk = [&](int c0, int bsel, auto first_tag) __attribute__((always_inline)) {
@@ -604,6 +602,9 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   };
   chunk(0, 0, std::true_type{});
   for (int c0 = KC, bsel = 1; c0 < Ci; c0 += KC, bsel ^= 1) chunk(c0, bsel, std::false_type{});
+#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
+  if (tl) tl_t[2] = __builtin_amdgcn_s_memtime();
+#endif
   if constexpr ((ABL & 4) != 0) {
     float t = 0.f;   // (keeps every accumulator alive)
 #pragma unroll
@@ -615,6 +616,20 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   }
   if (bn_epi) wino2_epilogue<C, TH, TW, NT, true>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
   else wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
+#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
+  if (tl) {
+    __syncthreads();
+    tl_t[3] = __builtin_amdgcn_s_memtime(), tl_t[5] = __builtin_amdgcn_s_memrealtime();
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (tid == 0) {
+      uint64_t* d = reinterpret_cast<uint64_t*>(p.stat_part) + 8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
+      for (int k = 0; k < 6; ++k) d[k] = tl_t[k];
+      d[6] = hw, d[7] = xcc;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ filter transform

@@ -342,15 +342,9 @@ struct ConvSpCfg {
   static constexpr int B_PIECES = B_BYTES / 16, NBW = (B_PIECES + 255) / 256;
   static constexpr int RED_BYTES = 8 * CO_T * 4;
   // waves per SIMD the register allocator must leave room for (a tighter cap spills the staging state into scratch)
-#ifndef WSL_SP_MINW16
-#define WSL_SP_MINW16 3   // (A / B: 2 = no register cap for the 16-channel blocks: no spills, one workgroup per CU fewer)
-#endif
-  static constexpr int MINW = (NT == 1 && Img::NR == 1) ? WSL_SP_MINW16 : 2;
-#ifndef WSL_SP_DB
-#define WSL_SP_DB 1       // (A / B: 0 = one streamed weight buffer for every block width)
-#endif
+  static constexpr int MINW = (NT == 1 && Img::NR == 1) ? 3 : 2;   // (measured against 2 for the 16-channel blocks: profiles/r4_minw_ab.log)
   // streamed weight blocks double-buffered where two workgroups per CU still fit: 32 KB image + 2 x 20 KB + table <= 80 KB
-  static constexpr bool DB = WSL_SP_DB && CO_T <= 32;
+  static constexpr bool DB = CO_T <= 32;
   static constexpr int COEF_BYTES_PER_CH = 8;                      // {scale, shift} x operand scale, [octet][scale x 8 | shift x 8]
   // Resident-weight kernels (<= 64 input channels = 8 octets) keep the table in the tail padding of the image planes (ROWS * ROWB = 8000 of
   // 8192 bytes used: three 64-byte octet entries per plane, four planes): the 16-wide blocks sit exactly at three workgroups per CU
@@ -444,10 +438,7 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
   // The 64-wide block with the statistics epilogue is the one instantiation whose register file is full: it recomputes the six offsets
   // per item (a dozen instructions in front of 240 MFMAs) from a lane index hipcc cannot trace back to threadIdx -- kept across the tile
   // loop they are live through the staging code -- and fences the scheduler between K-steps (below); without both it spills
-#ifndef WSL_SP_TIGHT
-#define WSL_SP_TIGHT 1    // (A / B: 0 = never, 2 = every 64-wide instantiation)
-#endif
-  constexpr bool kTightRegs = C::NT == 4 && (WSL_SP_TIGHT == 2 || (WSL_SP_TIGHT == 1 && EPI == 1));
+  constexpr bool kTightRegs = C::NT == 4 && EPI == 1;
   constexpr bool kOffsetsPerItem = kTightRegs;
   if constexpr (!kOffsetsPerItem) operand_offsets(lane);
 
@@ -567,23 +558,14 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
       WSL_DETACH32(lv);
       operand_offsets(lv);
     }
-#ifndef WSL_SP_PIPE
-#define WSL_SP_PIPE 1     // blocks of <= 32 output channels: operands of the next group of MFMAs read while the current group issues, the order
-                          // pinned with sched_group_barrier (+0.45 % on the split step; 0 = hipcc's own placement;
-                          // profiles/r4_conv_sp_where_the_time_goes.md section 7)
-#endif
-#if WSL_SP_PIPE && !defined(WSL_HOST_EMUL)
+    // blocks of <= 32 output channels: operands of the next group of MFMAs read while the current group issues, the order pinned with
+    // sched_group_barrier (+0.45 % on the split step against hipcc's own placement; profiles/r4_conv_sp_where_the_time_goes.md section 7)
+#ifndef WSL_HOST_EMUL
 #define WSL_SP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #else
 #define WSL_SP_SGB(mask, n)
 #endif
-#ifndef WSL_SP_PRIO
-#define WSL_SP_PRIO 0     // (EXPERIMENT, not in the product: issue priority of a wave raised to this value for the duration of its MFMA loop)
-#endif
-#if WSL_SP_PRIO && !defined(WSL_HOST_EMUL)
-    __builtin_amdgcn_s_setprio(WSL_SP_PRIO);
-#endif
-    constexpr bool kPipe = WSL_SP_PIPE && C::NT <= 2;
+    constexpr bool kPipe = C::NT <= 2;
     if constexpr (kPipe) {
       // groups g = (K-step s, row-tile pair i0): A operands double-buffered per group, B operands per K-step
       constexpr int GPS = C::MT / 2, G = 5 * GPS;
@@ -672,9 +654,6 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
       // inside the tile loop, and a spill reload is a vector-memory load that waits for every prefetch in flight
       if constexpr (kTightRegs) WSL_SCHED_BARRIER();
     }
-#if WSL_SP_PRIO && !defined(WSL_HOST_EMUL)
-    __builtin_amdgcn_s_setprio(0);
-#endif
     WSL_LDS_BARRIER();   // the tile image and this chunk's weight block are free again
     if constexpr (!BRES && !DB) if (nt < tend && !WSL_ABLATED(p, 16)) dma_weights(nc0, 0);
     if constexpr (DB) buf ^= 1;
@@ -730,7 +709,10 @@ __global__ __launch_bounds__(256, (ConvSpCfg<TH, TW, CO_T>::MINW)) void conv_sp_
               *reinterpret_cast<float4*>(yj + (i / C::SEGS) * W + (i % C::SEGS) * 16 + lane_off) = make_float4(v[0], v[1], v[2], v[3]);
           }
         }
-        stored = true;
+        // WSL_VM_WAIT(C::MT * C::NT) above counts exactly THESE stores: it may only be taken when every one of them was issued
+        // (the ablation build skips them), and the count must fit the 6-bit vmcnt field
+        static_assert(C::MT * C::NT <= 63, "vmcnt field");
+        stored = !WSL_ABLATED(p, 4);
       }
       if constexpr (EPI == 2) bn_bwd_store<C::NT, CO_T, true>(p.bn, s1, s2, red, co0, Co, t, nb);
       if constexpr (EPI == 1) {
@@ -799,10 +781,7 @@ static SpPlan sp_plan(int N, int H, int W, int Ci, int Co, bool want_bn_epilogue
   // kernel is short of) then feeds 240 / 120 MFMAs per wave instead of 120 / 60
   // (16-column tiles: not where the caller wants the BatchNorm-backward statistics from the epilogue -- only blocks of <= 2 column tiles
   //  have the registers for them, and at 16 x 16 the stand-alone reduction pass costs more than the wider block saves)
-#ifndef WSL_SP_BN_CAP32
-#define WSL_SP_BN_CAP32 0   // (A / B: 1 = never a 64-wide block where the BatchNorm-backward statistics are wanted from the epilogue)
-#endif
-  if (Co % 64 == 0 && tiles * (Co / 64) >= 2 * device_cu_count() && !(want_bn_epilogue && (f.tw == 16 || WSL_SP_BN_CAP32))) f.co_t = 64;
+  if (Co % 64 == 0 && tiles * (Co / 64) >= 2 * device_cu_count() && !(want_bn_epilogue && f.tw == 16)) f.co_t = 64;
   f.ok = true;
   return f;
 }
@@ -917,14 +896,10 @@ struct WgradSpP {
 
 template <int TH, int TW, int CB>
 struct WgradSpCfg {
-#ifdef WSL_SP_WG_LAYOUT2   // A / B build (tools/build_sp_variants.sh): the pitch / plane offset that halves the transpose reads' bank
-                           // conflicts in the model of tools/lds_tr_conflicts.py (profiles/r3_wgrad_sp_lds_conflicts.md); 32-pixel rows only
-  using In = SpImg<TH + 2, (TW + 8) / 4, CB / 8, (TW == 32 ? 12 : (TW + 8) / 4), (TW == 32 ? 16 : 0)>;
-  using Dy = SpImg<TH, TW / 4, CB / 8, (TW == 32 ? 12 : TW / 4), (TW == 32 ? 16 : 0)>;
-#else
+  // (a pitch / plane offset that halves the transpose reads' bank conflicts in the model of tools/lds_tr_conflicts.py measured no faster:
+  //  profiles/r3_wgrad_sp_lds_conflicts.md, profiles/r4_conv_sp_rework_ab.log)
   using In = SpImg<TH + 2, (TW + 8) / 4, CB / 8, (TW + 8) / 4>;
   using Dy = SpImg<TH, TW / 4, CB / 8, TW / 4>;
-#endif
   static constexpr int KS = TH * TW / 32, KROWS = 32 / TW;      // K-steps per tile; tile rows per K-step
   static constexpr size_t SMEM = In::BYTES + Dy::BYTES;
   static_assert(TW == 16 || TW == 32, "a K-step is one row of 32 pixels or two rows of 16");

@@ -269,10 +269,21 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* part, i
   __shared__ double tot[64];
   {
     const int w = threadIdx.x >> 6, k = threadIdx.x & 63;
-    double acc = 0;
-    if (k < K)
-      for (int b = w; b < nblk; b += 4) acc += part[(int64_t)b * K + k];
-    red4[w][k] = acc;
+    // (eight rows in flight per thread: one dependent load per iteration made this single-workgroup kernel 64 us of L2 round trips --
+    //  round 5; the eight partial sums are merged in a fixed order)
+    double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k < K) {
+      int b = w;
+      for (; b + 28 < nblk; b += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + 4 * u) * K + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] += (double)v[u];
+      }
+      for (; b < nblk; b += 4) a8[0] += part[(int64_t)b * K + k];
+    }
+    red4[w][k] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     __syncthreads();
     if (threadIdx.x < 64) tot[threadIdx.x] = (red4[0][threadIdx.x] + red4[1][threadIdx.x]) + (red4[2][threadIdx.x] + red4[3][threadIdx.x]);
     __syncthreads();
@@ -1241,7 +1252,9 @@ extern "C" int wsl_head_reg_fwd_bwd(const float* z, const uint8_t* label, int ig
   float* scal = part + (size_t)kMaxBlocks * kMaxK;
   // the regulariser's partial sums: the head's own partials (ws[0 .. kMaxBlocks * kMaxK)) are dead once its finalize kernel ran, but its
   // coefficients `scal` right behind them (and the Mumford-Shah moments behind those) must survive until the last pass -- small
-  // problems re-use the head's region, large ones (more TV tiles than it holds) the rest of the workspace behind the moments
+  // problems re-use the head's region, large ones (more TV tiles than it holds) the rest of the workspace behind the moments.
+  // Workspace layout (wsl_loss_ws_bytes, floats): [part: max(tiles, kMaxBlocks) * kMaxK][scal: 64][mom: N * chunks * (kMaxC + 1)][CRF /
+  // large-layout regulariser partials: 2 * N * (HW / 256 + 64)] -- the bound is checked below, not assumed
   const int chunks = cdiv(HW, 4096);
   float* mom = scal + 64;
   const size_t rneed = (size_t)N * C * cdiv(W, 16) * cdiv(H, 16) + (size_t)N * chunks * 2 + kMaxBlocks;
@@ -1273,6 +1286,8 @@ extern "C" int wsl_head_reg_fwd_bwd(const float* z, const uint8_t* label, int ig
       const double numel = (double)N * C * HW;
       WSL_LAUNCH(softmax_mse_ds_kernel, dim3(nb), dim3(kThreads), 0, stream, s, zt, C, HW, h.P, (float)(cons_weight / numel), ds, rpart);
       WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, rpart, nb, 1, 1.0 / numel, out + 5);
+    } else {
+      WSL_LAUNCH(sum_finalize_kernel, dim3(1), dim3(kThreads), 0, stream, rpart, 0, 1, 0.0, out + 5);   // no teacher: out[5] = 0, never stale
     }
   }
   {   // pass 2: dz = w_ce * dCE/dz + softmax_backward(s, ds) -- written once

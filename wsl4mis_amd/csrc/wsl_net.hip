@@ -46,8 +46,11 @@ struct Plan {
   int sp;
   size_t wg_bytes, bn_bytes, bn_coef_bytes, total_floats;   // wg_bytes: per scratch set, room for the partials of EVERY layer of a phase
   // named regions of the workspace, in allocation order (wsl_debug_net_ws_region: the tools that compare two runs' workspaces)
+  // (recorded only when want_regions is set -- by wsl_debug_net_ws_region alone: make_plan runs several times per training step and has no
+  //  use for a hundred formatted names; overflow is an error of the debug entry point, never a silent truncation)
   struct Region { char name[48]; size_t off, n; } regs[192];
   int nregs;
+  bool want_regions = false, regs_overflow = false;
 };
 
 struct Bump {
@@ -122,10 +125,14 @@ static int make_plan(const WslNetDesc* d, Plan& P) {
     size_t& off;
     size_t take(size_t n, const char* what = "") {
       const size_t o = b.take(n);
-      if (P.nregs < 192) {
-        Plan::Region& r = P.regs[P.nregs++];
-        snprintf(r.name, sizeof(r.name), "%s[%d,%d].%s", tag, i0, i1, what);
-        r.off = o, r.n = n;
+      if (P.want_regions) {
+        if (P.nregs < 192) {
+          Plan::Region& r = P.regs[P.nregs++];
+          snprintf(r.name, sizeof(r.name), "%s[%d,%d].%s", tag, i0, i1, what);
+          r.off = o, r.n = n;
+        } else {
+          P.regs_overflow = true;
+        }
       }
       return o;
     }
@@ -749,7 +756,9 @@ __global__ __launch_bounds__(256) void dbg_argmax_kernel(const float* y, const f
 
 extern "C" int wsl_debug_net_ws_region(const WslNetDesc* d, int index, char* name, size_t name_len, size_t* off_floats, size_t* n_floats) {
   Plan P;
+  P.want_regions = true;
   WSL_TRY(make_plan(d, P));
+  WSL_REQUIRE(!P.regs_overflow, "debug_net_ws_region: more than 192 workspace regions (raise Plan::regs)");
   if (index < 0 || index >= P.nregs) return 1;   // (past the end: not an error worth a message)
   WSL_REQUIRE(name && name_len > 0 && off_floats && n_floats, "debug_net_ws_region: null argument");
   snprintf(name, name_len, "%s", P.regs[index].name);

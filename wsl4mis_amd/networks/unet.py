@@ -416,4 +416,11 @@ class UpBlock(nn.Module):
         # training-mode BatchNorm); wrap evaluation in torch.no_grad() as the reference's val_2D.py does
         if torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad):
             raise NotImplementedError("UpBlock: gradients in eval mode are not built; call .train() or wrap the forward in torch.no_grad()")
+        if torch.is_grad_enabled() and not self.training and not getattr(self, "_warned_eval_grad", False) and \
+                any(p.requires_grad for p, _, _, _ in self._plist):
+            import warnings     # (a loss computed under .eval() with grad enabled would otherwise fail late or train nothing)
+            warnings.warn("UpBlock.forward in eval mode returns a tensor WITHOUT an autograd graph although its parameters require grad: "
+                          "parameter gradients in eval mode are not built -- call .train() for training or wrap evaluation in torch.no_grad()",
+                          RuntimeWarning, stacklevel=2)
+            self._warned_eval_grad = True
         return self._run_forward(x1, x2)
