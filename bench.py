@@ -129,28 +129,44 @@ def cpu_baseline(args):
         return {"batch": B, "value": round(B * iters / dt, 3), "timed_steps": iters, "seconds": round(dt, 2)}
 
     # the host's best.  Thread sweep up to every core (torch's intra-op pool; oneDNN convolutions stop scaling long before
-    # 256 threads on these shapes, which is why the sweep exists) at the small batch; then batch 16 and -- if the budget allows -- the
-    # GPU line's own batch 64 at the best thread count.  About 30 s of CPU work on the GPU box's host.
+    # 256 threads on these shapes, which is why the sweep exists) at the small batch, starting from the count that was best in earlier
+    # rounds; then batch 16 and -- if the budget allows -- the GPU line's own batch 64 at the best thread count.  Bounded: a leg is
+    # started only while the whole CPU part is under ~70 s, and every finished leg is printed at once (the parent keeps what arrived
+    # if the time-out cuts the rest).
     if args.cpu_threads:
         sweep = [args.cpu_threads]
     else:
-        sweep = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} or {ncpu})
+        sweep = [t for t in (32, 64, 128, ncpu, 16) if t <= ncpu] or [ncpu]
+        sweep = list(dict.fromkeys(sweep))
     legs = []
     t_start = time.perf_counter()
-    for t in sweep:
-        torch.set_num_threads(t)
-        r = leg(args.cpu_batch, 2.5)
-        r["threads"] = t
+
+    def run_leg(B, threads, budget):
+        torch.set_num_threads(threads)
+        r = leg(B, budget)
+        r["threads"] = threads
         legs.append(r)
+        print("LEG " + json.dumps(r), flush=True)
+
+    # (measured on the GPU box's 256-core host, round 5: 32 threads 14.4 slices/s, 64: 6.5, 128: 2.0, 256: minutes per step -- the sweep
+    #  walks up from 32 only while it still gains, then tries 16)
+    for t in sweep:
+        if legs and time.perf_counter() - t_start > 50.0:
+            break
+        if legs and t > legs[-1]["threads"] and legs[-1]["value"] < 0.95 * max(r["value"] for r in legs):
+            continue                                            # more threads already lost: do not go further up
+        run_leg(args.cpu_batch, t, 2.5)
     n_thr = max(legs, key=lambda r: r["value"])["threads"]
-    torch.set_num_threads(n_thr)
     if not args.cpu_one_batch:
         rate = max(r["value"] for r in legs)
-        for B in (16, 64):     # larger batches at the best thread count, while three steps of them fit what is left of ~60 s
-            if B != args.cpu_batch and (time.perf_counter() - t_start) + 3.0 * B / rate < 60.0:
-                r = leg(B, 3.0)
-                r["threads"] = n_thr
-                legs.append(r)
+        for B in (16, 64):     # larger batches at the best thread count, while three steps of them fit what is left of ~70 s
+            if B != args.cpu_batch and (time.perf_counter() - t_start) + 3.0 * B / rate < 70.0:
+                run_leg(B, n_thr, 3.0)
+    return cpu_result(args, legs, sweep, ncpu, crf)
+
+
+def cpu_result(args, legs, sweep, ncpu, crf):
+    S = args.size
     best = max(legs, key=lambda r: r["value"])
     return {"value": best["value"], "unit": "slices/s", "cores": best["threads"], "kind": "port",
             "sample": f"oracle/torch_ref.py (stock torch CPU ops = what the reference's CPU path executes), {args.net} {args.loss}"
@@ -168,14 +184,23 @@ def cpu_baseline_subprocess(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--loss", args.loss, "--net", args.net,
            "--size", str(args.size), "--crf-radius", str(args.crf_radius), "--cpu-batch", str(args.cpu_batch),
            "--cpu-iters", str(args.cpu_iters), "--cpu-threads", str(args.cpu_threads)] + (["--cpu-one-batch"] if args.cpu_one_batch else [])
+    def partial(out, why):
+        legs = [json.loads(ln[4:]) for ln in (out or "").splitlines() if ln.startswith("LEG ")]
+        if not legs:
+            return {"value": None, "unit": "slices/s", "cores": 0, "kind": "port", "sample": why}
+        crf = args.crf_radius if args.loss == "pce_gatedcrf" else None
+        res = cpu_result(args, legs, sorted({r["threads"] for r in legs}), os.cpu_count() or 1, crf)
+        res["sample"] += f" [{why}: the legs that had finished]"
+        return res
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=200, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
-        return {"value": None, "unit": "slices/s", "cores": 0, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "slices/s", "cores": 0, "kind": "port", "sample": "timed out after 240 s"}
+        return partial(r.stdout, "failed: " + r.stderr[-300:])
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else e.stdout
+        return partial(out, "timed out after 200 s")
 
 
 def main():

@@ -499,14 +499,6 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     for (int i = 0; i < C::NWL; ++i) WSL_LDS_DMA16_UNTRACKED_SO(wb + i * (4 * kThreads), (uint32_t)tid * 16u, wdst + i * (4 * kThreads));
   };
 
-#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
-  // (experiments build, env WSL_CONV_ABLATE & 128: per-workgroup timeline -- shader-clock stamps at entry / first chunk landed / channel
-  //  loop done / end, the 100 MHz real-time counter at entry and end, HW_ID and XCC_ID -- dumped over the BatchNorm partials;
-  //  tools/timeline_wino2r.py)
-  const bool tl = (p.ablate & 128) != 0 && p.stat_part != nullptr;
-  uint64_t tl_t[6] = {0, 0, 0, 0, 0, 0};
-  if (tl) tl_t[0] = __builtin_amdgcn_s_memtime(), tl_t[4] = __builtin_amdgcn_s_memrealtime();
-#endif
   issue(0, 0);
   // data-gradient launches with the BatchNorm-backward statistics epilogue: its y / keep-mask reads are issued HERE, a whole
   // channel loop ahead of their use (this kernel has the 40 registers; the epilogue would otherwise sit out their latency)
@@ -531,9 +523,6 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   const int b_off = lane * NT;
   WSL_WAIT_ALL();
   __syncthreads();   // first chunk landed, zero slots visible
-#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
-  if (tl) tl_t[1] = __builtin_amdgcn_s_memtime();
-#endif
 
   // one chunk; FIRST: the accumulators start from the MFMA's zero C operand (no 128-register clear)
   auto chunk = [&](int c0, int bsel, auto first_tag) __attribute__((always_inline)) {
@@ -602,9 +591,6 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   };
   chunk(0, 0, std::true_type{});
   for (int c0 = KC, bsel = 1; c0 < Ci; c0 += KC, bsel ^= 1) chunk(c0, bsel, std::false_type{});
-#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
-  if (tl) tl_t[2] = __builtin_amdgcn_s_memtime();
-#endif
   if constexpr ((ABL & 4) != 0) {
     float t = 0.f;   // (keeps every accumulator alive)
 #pragma unroll
@@ -616,20 +602,6 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   }
   if (bn_epi) wino2_epilogue<C, TH, TW, NT, true>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
   else wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
-#if defined(WSL_EXPERIMENTS) && !defined(WSL_HOST_EMUL)
-  if (tl) {
-    __syncthreads();
-    tl_t[3] = __builtin_amdgcn_s_memtime(), tl_t[5] = __builtin_amdgcn_s_memrealtime();
-    unsigned hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    if (tid == 0) {
-      uint64_t* d = reinterpret_cast<uint64_t*>(p.stat_part) + 8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
-      for (int k = 0; k < 6; ++k) d[k] = tl_t[k];
-      d[6] = hw, d[7] = xcc;
-    }
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ filter transform
