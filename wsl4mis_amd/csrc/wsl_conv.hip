@@ -802,6 +802,49 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(ReduceTable t) 
   }
 }
 
+// the same second stage with four consecutive elements per thread (512-byte instead of 128-byte runs per split row; round 5: 67 us per
+// launch at 2 TB/s before): a workgroup = 128 consecutive elements x 8 split groups; the same sums in the same order, element by element
+__global__ __launch_bounds__(256) void wgrad_reduce_batch4_kernel(ReduceTable t) {
+  __shared__ float4 red[kThreads];
+  constexpr int SG = 8, EPB = kThreads / SG;
+  int li = 0;
+  for (int i = 1; i < t.n; ++i) li = (int64_t)blockIdx.x >= t.e[i].blk0 ? i : li;   // uniform
+  const ReduceTable::E& L = t.e[li];
+  const int64_t E = (int64_t)L.KK * L.Co * L.Ci;
+  const int64_t total = E + (L.db ? L.Co : 0);
+  const int el = threadIdx.x % EPB, sg = threadIdx.x / EPB;
+  const int64_t e = (((int64_t)blockIdx.x - L.blk0) * EPB + el) * 4;   // E and Co are multiples of 4: a quad never straddles the two regions
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < total) {
+    const float* src = e < E ? L.pdw + e : L.pdb + (e - E);
+    const int64_t stride = e < E ? E : L.Co;
+#pragma unroll 4
+    for (int k = sg; k < L.nsplit; k += SG) {
+      const float4 v = *reinterpret_cast<const float4*>(src + k * stride);
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sg == 0 && e < total) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < SG; ++k) {
+      const float4 r = red[k * EPB + el];
+      v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
+    }
+    if (e < E) {
+      const int64_t CC = (int64_t)L.Co * L.Ci;
+      const int tap = (int)(e / CC);             // (CC is a multiple of 4: the quad stays inside one tap)
+      const int64_t rem = e - (int64_t)tap * CC;  // co*Ci + ci
+#pragma unroll
+      for (int q = 0; q < 4; ++q) L.dw[(rem + q) * L.KK + tap] = v[q];
+    } else {
+      *reinterpret_cast<float4*>(L.db + (e - E)) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 }  // namespace wsl
 
 extern "C" int wsl_wgrad_reduce_batch(const WslWgradPending* items, int n, void* stream) {
@@ -811,16 +854,24 @@ extern "C" int wsl_wgrad_reduce_batch(const WslWgradPending* items, int n, void*
     t.n = n - i0 < kReduceMax ? n - i0 : kReduceMax, t._pad = 0;
     int64_t blk = 0;
     double bytes = 0.0;
+    bool quad = true;   // four elements per thread where every layer of the batch allows it
     for (int i = 0; i < t.n; ++i) {
       const WslWgradPending& q = items[i0 + i];
       WSL_REQUIRE(q.part_dw && q.dw && q.Co > 0 && q.Ci > 0 && q.KK > 0 && q.nsplit > 0, "wgrad_reduce_batch: item %d is malformed", i0 + i);
+      quad = quad && ((int64_t)q.Co * q.Ci) % 4 == 0 && q.Co % 4 == 0 && (reinterpret_cast<uintptr_t>(q.part_dw) & 15) == 0 &&
+             (!q.db || ((reinterpret_cast<uintptr_t>(q.part_db) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.db) & 15) == 0));
+    }
+    const int epw = quad ? 128 : 32;
+    for (int i = 0; i < t.n; ++i) {
+      const WslWgradPending& q = items[i0 + i];
       const int64_t total = (int64_t)q.KK * q.Co * q.Ci + (q.db ? q.Co : 0);
       t.e[i] = ReduceTable::E{q.part_dw, q.part_db, q.dw, q.db, q.Co, q.Ci, q.KK, q.nsplit, blk};
-      blk += (total + 31) / 32;
+      blk += (total + epw - 1) / epw;
       bytes += 4.0 * (double)total * (q.nsplit + 1);
     }
     ProfScope ps(PF_WGRAD_REDUCE, 0.0, bytes, stream);
-    WSL_LAUNCH(wgrad_reduce_batch_kernel, dim3((unsigned)blk), dim3(kThreads), 0, stream, t);
+    if (quad) WSL_LAUNCH(wgrad_reduce_batch4_kernel, dim3((unsigned)blk), dim3(kThreads), 0, stream, t);
+    else WSL_LAUNCH(wgrad_reduce_batch_kernel, dim3((unsigned)blk), dim3(kThreads), 0, stream, t);
   }
   return check_launch("wgrad_reduce_batch_kernel");
 }
