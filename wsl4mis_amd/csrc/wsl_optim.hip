@@ -75,8 +75,34 @@ struct MaskTable {
 
 __global__ __launch_bounds__(256) void masks_kernel(MaskTable t, uint32_t k0, uint32_t k1) {
   const int m = blockIdx.y;
-  const int64_t n4 = (t.e[m].numel + 3) >> 2;
   const uint32_t th = t.e[m].thresh;
+  if (!t.e[m].is_f32) {
+    // uint8 keep masks (one byte per activation element, 130 MB per step at N = 64): SIXTEEN random bits per element, eight elements per
+    // Philox call -- the generator's integer multiplies are what this kernel is made of (68 -> ~36 us per step); the keep probability is
+    // quantised to 1 / 65536 (0.95 -> 0.949997), far inside the sampling noise of any mask
+    const int64_t n8 = (t.e[m].numel + 7) >> 3;
+    const uint32_t th16 = th >> 16;
+    uint8_t* o = static_cast<uint8_t*>(t.e[m].out);
+    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < n8; q += (int64_t)gridDim.x * kThreads) {
+      uint32_t r[4];
+      philox4(k0, k1, (uint32_t)q, (uint32_t)(q >> 32), (uint32_t)m, 0x57534c38u, r);
+      const int64_t e = q << 3;
+      uint32_t lo = 0, hi = 0;   // bytes 0-3 and 4-7
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        lo |= ((r[k] & 0xffffu) < th16 ? 1u : 0u) << (16 * k) | ((r[k] >> 16) < th16 ? 1u : 0u) << (16 * k + 8);
+        hi |= ((r[2 + k] & 0xffffu) < th16 ? 1u : 0u) << (16 * k) | ((r[2 + k] >> 16) < th16 ? 1u : 0u) << (16 * k + 8);
+      }
+      if (e + 7 < t.e[m].numel && (reinterpret_cast<uintptr_t>(o) & 7) == 0) {
+        *reinterpret_cast<uint64_t*>(o + e) = (uint64_t)lo | ((uint64_t)hi << 32);
+      } else {
+        for (int k = 0; k < 8; ++k)
+          if (e + k < t.e[m].numel) o[e + k] = (uint8_t)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 1u);
+      }
+    }
+    return;
+  }
+  const int64_t n4 = (t.e[m].numel + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < n4; q += (int64_t)gridDim.x * kThreads) {
     uint32_t r[4];
     philox4(k0, k1, (uint32_t)q, (uint32_t)(q >> 32), (uint32_t)m, 0x57534c34u, r);
@@ -157,7 +183,7 @@ extern "C" int wsl_draw_masks(int n_masks, void* const* outs, const int64_t* num
     t.e[i].thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
     if (numels[i] > biggest) biggest = numels[i];
   }
-  int64_t blocks = (biggest / 4 + kThreads - 1) / kThreads;
+  int64_t blocks = (biggest / 8 + kThreads - 1) / kThreads;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
   double mbytes = 0.0;
