@@ -812,6 +812,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float
 __global__ __launch_bounds__(256) void pack_table_kernel(PackTable t, const float* params, float* packf, float* packd) {
   const PackEntry e = t.e[blockIdx.y];
   const int dgrad = blockIdx.z;
+  if ((e._pad >> dgrad) & 1) return;   // (the network's launches of this layer and direction take the Winograd image: wsl_net.hip, pack_all)
   const int Co = dgrad ? e.Ci : e.Co, Ci = dgrad ? e.Co : e.Ci, KK = e.KK;   // GEMM-out / GEMM-in of this image
   const float* w = params + e.w;
   float* wp = (dgrad ? packd : packf) + e.w;

@@ -644,23 +644,64 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* w, float* u
 }
 
 // every 3x3 layer of a network in ONE launch: blockIdx.y = layer, blockIdx.z = 0 forward image / 1 data-gradient image;
-// the images live at twice the raw weight's arena offset (16/9 of its size)
+// the images live at twice the raw weight's arena offset (16/9 of its size).  A workgroup builds one (chunk, channel block) = one
+// contiguous 16 x 8 x co_t block of the image at a time: its 8 x co_t (ci, co) pairs read their nine taps in runs along the raw tensor's
+// fastest axis, the sixteen transformed values go to their operand slots in LDS, and the block leaves as a linear float4 copy
+// (round 5: the one-pair-per-thread form wrote 34 MB per step in scattered 4-byte stores, 50 us; wino_filter above keeps that form for
+// the single-layer entry point)
 __global__ __launch_bounds__(256) void wino_pack_table_kernel(PackTable t, const float* params, float* uf, float* ud) {
+  __shared__ __attribute__((aligned(16))) float blk[16 * 8 * 32];
   const PackEntry e = t.e[blockIdx.y];
   if (e.KK != 9) return;
   const int dgrad = blockIdx.z;
   const int Co = dgrad ? e.Ci : e.Co, Ci = dgrad ? e.Co : e.Ci;
   if (Ci % 8 || Co % 16) return;   // not a Winograd layer in this direction (the blocked image needs whole blocks)
-  const int64_t total = (int64_t)Ci * Co;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads)
-    wino_filter(params + e.w, (dgrad ? ud : uf) + 2 * e.w, Co, Ci, dgrad, i);
+  const int co_t = (Co % 32 == 0) ? 32 : 16, nt = co_t / 16, ncb = Co / co_t, nblocks = (Ci / 8) * ncb;
+  const float* w = params + e.w;
+  float* u = (dgrad ? ud : uf) + 2 * e.w;
+  const int tid = threadIdx.x;
+  // forward: w[co][ci][tap] -- ci fastest among the threads; data gradient: w[ci][co][8 - tap] with the roles swapped -- co fastest
+  const int ci_l = dgrad ? tid / co_t : tid % 8, co_l = dgrad ? tid % co_t : tid / 8;
+  const bool live = tid < 8 * co_t;
+  const int xs = 4 * 16 * 2 * nt;   // floats per transform position
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int chunk = b / ncb, cob = b - chunk * ncb;
+    if (live) {
+      const int ci = chunk * 8 + ci_l, co = cob * co_t + co_l;
+      float g[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        g[tap] = dgrad ? w[((int64_t)ci * Co + co) * 9 + (8 - tap)] : w[((int64_t)co * Ci + ci) * 9 + tap];
+      float tt[4][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        tt[0][c] = g[c];
+        tt[1][c] = 0.5f * ((g[c] + g[3 + c]) + g[6 + c]);
+        tt[2][c] = 0.5f * ((g[c] - g[3 + c]) + g[6 + c]);
+        tt[3][c] = g[6 + c];
+      }
+      const int kg = (ci_l >> 2) & 1, k = ci_l & 3, j = co_l >> 4, col = co_l & 15;
+      float* dst = blk + kg * (64 * nt) + (k * 16 + col) * nt + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dst[(4 * r + 0) * xs] = tt[r][0];
+        dst[(4 * r + 1) * xs] = 0.5f * ((tt[r][0] + tt[r][1]) + tt[r][2]);
+        dst[(4 * r + 2) * xs] = 0.5f * ((tt[r][0] - tt[r][1]) + tt[r][2]);
+        dst[(4 * r + 3) * xs] = tt[r][2];
+      }
+    }
+    __syncthreads();
+    float* out = u + (int64_t)b * (16 * 8 * co_t);
+    for (int q = tid; q < 16 * 8 * co_t / 4; q += kThreads) reinterpret_cast<float4*>(out)[q] = reinterpret_cast<const float4*>(blk)[q];
+    __syncthreads();
+  }
 }
 
 int wino_pack_table(const PackTable& t, const float* params, float* uf, float* ud, int with_dgrad, void* stream) {
   double e = 0.0;
   for (int i = 0; i < t.n; ++i) e += t.e[i].KK == 9 ? (double)t.e[i].Co * t.e[i].Ci : 0.0;
   ProfScope ps(PF_PREP, 0.0, 4.0 * e * (9.0 + 16.0 * (with_dgrad ? 2.0 : 1.0)), stream);
-  WSL_LAUNCH(wino_pack_table_kernel, dim3(16, t.n, with_dgrad ? 2 : 1), dim3(kThreads), 0, stream, t, params, uf, ud);
+  WSL_LAUNCH(wino_pack_table_kernel, dim3(32, t.n, with_dgrad ? 2 : 1), dim3(kThreads), 0, stream, t, params, uf, ud);
   return check_launch("wino_pack_table_kernel");
 }
 

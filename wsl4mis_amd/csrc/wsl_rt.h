@@ -429,7 +429,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct PackEntry {
   int64_t w;       // offset of the raw [Co][Ci][ks][ks] weight in the parameter arena (= offset of its packed images)
   int Co, Ci, KK;
-  int _pad;
+  int _pad;        // pack_table_kernel: bit 0 / bit 1 = skip the direct forward / data-gradient image (nobody reads it)
 };
 struct PackTable {
   int n;
