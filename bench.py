@@ -136,7 +136,7 @@ def cpu_baseline(args):
     if args.cpu_threads:
         sweep = [args.cpu_threads]
     else:
-        sweep = [t for t in (32, 64, 128, ncpu, 16) if t <= ncpu] or [ncpu]
+        sweep = [t for t in (32, 64, 128, ncpu, 16, 8, 4) if t <= ncpu] or [ncpu]
         sweep = list(dict.fromkeys(sweep))
     legs = []
     t_start = time.perf_counter()
@@ -149,12 +149,15 @@ def cpu_baseline(args):
         print("LEG " + json.dumps(r), flush=True)
 
     # (measured on the GPU box's 256-core host, round 5: 32 threads 14.4 slices/s, 64: 6.5, 128: 2.0, 256: minutes per step -- the sweep
-    #  walks up from 32 only while it still gains, then tries 16)
+    #  walks up from 32 only while it still gains, then down -- 16, 8, 4 -- on the same rule)
     for t in sweep:
         if legs and time.perf_counter() - t_start > 50.0:
             break
-        if legs and t > legs[-1]["threads"] and legs[-1]["value"] < 0.95 * max(r["value"] for r in legs):
+        best_so_far = max((r["value"] for r in legs), default=0.0)
+        if legs and t > legs[-1]["threads"] and legs[-1]["value"] < 0.95 * best_so_far:
             continue                                            # more threads already lost: do not go further up
+        if legs and t < 32 and t < legs[-1]["threads"] and legs[-1]["threads"] < 32 and legs[-1]["value"] < 0.95 * best_so_far:
+            continue                                            # ... nor further down once fewer threads lost
         run_leg(args.cpu_batch, t, 2.5)
     n_thr = max(legs, key=lambda r: r["value"])["threads"]
     if not args.cpu_one_batch:
