@@ -165,6 +165,8 @@ def cpu_baseline(args):
         for B in (16, 64):     # larger batches at the best thread count, while three steps of them fit what is left of ~70 s
             if B != args.cpu_batch and (time.perf_counter() - t_start) + 3.0 * B / rate < 70.0:
                 run_leg(B, n_thr, 3.0)
+                if legs[-1]["value"] < 0.9 * rate:
+                    break          # a larger batch already lost (the host is cache-bound): batch 64 would only cost half a minute
     return cpu_result(args, legs, sweep, ncpu, crf)
 
 
