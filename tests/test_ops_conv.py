@@ -202,6 +202,42 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
     assert close(be.np(db), bt.grad.numpy(), TOL)
 
 
+# (N, H, W, Ca, Cb, Co, persistent workgroups forced): Winograd weight-gradient launches whose workgroups walk several tiles each, in the
+# interleaved XCD-grouped order (splits % 8 == 0) and in contiguous runs (otherwise); tiles 4 x 64, 4 x 32, 8 x 16; one and two sources
+WALKS = [(3, 24, 64, 16, 0, 16, 8), (5, 16, 32, 16, 0, 16, 8), (2, 16, 128, 16, 0, 16, 8), (6, 16, 16, 16, 0, 16, 8),
+         (3, 16, 64, 32, 32, 32, 16), (3, 32, 16, 32, 0, 32, 8), (2, 8, 128, 16, 16, 16, 16), (3, 24, 64, 16, 0, 16, 5),
+         (2, 16, 64, 64, 0, 64, 32)]
+
+
+@pytest.mark.parametrize("case", WALKS)
+def test_wgrad_tile_walk_orders(be, variant, case):
+    N, H, W, Ca, Cb, Co, wgs = case
+    Ci = Ca + Cb
+    rng = np.random.default_rng(sum(case))
+    xa = rng.standard_normal((N, Ca, H, W)).astype(np.float32)
+    xb = rng.standard_normal((N, Cb, H, W)).astype(np.float32) if Cb else None
+    scale, shift = (rng.standard_normal(Ca) * 0.5 + 1).astype(np.float32), (rng.standard_normal(Ca) * 0.3).astype(np.float32)
+    va = virt_input(xa, scale, shift, None, 1.0, None)
+    vin = torch.cat([va, torch.from_numpy(xb)], 1) if Cb else va
+    wt = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    bt = torch.zeros(Co, requires_grad=True)
+    r = rng.standard_normal((N, Co, H, W)).astype(np.float32)
+    (F.conv2d(vin, wt, bt, padding=1) * torch.from_numpy(r)).sum().backward()
+    d = {k: (be.arr(v) if v is not None else None) for k, v in dict(xa=xa, xb=xb, scale=scale, shift=shift, r=r).items()}
+    sa = be.src(d["xa"], Ca, scale=d["scale"], shift=d["shift"])
+    sb = be.src(d["xb"], Cb) if Cb else be.src()
+    be.call("wsl_debug_wgrad_workgroups", wgs)
+    try:
+        nws = be.lib.wsl_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co, 3)
+        ws, dw, db = be.ws(nws), be.zeros((Co, Ci, 3, 3)), be.zeros((Co,))
+        be.call("wsl_conv2d_wgrad", sa, sb, be.ptr(d["r"]), Co * H * W, be.ptr(dw), be.ptr(db), N, H, W, Co, 3, be.ptr(ws), nws,
+                be.stream)
+        assert close(be.np(dw), wt.grad.numpy(), TOL)
+        assert close(be.np(db), bt.grad.numpy(), TOL)
+    finally:
+        be.call("wsl_debug_wgrad_workgroups", 0)
+
+
 def test_conv_channel_slice_views(be):
     """batch strides: read a channel slice of a wider tensor, write into a channel slice (no copies for cat/split)."""
     rng = np.random.default_rng(3)

@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_dw,
   }
 }
 
+static int g_forced_wgrad_wgs = 0;   // wsl_debug_wgrad_workgroups(): small launches walk several tiles per workgroup in the tests
 struct WgPlan {
   int th, tw, cb, ib, wk, nsplit, items, tiles_x, tiles_y, co_blocks, ci_blocks;
 };
@@ -505,7 +506,7 @@ static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co, bool v2 = false, b
   g.items = N * g.tiles_x * g.tiles_y;
   g.co_blocks = cdiv(Co, g.cb), g.ci_blocks = cdiv(Ci, g.ib);
   static const int wgs = WSL_TUNE("WSL_WGRAD_WGS", 768);   // 3 resident workgroups x 256 CUs
-  int want = (wide ? 512 : wgs) / (g.co_blocks * g.ci_blocks);
+  int want = (g_forced_wgrad_wgs > 0 ? g_forced_wgrad_wgs : wide ? 512 : wgs) / (g.co_blocks * g.ci_blocks);
   if (want < 1) want = 1;
   g.nsplit = g.items < want ? g.items : want;
   return g;
@@ -577,6 +578,11 @@ using namespace wsl;
 
 extern "C" int wsl_debug_conv_plan(int th, int tw, int co_t) {
   g_forced_plan[0] = th > 0 ? th : 0, g_forced_plan[1] = tw, g_forced_plan[2] = co_t;
+  return WSL_OK;
+}
+
+extern "C" int wsl_debug_wgrad_workgroups(int n) {
+  g_forced_wgrad_wgs = n > 0 ? n : 0;
   return WSL_OK;
 }
 

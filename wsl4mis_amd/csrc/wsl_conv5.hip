@@ -835,7 +835,7 @@ struct WgWinoP {
   int64_t dy_bs;
   float* part_dw;   // [nsplit][9][Co][Ci]
   float* part_db;   // [nsplit][Co]
-  int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, co_blocks;
+  int N, H, W, Ci, Co, tiles_x, tiles_y, items, nsplit, co_blocks, interleave;
 };
 
 template <int TH, int TW, int NCO, int NCI, int NW>   // NCO dY channel tiles per wave, NCI input-channel tiles and NW waves per workgroup
@@ -872,7 +872,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
   float* tiles = reinterpret_cast<float*>(smem);                    // NBUF x {dy tile, input tile}
   float2* tab = reinterpret_cast<float2*>(tiles + C::MAIN_FLOATS);   // [IB] {scale, shift} of this block's channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cb = blockIdx.x % p.co_blocks, ib = blockIdx.x / p.co_blocks, split = blockIdx.y;
+  // Which tiles a workgroup walks.  The hardware deals workgroups to the eight XCDs round-robin in launch order (x fastest) and every
+  // XCD has an L2 of its own, so (nsplit % 8 == 0) the workgroups of one XCD take ALL channel blocks of nsplit / 8 consecutive splits,
+  // and split s walks the tiles s, s + nsplit, s + 2 nsplit, ...: in every round the workgroups of an XCD stage neighbouring tiles
+  // together -- halo rows, the partly used 128-byte lines at a tile's left / right edge and the tiles the channel blocks share come out
+  // of that L2.  (Rounds 2-4 gave every split one contiguous run of tiles: by the time a workgroup came back to a halo line, 6 MB of
+  // other workgroups' tiles had gone through the 4 MB L2 -- 7 % hits, 2.1 x the algorithmic bytes fetched on the full-resolution
+  // layers, which made the kernel HBM-bound there: profiles/r5_wgrad_item_order.md.)
+  int blk = blockIdx.x, split = blockIdx.y;
+  const bool interleaved = (p.nsplit & 7) == 0 && p.interleave;
+  if (interleaved) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, j = lin >> 3;
+    blk = j % (int)gridDim.x;
+    split = (lin & 7) * (p.nsplit >> 3) + j / (int)gridDim.x;
+  }
+  const int cb = blk % p.co_blocks, ib = blk / p.co_blocks;
   const int co0 = cb * C::CB, ci0 = ib * C::IB;
   const int H = p.H, W = p.W, Ci = p.Ci;
   const int HW = H * W;
@@ -906,7 +920,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
   }
   const int cit = wave % NCI, sub = wave / NCI;
   const bool dbw = (ib == 0) && (p.part_db != nullptr) && cit == 0;
-  const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
+  // this workgroup's tiles: it0 + k * step, k < it_count; (tx, ty, n) advance by the step's own decomposition with carries
+  const int it0 = interleaved ? split : (int)((int64_t)split * p.items / p.nsplit);
+  const int it_count = interleaved ? (p.items - split + p.nsplit - 1) / p.nsplit : (int)((int64_t)(split + 1) * p.items / p.nsplit) - it0;
+  const int step = interleaved ? p.nsplit : 1;
   int nx_tx, nx_ty, nx_n;
   {
     int q = it0;
@@ -915,6 +932,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
     nx_ty = q % p.tiles_y;
     nx_n = q / p.tiles_y;
   }
+  const int st_tx = step % p.tiles_x, st_ty = (step / p.tiles_x) % p.tiles_y, st_n = step / (p.tiles_x * p.tiles_y);
   const int c16 = lane & 15, t4 = lane >> 4;
 
   // ---- staging: global -> registers (issue), registers -> transform -> LDS tile buffer (commit)
@@ -924,10 +942,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
   bool pr_aok = false;
   auto issue = [&]() __attribute__((always_inline)) {
     const int n = nx_n, y0 = nx_ty * TH, x0 = nx_tx * TW;
-    if (++nx_tx == p.tiles_x) {
-      nx_tx = 0;
-      if (++nx_ty == p.tiles_y) nx_ty = 0, ++nx_n;
-    }
+    nx_tx += st_tx;
+    const int cx = nx_tx >= p.tiles_x ? 1 : 0;
+    nx_tx -= cx ? p.tiles_x : 0;
+    nx_ty += st_ty + cx;
+    const int cy = nx_ty >= p.tiles_y ? 1 : 0;
+    nx_ty -= cy ? p.tiles_y : 0;
+    nx_n += st_n + cy;
     const float* dyb = p.dy + n * p.dy_bs + (int64_t)co0 * HW + (uint32_t)(tdconst + y0 * W + x0);
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) prd[i] = *reinterpret_cast<const float4*>(dyb + i * dstride);
@@ -1036,13 +1057,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
   __syncthreads();   // BN table visible
   if constexpr (C::NBUF == 1 && (ABL & 32) != 0) {
     // (experiment: the next tile's global loads are in flight during the matrix phase, committed after it)
-    if (it0 < it1) {
+    if (it_count > 0) {
       issue();
       commit(tiles, tiles + C::DY_FLOATS);
     }
     __syncthreads();
-    for (int item = it0; item < it1; ++item) {
-      const bool more = item + 1 < it1;
+    for (int item = 0; item < it_count; ++item) {
+      const bool more = item + 1 < it_count;
       if (more) issue();
       compute(tiles, tiles + C::DY_FLOATS);
       __syncthreads();
@@ -1051,10 +1072,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
     }
   } else if constexpr (C::NBUF == 1) {
     // a step is ~5000 cycles of matrix work per wave; the co-resident workgroup covers this one's load latency
-    for (int item = it0; item < it1; ++item) {
+    for (int item = 0; item < it_count; ++item) {
       // (ABL: compile-time phase ablations of the experiments build, env WSL_WGWINO_ABLATE -- 1 no matrix phase, 2 global loads +
       //  staging only for the first tile, 4 / 8 inside the matrix phase; wrong results by design)
-      if ((ABL & 2) == 0 || item == it0) {
+      if ((ABL & 2) == 0 || item == 0) {
         issue();
         commit(tiles, tiles + C::DY_FLOATS);
       }
@@ -1063,14 +1084,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(
       __syncthreads();
     }
   } else {
-    if (it0 < it1) {
+    if (it_count > 0) {
       issue();
       commit(tiles, tiles + C::DY_FLOATS);
     }
     __syncthreads();
     int cur = 0;
-    for (int item = it0; item < it1; ++item, cur ^= 1) {
-      const bool more = item + 1 < it1;
+    for (int item = 0; item < it_count; ++item, cur ^= 1) {
+      const bool more = item + 1 < it_count;
       if (more) issue();                                         // in flight during the compute phase
       compute(tiles + cur * C::BUF_FLOATS, tiles + cur * C::BUF_FLOATS + C::DY_FLOATS);
       if (more) commit(tiles + (cur ^ 1) * C::BUF_FLOATS, tiles + (cur ^ 1) * C::BUF_FLOATS + C::DY_FLOATS);
@@ -1203,6 +1224,8 @@ int wgrad_wino_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t
   p.dy = dy, p.dy_bs = dy_bs, p.part_dw = part_dw, p.part_db = part_db;
   p.N = N, p.H = H, p.W = W, p.Ci = a.C + p.b.C, p.Co = Co;
   p.tiles_x = tiles_x, p.tiles_y = tiles_y, p.items = items, p.nsplit = nsplit, p.co_blocks = co_blocks;
+  static const int il = WSL_TUNE("WSL_WGWINO_INTERLEAVE", 1);
+  p.interleave = il;
   if (cb == 32) {
     return th == 4 ? launch_wgrad_wino<4, 32, 2, 2, 4>(p, ci_blocks, stream) : launch_wgrad_wino<8, 16, 2, 2, 4>(p, ci_blocks, stream);
   }
