@@ -206,7 +206,9 @@ def test_conv_fwd_dgrad_wgrad_stats(be, variant, case):
 # interleaved XCD-grouped order (splits % 8 == 0) and in contiguous runs (otherwise); tiles 4 x 64, 4 x 32, 8 x 16; one and two sources
 WALKS = [(3, 24, 64, 16, 0, 16, 8), (5, 16, 32, 16, 0, 16, 8), (2, 16, 128, 16, 0, 16, 8), (6, 16, 16, 16, 0, 16, 8),
          (3, 16, 64, 32, 32, 32, 16), (3, 32, 16, 32, 0, 32, 8), (2, 8, 128, 16, 16, 16, 16), (3, 24, 64, 16, 0, 16, 5),
-         (2, 16, 64, 64, 0, 64, 32)]
+         (2, 16, 64, 64, 0, 64, 32),
+         # the narrow-operand kernel (first convolution 1 -> 16, classifier 16 -> 4; 8 x 64 tiles)
+         (3, 24, 128, 1, 0, 16, 8), (5, 16, 64, 16, 0, 4, 8), (3, 24, 128, 16, 0, 4, 5)]
 
 
 @pytest.mark.parametrize("case", WALKS)
@@ -217,14 +219,14 @@ def test_wgrad_tile_walk_orders(be, variant, case):
     xa = rng.standard_normal((N, Ca, H, W)).astype(np.float32)
     xb = rng.standard_normal((N, Cb, H, W)).astype(np.float32) if Cb else None
     scale, shift = (rng.standard_normal(Ca) * 0.5 + 1).astype(np.float32), (rng.standard_normal(Ca) * 0.3).astype(np.float32)
-    va = virt_input(xa, scale, shift, None, 1.0, None)
+    va = virt_input(xa, scale, shift, None, 1.0, None) if Ca > 1 else torch.from_numpy(xa)
     vin = torch.cat([va, torch.from_numpy(xb)], 1) if Cb else va
     wt = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
     bt = torch.zeros(Co, requires_grad=True)
     r = rng.standard_normal((N, Co, H, W)).astype(np.float32)
     (F.conv2d(vin, wt, bt, padding=1) * torch.from_numpy(r)).sum().backward()
     d = {k: (be.arr(v) if v is not None else None) for k, v in dict(xa=xa, xb=xb, scale=scale, shift=shift, r=r).items()}
-    sa = be.src(d["xa"], Ca, scale=d["scale"], shift=d["shift"])
+    sa = be.src(d["xa"], Ca, scale=d["scale"], shift=d["shift"]) if Ca > 1 else be.src(d["xa"], Ca)
     sb = be.src(d["xb"], Cb) if Cb else be.src()
     be.call("wsl_debug_wgrad_workgroups", wgs)
     try:

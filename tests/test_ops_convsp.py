@@ -147,6 +147,45 @@ def test_sp_conv_fwd_dgrad_wgrad(be, case):
     assert close(be.np(db), bt.grad.numpy(), TOL)
 
 
+# (N, H, W, Ca, Cb, Co, persistent workgroups forced): workgroups that walk several tiles each in the interleaved, XCD-grouped order
+# (splits % 8 == 0) and in contiguous runs (otherwise); 32 x 32 and 16 x 16 channel blocks, tiles 4 x 32 and 8 x 16
+SP_WALKS = [(3, 16, 64, 32, 0, 32, 8), (5, 8, 32, 16, 0, 16, 8), (3, 16, 16, 32, 32, 32, 16), (3, 16, 64, 32, 0, 32, 5),
+            (2, 16, 64, 64, 0, 64, 32)]
+
+
+@pytest.mark.parametrize("case", SP_WALKS)
+def test_sp_wgrad_tile_walk_orders(be, case):
+    import ctypes as C
+    from wsl4mis_amd import _lib
+    N, H, W, Ca, Cb, Co, wgs = case
+    Ci = Ca + Cb
+    rng = np.random.default_rng(sum(case))
+    xa = rng.standard_normal((N, Ca, H, W)).astype(np.float32)
+    xb = rng.standard_normal((N, Cb, H, W)).astype(np.float32) if Cb else None
+    scale, shift = (rng.standard_normal(Ca) * 0.5 + 1).astype(np.float32), (rng.standard_normal(Ca) * 0.3).astype(np.float32)
+    va = virt_input(xa, scale, shift, None, 1.0, None)
+    vin = torch.cat([va, torch.from_numpy(xb)], 1) if Cb else va
+    wt, bt = torch.zeros(Co, Ci, 3, 3, requires_grad=True), torch.zeros(Co, requires_grad=True)
+    r = (rng.standard_normal((N, Co, H, W)) * 3e-5).astype(np.float32)
+    (F.conv2d(vin, wt, bt, padding=1) * torch.from_numpy(r)).sum().backward()
+    d = {k: (be.arr(v) if v is not None else None) for k, v in dict(xa=xa, xb=xb, scale=scale, shift=shift, r=r).items()}
+    sa = be.src(d["xa"], Ca, scale=d["scale"], shift=d["shift"])
+    sb = be.src(d["xb"], Cb) if Cb else be.src()
+    rmax = _set_amax(be, None, np.abs(r).max())
+    be.call("wsl_debug_wgrad_workgroups", wgs)
+    try:
+        nws = be.lib.wsl_sp_conv2d_wgrad_ws_bytes(N, H, W, Ci, Co)
+        ws, dw, db = be.ws(nws), be.zeros((Co, Ci, 3, 3)), be.zeros((Co,))
+        pend = _lib.WslWgradPending()
+        be.call("wsl_sp_conv2d_wgrad_partial", sa, sb, be.ptr(d["r"]), Co * H * W, be.ptr(rmax), be.ptr(dw), be.ptr(db), N, H, W, Co,
+                be.ptr(ws), nws, C.byref(pend), be.stream)
+        be.call("wsl_wgrad_reduce_batch", C.byref(pend), 1, be.stream)
+        assert close(be.np(dw), wt.grad.numpy(), TOL)
+        assert close(be.np(db), bt.grad.numpy(), TOL)
+    finally:
+        be.call("wsl_debug_wgrad_workgroups", 0)
+
+
 def test_sp_raw_source_beyond_the_static_range(be):
     """the second source of a decoder block's first convolution is the RAW upsampled tensor (networks/unet.py:63-68) -- not
     BatchNorm-normalised, so nothing bounds it by the static activation scale 2^4 (|v| < 4094).  Its maximum is tracked by the

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_dw,
   }
 }
 
-static int g_forced_wgrad_wgs = 0;   // wsl_debug_wgrad_workgroups(): small launches walk several tiles per workgroup in the tests
+int g_forced_wgrad_wgs = 0;   // wsl_debug_wgrad_workgroups(): small launches walk several tiles per workgroup in the tests (also wsl_convsp.hip)
 struct WgPlan {
   int th, tw, cb, ib, wk, nsplit, items, tiles_x, tiles_y, co_blocks, ci_blocks;
 };

@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(WgSmallP p) {
   float* b_t = a_t + C::A_FLOATS;
   float2* tab = reinterpret_cast<float2*>(a_t + C::MAIN_FLOATS);   // [16] {scale, shift}
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int split = blockIdx.x;
+  // (nsplit % 8 == 0: the workgroups of one XCD take consecutive splits, split s walks the tiles s, s + nsplit, ... -- the narrow
+  //  operand's halo lines come out of the XCD's L2: wgrad_wino_kernel's order, profiles/r5_wgrad_item_order.md)
+  const bool interleaved = (p.nsplit & 7) == 0;
+  const int split = interleaved ? ((int)blockIdx.x & 7) * (p.nsplit >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   const int H = p.H, W = p.W, HW = H * W;
   const bool has_scale = p.a_scale != nullptr;
   if (tid < 16) tab[tid] = has_scale ? make_float2(p.a_scale[tid], p.a_shift[tid]) : make_float2(1.f, 0.f);
@@ -71,7 +74,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(WgSmallP p) {
     bl[i] = bch[i] * C::PLB + brow[i] * C::ROWP + bcol[i];
   }
 
-  const int it0 = (int)((int64_t)split * p.items / p.nsplit), it1 = (int)((int64_t)(split + 1) * p.items / p.nsplit);
+  const int it0 = interleaved ? split : (int)((int64_t)split * p.items / p.nsplit);
+  const int it_count = interleaved ? (p.items - split + p.nsplit - 1) / p.nsplit : (int)((int64_t)(split + 1) * p.items / p.nsplit) - it0;
+  const int step = interleaved ? p.nsplit : 1;
   int nx_tx, nx_ty, nx_n;
   {
     int q = it0;
@@ -80,14 +85,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(WgSmallP p) {
     nx_ty = q % p.tiles_y;
     nx_n = q / p.tiles_y;
   }
+  const int st_tx = step % p.tiles_x, st_ty = (step / p.tiles_x) % p.tiles_y, st_n = step / (p.tiles_x * p.tiles_y);
   float4 pra[C::ND], prb[C::NB];
   bool prok[C::NB];
   auto issue = [&]() __attribute__((always_inline)) {
     const int n = nx_n, y0 = nx_ty * C::TH, x0 = nx_tx * C::TW;
-    if (++nx_tx == p.tiles_x) {
-      nx_tx = 0;
-      if (++nx_ty == p.tiles_y) nx_ty = 0, ++nx_n;
-    }
+    nx_tx += st_tx;
+    const int cx = nx_tx >= p.tiles_x ? 1 : 0;
+    nx_tx -= cx ? p.tiles_x : 0;
+    nx_ty += st_ty + cx;
+    const int cy = nx_ty >= p.tiles_y ? 1 : 0;
+    nx_ty -= cy ? p.tiles_y : 0;
+    nx_n += st_n + cy;
     const float* ab = p.a + n * p.a_bs + y0 * W + x0;
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) pra[i] = *reinterpret_cast<const float4*>(ab + (int64_t)i * C::GD * HW + taoff);
@@ -133,12 +142,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(WgSmallP p) {
 #pragma unroll
   for (int t = 0; t < C::NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
 
-  if (it0 < it1) issue();
+  if (it_count > 0) issue();
   __syncthreads();   // table visible
-  for (int item = it0; item < it1; ++item) {
+  for (int item = 0; item < it_count; ++item) {
     commit();
     __syncthreads();
-    if (item + 1 < it1) issue();   // next tile in flight during the MFMA loop
+    if (item + 1 < it_count) issue();   // next tile in flight during the MFMA loop
     constexpr int RW = C::TH / 4, NX = C::TW / 4;
 #pragma unroll 4
     for (int st = 0; st < RW * NX; ++st) {

@@ -915,8 +915,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
   unsigned char* in_img = smem;
   unsigned char* dy_img = smem + II::BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = WSL_WAVE_UNIFORM(tid >> 6);
-  const int cob = blockIdx.x / p.ci_blocks, cib = blockIdx.x - cob * p.ci_blocks;
-  const int split = blockIdx.y;
+  // (nsplit % 8 == 0: the workgroups of one XCD -- dealt round-robin in launch order -- take all channel blocks of nsplit / 8 consecutive
+  //  splits and split s walks the tiles s, s + nsplit, ...: wgrad_wino_kernel's order, profiles/r5_wgrad_item_order.md)
+  int blk = blockIdx.x, split = blockIdx.y;
+  const bool interleaved = (p.nsplit & 7) == 0;
+  if (interleaved) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, j = lin >> 3;
+    blk = j % (int)gridDim.x;
+    split = (lin & 7) * (p.nsplit >> 3) + j / (int)gridDim.x;
+  }
+  const int cob = blk / p.ci_blocks, cib = blk - cob * p.ci_blocks;
   const int H = p.H, W = p.W, Ci = p.Ci, Co = p.Co, HW = H * W;
   const int ci0 = cib * CB, co0 = cob * CB;
   const bool ina = ci0 < p.a.C;                           // the block's input channels live in one source
@@ -964,11 +972,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
     sp_issue<II>(tki, pri, src.x + n * src.bs, src.emask ? src.emask + (int64_t)n * src.C * HW : nullptr, chb, HW);
     sp_issue<ID>(tkd, prd, p.dy + n * p.dy_bs, nullptr, co0, HW);
   };
-  // every split owns one contiguous run of tiles: neighbouring tiles share their halo lines, and walked back to back by one
-  // workgroup those lines are still in its CU's L1 / its XCD's L2 (dealt round-robin, three XCDs fetch them over the fabric)
+  // neighbouring tiles share their halo lines: the workgroups of an XCD stage neighbouring tiles in the same round, so those lines come
+  // out of its L2 (rounds 3-4: one contiguous run of tiles per split -- by the time a workgroup came back to a line, the XCD's other
+  // workgroups had pushed it out); launches whose split count does not divide by eight keep the contiguous runs
   const int run = (p.items + p.nsplit - 1) / p.nsplit;
-  int t = split * run;
-  const int t_end = (t + run < p.items) ? t + run : p.items;
+  const int step = interleaved ? p.nsplit : 1;
+  int t = interleaved ? split : split * run;
+  const int t_end = interleaved ? p.items : ((t + run < p.items) ? t + run : p.items);
   if (t < t_end) issue(t);
   // a thread stages the same octet of every tile: its eight BatchNorm coefficient pairs stay in registers for the whole kernel
   SpCoef<II::NR> cfr;
@@ -978,7 +988,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sp_kernel(WgradSpP p) {
                   src.emask != nullptr, src.cmask != nullptr, src.es, src.scale == nullptr, act_mul, true);
     sp_commit<ID>(tkd, prd, dy_img, SpCoef<ID::NR>{}, 1.f, nullptr, 0, false, false, false, 1.f, true, dy_mul, true);
     __syncthreads();
-    const int tn = t + 1;
+    const int tn = t + step;
     if (tn < t_end) issue(tn);   // in flight during the MFMA phase
     auto read_a = [&](int ks, wsl_u4& ah, wsl_u4& al) __attribute__((always_inline)) {
       const int dk = ks * C::KROWS * ID::ROWB;
@@ -1065,6 +1075,7 @@ struct WgSpPlan {
   int th, tw, cb, nsplit, splits, items, tiles_x, tiles_y, co_blocks, ci_blocks;
   bool ok;
 };
+extern int g_forced_wgrad_wgs;   // wsl_conv.hip: wsl_debug_wgrad_workgroups()
 static WgSpPlan wgrad_sp_plan(int N, int H, int W, int Ca, int Cb, int Co) {
   WgSpPlan g{};
   const int Ci = Ca + Cb;
@@ -1075,7 +1086,7 @@ static WgSpPlan wgrad_sp_plan(int N, int H, int W, int Ca, int Cb, int Co) {
   g.cb = (Co % 32 == 0 && Ci % 32 == 0 && (Cb == 0 || Ca % 32 == 0)) ? 32 : 16;
   g.tiles_x = W / g.tw, g.tiles_y = H / g.th, g.items = N * g.tiles_x * g.tiles_y;
   g.co_blocks = Co / g.cb, g.ci_blocks = Ci / g.cb;
-  int want = 2 * device_cu_count() / (g.co_blocks * g.ci_blocks);     // two persistent workgroups per CU
+  int want = (g_forced_wgrad_wgs > 0 ? g_forced_wgrad_wgs : 2 * device_cu_count()) / (g.co_blocks * g.ci_blocks);   // two persistent workgroups per CU
   if (want < 1) want = 1;
   g.nsplit = g.items < want ? g.items : want;
   g.splits = g.cb == 32 ? g.nsplit : 4 * g.nsplit;
@@ -1191,7 +1202,7 @@ extern "C" size_t wsl_sp_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int 
   if (!g.ok) return 0;
   // upper bound over both channel blockings (how Ci splits over two sources may lower the block to 16): 4 partials per
   // persistent workgroup, at most two workgroups per CU
-  const int want = 2 * device_cu_count();
+  const int want = g_forced_wgrad_wgs > 0 ? g_forced_wgrad_wgs : 2 * device_cu_count();
   const size_t splits = (size_t)4 * (g.items < want ? g.items : want);
   return sizeof(float) * splits * ((size_t)9 * Co * Ci + Co);
 }
