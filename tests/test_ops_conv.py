@@ -236,6 +236,14 @@ def test_wgrad_tile_walk_orders(be, variant, case):
                 be.stream)
         assert close(be.np(dw), wt.grad.numpy(), TOL)
         assert close(be.np(db), bt.grad.numpy(), TOL)
+        if Co == 4 and Ca == 16 and Cb == 0:   # the classifier's forward kernel is persistent too (conv_cls_kernel): same walk orders
+            w = (rng.standard_normal((Co, Ci, 3, 3)) * 0.2).astype(np.float32)
+            bias = rng.standard_normal(Co).astype(np.float32)
+            y_ref = F.conv2d(vin, torch.from_numpy(w), torch.from_numpy(bias), padding=1).numpy()
+            dwt, dbias, wp, y = be.arr(w), be.arr(bias), be.zeros((9, Ci, Co)), be.zeros((N, Co, H, W))
+            be.call("wsl_conv2d_pack_weights", be.ptr(dwt), be.ptr(wp), Co, Ci, 3, 0, be.stream)
+            be.call("wsl_conv2d_fwd", sa, sb, be.ptr(wp), be.ptr(dbias), be.ptr(y), Co * H * W, N, H, W, Co, 3, 2, None, None, be.stream)
+            assert close(be.np(y), y_ref, TOL)
     finally:
         be.call("wsl_debug_wgrad_workgroups", 0)
 

@@ -1386,7 +1386,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma2s_kernel(Wgrad2P p) {
   float* a_t = dy_t + C::DY_FLOATS;
   float2* tab = reinterpret_cast<float2*>(dy_t + C::MAIN_FLOATS);   // [IB] {scale, shift} of this block's channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cb = blockIdx.x % p.co_blocks, ib = blockIdx.x / p.co_blocks, split = blockIdx.y;
+  // (nsplit % 8 == 0: all channel blocks of a split on ONE XCD -- dealt round-robin in launch order -- so the dy / input tiles they share
+  //  come out of its L2: the 1x1 layers fetched 1.33 x their bytes with the blocks of a split spread over the XCDs)
+  int blk = blockIdx.x, split = blockIdx.y;
+  if ((p.nsplit & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, j = lin >> 3;
+    blk = j % (int)gridDim.x;
+    split = (lin & 7) * (p.nsplit >> 3) + j / (int)gridDim.x;
+  }
+  const int cb = blk % p.co_blocks, ib = blk / p.co_blocks;
   const int co0 = cb * CB, ci0 = ib * IB;
   const int wp_ = wave % C::WP, wk = wave / C::WP;
   const int H = p.H, W = p.W, Ci = p.Ci;

@@ -258,6 +258,7 @@ int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs
 // products per instruction = 64 consecutive pixels of a row (4 per block) x the 4 classes, K = 1 (one (ci, tap) pair).
 // Lane l supplies the input of pixel l (A) and the weight of class l & 3 (B) and receives pixels 4*(l>>2)..+3 of class
 // l & 3 -- a float4 store.  The 144 weights of a lane's class live in registers for the whole (persistent) workgroup.
+extern int g_forced_wgrad_wgs;   // wsl_conv.hip
 struct ClsP {
   const float* x;        // [N,16,H,W] raw conv output of the last decoder block
   int64_t x_bs;
@@ -297,7 +298,14 @@ __global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
   const int pty = tid / C::ROWP4, ptx4 = tid - pty * C::ROWP4;
   const bool owner = tid < C::POS;
   const int loff = pty * C::ROWP + ptx4 * 4;
-  const int it0 = (int)((int64_t)blockIdx.x * p.items / gridDim.x), it1 = (int)((int64_t)(blockIdx.x + 1) * p.items / gridDim.x);
+  // tiles of this (persistent) workgroup: it0, it0 + step, ... < it1.  gridDim.x % 8 == 0: the workgroups of one XCD take neighbouring
+  // tiles in every round, so the halo lines two tiles share come out of that XCD's L2 (one contiguous run per workgroup read the input
+  // twice: 535 MB fetched for a 268 MB tensor, L2 hit share 0.19; profiles/r5_wgrad_item_order.md)
+  const int nwg = (int)gridDim.x, bx = (int)blockIdx.x;
+  const bool interleaved = (nwg & 7) == 0;
+  const int it0 = interleaved ? (bx & 7) * (nwg >> 3) + (bx >> 3) : (int)((int64_t)bx * p.items / nwg);
+  const int it1 = interleaved ? p.items : (int)((int64_t)(bx + 1) * p.items / nwg);
+  const int step = interleaved ? nwg : 1;
 
   float4 pre[C::KC];
   bool pok = false;
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
 
   if (it0 < it1) issue(it0, 0);
   __syncthreads();   // table visible
-  for (int item = it0; item < it1; ++item) {
+  for (int item = it0; item < it1; item += step) {
     acc[0] = v4f{bias, bias, bias, bias}, acc[1] = acc[0];
     commit(0);
     __syncthreads();
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
     __syncthreads();
     commit(1);
     __syncthreads();
-    if (item + 1 < it1) issue(item + 1, 0);
+    if (item + step < it1) issue(item + step, 0);
     mfma_half(std::integral_constant<int, 1>{});
     __syncthreads();
     int n, y0, x0;
@@ -394,7 +402,7 @@ int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* 
     (void)WSL_SET_MAX_DYN_SMEM(conv_cls_kernel, ClsCfg::SMEM);
     attr_done = true;
   }
-  int wgs = 2 * device_cu_count();
+  int wgs = g_forced_wgrad_wgs > 0 ? g_forced_wgrad_wgs : 2 * device_cu_count();   // (wsl_debug_wgrad_workgroups(): tests force a few)
   if (wgs > p.items) wgs = p.items;
   const double px = (double)N * H * W;
   void* tok = prof_begin(0, 2.0 * px * 4 * 16 * 9, 4.0 * px * (16 + 4), stream);
