@@ -96,15 +96,20 @@ struct Wino2Cfg {
 
 // epilogue of both conv_wino2 kernels: output transform (register-only), bias, float4 stores, BatchNorm partials
 // positions of the lane's output float4s (and of the BatchNorm-backward epilogue's y / keep-mask reads): q = (m * NT + j) * 4
-// + {0: row 0, 1: row 0 + 4 px, 2: row 1, 3: row 1 + 4 px}
+// + {0: row 0, 1: row 0 + 4 px, 2: row 1, 3: row 1 + 4 px}, as a 32-bit ELEMENT offset from the workgroup's corner (n, co0, y0, x0):
+// the corner is wave-uniform (a scalar base register), so every access is base + 32-bit lane offset -- no 64-bit multiplies per
+// lane (the 64-bit form cost ~8 vector instructions per float4 pair, two of them quarter-rate v_mul_lo_u32).  wino_fwd() admits only
+// shapes with CO_T * H * W < 2^30.
 template <typename C, int NT>
-__device__ __forceinline__ int64_t wino2_out_index(const WinoP& p, int n, int co0, int y0, int x0, int q) {
+__device__ __forceinline__ uint32_t wino2_out_lane_off(int HW, int W, int q) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int a = q >> 2, m = a / NT, j = a - m * NT, r = q & 3;
   const int tb = (wave * C::MTW + m) * 16 + 4 * (lane >> 4);
   const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
-  return ((int64_t)n * p.Co + co0 + j * 16 + (lane & 15)) * ((int64_t)p.H * p.W) + (int64_t)(y0 + 2 * tyy + (r >> 1)) * p.W + x0 +
-         2 * txb + 4 * (r & 1);
+  return (uint32_t)((j * 16 + (lane & 15)) * HW + (2 * tyy + (r >> 1)) * W + 2 * txb + 4 * (r & 1));
+}
+__device__ __forceinline__ int64_t wino2_corner(int n, int64_t bs_or_chw, int co0, int HW, int y0, int W, int x0) {
+  return (int64_t)n * bs_or_chw + (int64_t)co0 * HW + (int64_t)y0 * W + x0;
 }
 
 // PRE: the caller has the BatchNorm-backward epilogue's y / keep-mask values in registers (loaded before its channel loop)
@@ -120,11 +125,9 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C:
   float bsum[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
+  char* const ycorner = reinterpret_cast<char*>(p.y + wino2_corner(n, p.y_bs, co0, HW, y0, W, x0));   // wave-uniform
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
-    const int tb = (wave * MTW + m) * 16 + 4 * (lane >> 4);          // first of this lane's 4 consecutive tiles
-    const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
-    float* yb = p.y + n * p.y_bs + (int64_t)(co0 + (lane & 15)) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int a = m * NT + j;
@@ -151,11 +154,11 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C:
         o[a][2 * r] = y00, o[a][2 * r + 1] = y01, o[a][8 + 2 * r] = y10, o[a][8 + 2 * r + 1] = y11;
         bs += (y00 + y01) + (y10 + y11);
       }
-      float* yj = yb + (int64_t)j * 16 * HW;
-      *reinterpret_cast<float4*>(yj) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
-      *reinterpret_cast<float4*>(yj + 4) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
-      *reinterpret_cast<float4*>(yj + W) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
-      *reinterpret_cast<float4*>(yj + W + 4) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
+      const uint32_t yo = 4u * wino2_out_lane_off<C, NT>(HW, W, a * 4), wb = 4u * (uint32_t)W;   // byte offsets
+      *reinterpret_cast<float4*>(ycorner + yo) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
+      *reinterpret_cast<float4*>(ycorner + (yo + 16u)) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
+      *reinterpret_cast<float4*>(ycorner + (yo + wb)) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
+      *reinterpret_cast<float4*>(ycorner + (yo + wb + 16u)) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
       bsum[j] += bs;
     }
   }
@@ -506,11 +509,14 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   uint32_t mpre[4 * C::NA];
   const bool bn_epi = p.bn.part != nullptr;
   if (bn_epi) {
+    const int64_t corner = wino2_corner(n, (int64_t)Co * HW, co0, HW, y0, W, x0);                      // wave-uniform
+    const char* const yc = reinterpret_cast<const char*>(p.bn.y + corner);
+    const uint8_t* const mc = p.bn.emask ? p.bn.emask + corner : nullptr;
 #pragma unroll
     for (int q = 0; q < 4 * C::NA; ++q) {
-      const int64_t idx = wino2_out_index<C, NT>(p, n, co0, y0, x0, q);
-      ypre[q] = *reinterpret_cast<const float4*>(p.bn.y + idx);
-      mpre[q] = p.bn.emask ? *reinterpret_cast<const uint32_t*>(p.bn.emask + idx) : 0u;
+      const uint32_t off = wino2_out_lane_off<C, NT>(HW, W, q);
+      ypre[q] = *reinterpret_cast<const float4*>(yc + 4u * off);
+      mpre[q] = mc ? *reinterpret_cast<const uint32_t*>(mc + off) : 0u;
     }
   }
   v4f acc[16][C::NA];   // [xi][m * NT + j]; first written by the first chunk's MFMAs
@@ -732,6 +738,7 @@ bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, 
   else if (W % 16 == 0 && H % 16 == 0) h = 16, w = 16;
   else return false;
   if ((int64_t)Ci * H * W >= (int64_t(1) << 31) || (int64_t)16 * Ci * Co >= (int64_t(1) << 31)) return false;
+  if ((int64_t)32 * H * W >= (int64_t(1) << 30)) return false;   // the epilogue's 32-bit byte offsets inside a channel block (wino2_out_lane_off)
   if (Co % 32 && !(h == 8 && (w == 64 || w == 32))) return false;   // 16-channel blocks: 8 x 64 / 8 x 32 tiles only (else direct kernels)
   if (th) *th = h;
   if (tw) *tw = w;
