@@ -12,9 +12,10 @@ int wsl_debug_conv_plan(int th, int tw, int co_t);
 /* Winograd F(2x2,3x3) path: 0 off (wsl_conv2d_wino_ok() returns 0), 1 only layers with Co % 32 == 0, 2 (default) also
  * layers with Co % 16 == 0; -1 restores the default. */
 int wsl_debug_conv_wino(int on);
-/* Number of persistent workgroups a weight-gradient launch aims at (default 768 = 3 per CU); n <= 0 restores it.  Tests force a few so
- * that a small layer's workgroups walk several tiles each (the interleaved, XCD-grouped tile order of wgrad_wino_kernel).  Set it before
- * wsl_conv2d_wgrad_ws_bytes(): the workspace is sized for the plan. */
+/* Number of persistent workgroups a weight-gradient launch (f32 and split-precision plans) and the classifier's forward kernel aim at
+ * (defaults: 768 = 3 per CU, 2 per CU); n <= 0 restores them.  Tests force a few so that a small layer's workgroups walk several tiles
+ * each (the interleaved, XCD-grouped tile order of wgrad_wino_kernel and its siblings).  Set it before wsl_conv2d_wgrad_ws_bytes() /
+ * wsl_sp_conv2d_wgrad_ws_bytes(): the workspaces are sized for the plan. */
 int wsl_debug_wgrad_workgroups(int n);
 
 /* The discrete decisions of the training forward held in a network workspace (wsl_net_forward(training = 1) ran on `ws`), as the
