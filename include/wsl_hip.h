@@ -32,7 +32,9 @@ extern "C" {
 
 int wsl_version(void);              /* 100*major + minor */
 const char* wsl_last_error(void);   /* thread-local, valid until the next failing call on this thread */
-const char* wsl_build_info(void);   /* "gfx950 hipcc ..." or "HOST-EMULATION (tests only)" */
+const char* wsl_build_info(void);   /* "gfx950 hipcc sha256:<hex>" (product), "gfx950 hipcc EXPERIMENTS ... sha256:<hex>" (tuning build) or
+                                     * "HOST-EMULATION (tests only ...) sha256:<hex>"; <hex> = SHA-256 over the library's sources
+                                     * (every .hip and .h file of csrc/ sorted by name, then this header) as build.sh saw them */
 
 /* Opt-in measurement: HIP events bracket every launch of the heavy kernel families on the launch stream while
  * enabled; wsl_prof_report() waits for those events (the library's only synchronising call) and fills one row per
@@ -374,7 +376,9 @@ int wsl_noisy_copy(const float* x, const float* noise, float* out, int64_t n, in
 
 /* Bernoulli masks for nn.Dropout / F.dropout2d in ONE launch (Philox4x32-10, counter-based: reproducible per seed).
  * Mask i: is_f32[i] == 0 -> uint8 keep mask (1 with probability keep_probs[i]); == 1 -> float multiplier
- * (scales[i] with probability keep_probs[i], else 0).  uint8 outputs must be 4-byte aligned.  n_masks <= 12. */
+ * (scales[i] with probability keep_probs[i], else 0).  uint8 outputs must be 4-byte aligned.  n_masks <= 12.
+ * uint8 masks draw sixteen random bits per element: their keep probability is keep_probs[i] ROUNDED to the nearest 1 / 65536
+ * (1.0 keeps every element, 0.0 none); float multipliers use 32 bits (keep_probs[i] to 2^-32; 1.0 drops one draw in 2^32). */
 int wsl_draw_masks(int n_masks, void* const* outs, const int64_t* numels, const float* keep_probs, const float* scales,
                    const int* is_f32, uint64_t seed, void* stream);
 

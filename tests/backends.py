@@ -1,7 +1,11 @@
 """Two ways to run the same C-ABI calls in the tests:
   EmulBackend -- tests/emul/libwslhip_emul.so, the kernel sources compiled for the lock-step host emulator
                  (logic check, CPU, tiny shapes).  Test infrastructure only.
-  HipBackend  -- the product library on cuda:0 (tests marked gpu)."""
+  HipBackend  -- the product library on cuda:0 (tests marked gpu).
+  HipExpBackend -- tools/exp/libwslhip_exp.so on cuda:0: the same sources built with -DWSL_EXPERIMENTS, the only hipcc build that has
+                 routing overrides (wsl_debug_conv_plan / _conv_wino / _wgrad_workgroups).  Only the tests that FORCE a route use it
+                 (kernel instantiations / tile walks at sizes the product's plan would not pick); every default-route test runs on the
+                 product library."""
 import ctypes as C
 import os
 
@@ -11,6 +15,7 @@ from wsl4mis_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMUL_PATH = os.path.join(ROOT, "tests", "emul", "libwslhip_emul.so")
+EXP_PATH = os.path.join(ROOT, "tools", "exp", "libwslhip_exp.so")
 
 
 class _Base:
@@ -98,3 +103,20 @@ class HipBackend(_Base):
 
     def sync(self):
         self.torch.cuda.synchronize()
+
+
+class HipExpBackend(HipBackend):
+    name = "hip"          # same device, tensors and tolerances as the product backend
+
+    def __init__(self, path=EXP_PATH):
+        import torch
+        self.torch = torch
+        assert torch.cuda.is_available(), "HipExpBackend needs a GPU"
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: run wsl4mis_amd/csrc/build.sh exp (__graft_entry__.build() does)")
+        self.lib = C.CDLL(path)
+        _lib.bind(self.lib)
+        info = self.lib.wsl_build_info()
+        assert b"EXPERIMENTS" in info, info
+        assert _lib.library_sha256(self.lib) == _lib.source_sha256(), "tools/exp/libwslhip_exp.so was not built from this tree"
+        self.dev = torch.device("cuda:0")

@@ -128,6 +128,8 @@ def get_backend(name):
                 subprocess.run([os.path.join(ROOT, "wsl4mis_amd", "csrc", "build.sh"), "emul"], check=True,
                                stdout=subprocess.DEVNULL)
             _BACKENDS[name] = backends.EmulBackend()
+        elif name == "hip_exp":
+            _BACKENDS[name] = backends.HipExpBackend()
         else:
             _BACKENDS[name] = backends.HipBackend()
     return _BACKENDS[name]
@@ -136,4 +138,12 @@ def get_backend(name):
 @pytest.fixture(params=[pytest.param("emul"), pytest.param("hip", marks=pytest.mark.gpu)])
 def be(request):
     """The C ABI behind either the host emulator (kernel-logic check, CPU) or the real library on cuda:0."""
+    return get_backend(request.param)
+
+
+@pytest.fixture(params=[pytest.param("emul"), pytest.param("hip_exp", marks=pytest.mark.gpu)])
+def be_route(request):
+    """For the tests that FORCE a route (tile plan, Winograd off, few persistent workgroups): the routing overrides exist only in builds with
+    -DWSL_EXPERIMENTS -- the host emulator and tools/exp/libwslhip_exp.so (same kernel sources, hipcc, gfx950).  The product library has
+    no such state."""
     return get_backend(request.param)

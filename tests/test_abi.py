@@ -26,9 +26,38 @@ def test_product_library_exports_every_declared_symbol():
     missing = [n for n in declared() if not hasattr(lib, n)]
     assert not missing, missing
     lib.wsl_build_info.restype = ctypes.c_char_p
-    assert lib.wsl_build_info() == b"gfx950 hipcc"              # host-only calls: no kernel is launched here
+    info = lib.wsl_build_info()                                    # host-only calls: no kernel is launched here
+    assert info.startswith(b"gfx950 hipcc sha256:") and b"EXPERIMENTS" not in info and b"EMULATION" not in info, info
     lib.wsl_version.restype = ctypes.c_int
     assert lib.wsl_version() >= 100
+
+
+def test_product_library_is_built_from_this_tree():
+    """libwslhip.so is git-ignored and travels prebuilt -- wsl_build_info() carries the SHA-256 of the sources it was
+    compiled from (csrc/build.sh puts it on wsl_api.hip's command line and rebuilds objects by content hash, not by modification time);
+    it must equal the hash of the tree the tests run in.  bench.py checks the same and prints it as config.library_sha."""
+    from wsl4mis_amd import _lib
+    lib = ctypes.CDLL(LIB)
+    lib.wsl_build_info.restype = ctypes.c_char_p
+    assert _lib.library_sha256(lib) == _lib.source_sha256(), "libwslhip.so is stale: run wsl4mis_amd/csrc/build.sh"
+
+
+def test_product_library_has_no_routing_hooks():
+    """no process-global switch that changes which kernel a launch takes -- the routing overrides and the
+    ablation template arms exist only with -DWSL_EXPERIMENTS (tools/exp/libwslhip_exp.so, the host emulator)."""
+    lib = ctypes.CDLL(LIB)
+    for hook in ("wsl_debug_conv_plan", "wsl_debug_conv_wino", "wsl_debug_wgrad_workgroups", "wsl_debug_mfma_stream", "wsl_debug_pk_probe"):
+        assert not hasattr(lib, hook), hook
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scan_vop3p
+    nm = os.path.join(os.path.dirname(scan_vop3p.OBJDUMP), "llvm-nm")
+    if os.path.exists(nm):
+        syms = subprocess.run([nm, "-D", "--defined-only", LIB], check=True, capture_output=True, text=True).stdout
+        assert "g_forced" not in syms and "g_wino" not in syms
+        dbg = sorted(ln.split()[-1] for ln in syms.splitlines() if "wsl_debug_" in ln)
+        assert dbg == ["wsl_debug_net_decisions", "wsl_debug_net_ws_region", "wsl_debug_sp_conv_residency"], dbg   # read-only queries
 
 
 def test_ctypes_binding_covers_the_header():

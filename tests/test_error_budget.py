@@ -187,7 +187,8 @@ def test_full_batch_forward_and_losses_match_the_oracle(full, mode):
         got, ref = full["hip"]["z"][b], full["f32"]["z"][b]
         truth = full["f64"]["z"][b] if full["with_f64"] else full["f64r"]["z"][b]     # (else: fp64 on the HIP forward's own decisions)
         e_hip, e_cpu = rel_err(got, truth), rel_err(ref, truth)
-        print(f"logits[{b}]: HIP vs fp64 truth {e_hip:.2e}, torch-CPU fp32 vs truth {e_cpu:.2e}, HIP vs fp32 {rel_err(got, ref):.2e}, "
+        what = "fp64 truth (free-running oracle)" if full["with_f64"] else "fp64 ON THE HIP FORWARD'S OWN REPLAYED DECISIONS (not an independent truth)"
+        print(f"logits[{b}]: HIP vs {what} {e_hip:.2e}, torch-CPU fp32 vs the same {e_cpu:.2e}, HIP vs fp32 {rel_err(got, ref):.2e}, "
               f"element-wise (RMS floor) {mixed_err(got, ref):.3f} of the 1e-4 budget")
         assert close(got, ref), (b, rel_err(got, ref), mixed_err(got, ref))
     # pseudo-label map of the mixed softmax, end to end (HIP logits -> HIP softmax -> mix -> argmax) vs the oracle's

@@ -62,10 +62,16 @@ CASES = [  # N, H, W, Ca, Cb, Co, ks, transforms on a
 
 @pytest.fixture
 def variant(be):
-    """the packed-path kernels with Winograd wherever it fits, including the 16-channel blocks"""
-    be.call("wsl_debug_conv_wino", 2)
-    yield 2
-    be.call("wsl_debug_conv_wino", -1)
+    """the packed-path kernels with Winograd wherever it fits, including the 16-channel blocks: the PRODUCT library's fixed routing
+    (it has no switch to set: the hook below exists in the emulator / experiments builds only, where an environment variable could
+    have moved the default)"""
+    if hasattr(be.lib, "wsl_debug_conv_wino"):
+        be.call("wsl_debug_conv_wino", 2)
+        yield 2
+        be.call("wsl_debug_conv_wino", -1)
+    else:
+        assert be.lib.wsl_conv2d_wino_ok(1, 8, 64, 16, 0, 16, 3) == 1 and be.lib.wsl_conv2d_wino_ok(1, 16, 16, 32, 32, 32, 3) == 1
+        yield 2
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -212,7 +218,8 @@ WALKS = [(3, 24, 64, 16, 0, 16, 8), (5, 16, 32, 16, 0, 16, 8), (2, 16, 128, 16, 
 
 
 @pytest.mark.parametrize("case", WALKS)
-def test_wgrad_tile_walk_orders(be, variant, case):
+def test_wgrad_tile_walk_orders(be_route, case):
+    be = be_route   # forces the number of persistent workgroups: emulator / experiments build
     N, H, W, Ca, Cb, Co, wgs = case
     Ci = Ca + Cb
     rng = np.random.default_rng(sum(case))
@@ -281,9 +288,10 @@ PLANS = [(8, 64, 16), (8, 64, 32), (8, 32, 16), (8, 32, 32), (8, 32, 64), (16, 1
 
 @pytest.mark.parametrize("plan", PLANS)
 @pytest.mark.parametrize("ks", [3, 1])
-def test_every_lean_conv_instantiation(be, plan, ks):
+def test_every_lean_conv_instantiation(be_route, plan, ks):
     """each tile shape of conv_mfma2l_kernel, forced at a small size (the built-in table only picks the wide channel
     blocks for launches that fill the chip): forward with a transformed + a raw source, data gradient, statistics"""
+    be = be_route   # forces tile plans: emulator / experiments build
     th, tw, ct = plan
     N, H, W, Ca, Cb, Co = 2, 2 * th if th == 8 else 16, tw, 16, 8, 64
     rng = np.random.default_rng(th * 1000 + tw * 10 + ct + ks)

@@ -154,7 +154,8 @@ SP_WALKS = [(3, 16, 64, 32, 0, 32, 8), (5, 8, 32, 16, 0, 16, 8), (3, 16, 16, 32,
 
 
 @pytest.mark.parametrize("case", SP_WALKS)
-def test_sp_wgrad_tile_walk_orders(be, case):
+def test_sp_wgrad_tile_walk_orders(be_route, case):
+    be = be_route   # forces the number of persistent workgroups: emulator / experiments build
     import ctypes as C
     from wsl4mis_amd import _lib
     N, H, W, Ca, Cb, Co, wgs = case

@@ -204,6 +204,14 @@ def test_draw_masks_statistics_and_determinism(be):
     assert abs(a[1].mean() - 0.5) < 4 * np.sqrt(0.25 / sizes[1])
     assert set(np.unique(a[3])) <= {0.0, 2.0} and abs((a[3] > 0).mean() - 0.5) < 4 * np.sqrt(0.25 / sizes[3])
     assert not np.array_equal(a[1][:7], a[2])             # masks of one call use distinct counter streams
+    # keep_prob 1.0 keeps EVERY element and 0.0 none, in both mask kinds' uint8 form (sixteen-bit thresholds are rounded and reach 65536:
+    # ADVICE r5 -- flooring dropped one element in 65536 at 1.0)
+    n_edge = 1 << (20 if be.name == "hip" else 18)
+    for pk, want in ((1.0, 1), (0.0, 0)):
+        o = be.zeros((n_edge,), np.uint8)
+        be.call("wsl_draw_masks", 1, (C.c_void_p * 1)(be.ptr(o)), (C.c_int64 * 1)(n_edge), (C.c_float * 1)(pk), (C.c_float * 1)(1.0),
+                (C.c_int * 1)(0), C.c_uint64(7), be.stream)
+        assert np.all(be.np(o) == want), (pk, int(np.count_nonzero(be.np(o) != want)))
 
 
 def test_noisy_copy_distribution_and_replay(be):

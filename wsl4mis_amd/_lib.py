@@ -165,8 +165,9 @@ _PROTOS = {
 
 # private hooks (wsl4mis_amd/csrc/wsl_debug.h): bound when the loaded library has them; tests and tools only
 _DEBUG_PROTOS = {
-    "wsl_debug_conv_plan": (i32, [i32, i32, i32]),
+    "wsl_debug_conv_plan": (i32, [i32, i32, i32]),        # (experiments build / emulator only)
     "wsl_debug_conv_wino": (i32, [i32]),
+    "wsl_debug_wgrad_workgroups": (i32, [i32]),
     "wsl_debug_net_decisions": (i32, [PD, c_fp, sz, i32, i32, c_fp, c_fp]),
     "wsl_debug_mfma4_probe": (i32, [c_fp, c_fp, c_fp, c_fp]),
     "wsl_debug_lds_dma_probe": (i32, [c_fp, c_fp, c_fp]),
@@ -243,6 +244,25 @@ def check(rc, cdll=None):
     if rc != 0:
         l = cdll or lib()
         raise WslError(f"wsl error {rc}: {l.wsl_last_error().decode()}")
+
+
+def source_sha256():
+    """SHA-256 over the library's sources as csrc/build.sh hashes them (csrc/*.hip and csrc/*.h sorted by name, then include/wsl_hip.h):
+    what wsl_build_info() of a library built from THIS tree must end in."""
+    import hashlib
+    cs = os.path.join(_HERE, "csrc")
+    names = sorted(f for f in os.listdir(cs) if f.endswith((".hip", ".h")))
+    h = hashlib.sha256()
+    for f in [os.path.join(cs, n) for n in names] + [os.path.join(os.path.dirname(_HERE), "include", "wsl_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def library_sha256(cdll=None):
+    """the source hash compiled into a loaded library (None when it carries none)"""
+    info = (cdll or lib()).wsl_build_info().decode()
+    return info.rsplit("sha256:", 1)[1].strip() if "sha256:" in info else None
 
 
 def declared_symbols():

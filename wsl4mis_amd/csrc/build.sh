@@ -1,55 +1,63 @@
 #!/usr/bin/env bash
 # Builds libwslhip.so (the product: hand-written HIP for gfx950) in-tree next to the sources.
-#   ./build.sh          product library only (no environment knobs, no ablation / probe / experiment code)
+#   ./build.sh          product library only (no environment knobs, no routing hooks, no ablation / probe / experiment code)
 #   ./build.sh emul     ALSO the test-only host emulation build (tests/emul/libwslhip_emul.so; -DWSL_EXPERIMENTS so the
 #                       experiment variants stay logic-checked on the CPU)
-#   ./build.sh exp      ALSO tools/exp/libwslhip_exp.so: the same sources with -DWSL_EXPERIMENTS (env tuning knobs, ablation
-#                       switches, measured-slower kernel families, machine probes) for the tuning tools -- never loaded by
-#                       wsl4mis_amd/, bench.py or the tests
+#   ./build.sh exp      ALSO tools/exp/libwslhip_exp.so: the same sources with -DWSL_EXPERIMENTS (env tuning knobs, routing overrides,
+#                       ablation switches, measured-slower kernel families, machine probes) for the tuning tools and for the GPU tests
+#                       that force a route (tests/backends.py::HipExpBackend) -- never loaded by wsl4mis_amd/ or bench.py
+#
+# What ties a binary to the tree:
+#   * SRC_SHA = SHA-256 over the bytes of csrc/*.hip, csrc/*.h (sorted by name, C locale) and include/wsl_hip.h, in that order --
+#     wsl4mis_amd/_lib.py::source_sha256() recomputes exactly this.  It is compiled into wsl_api.o of every variant
+#     (-DWSL_SRC_SHA256=...), wsl_build_info() returns it, bench.py refuses to run a library whose hash differs from the tree's
+#     and tests/test_abi.py asserts it.
+#   * an object is rebuilt when the HASH of (its source, the shared headers, its flags) differs from the one recorded next to it
+#     (build/<name>.o.key) -- not when a modification time says so: a checkout or a copy cannot leave a stale object behind.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 srcs=(wsl_api wsl_conv wsl_conv2 wsl_conv4 wsl_conv5 wsl_convsp wsl_bn wsl_convt wsl_loss wsl_optim wsl_net wsl_data)
-mkdir -p "$here/build"
-objs=()
-pids=()
-for s in "${srcs[@]}"; do
-  [ -f "$here/$s.hip" ] || continue
-  o="$here/build/$s.o"
-  objs+=("$o")
-  if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$here/wsl_debug.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
-    extra=""
-    # the Winograd kernels are bound by their vector-instruction count: the SLP vectoriser packs the output transforms into
-    # v_pk_add_f32 and then pays more v_mov_b32 to un-interleave the results than it saved (-8 % vector instructions without)
-    [ "$s" = "wsl_conv5" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
-    # (wsl_convsp: measured neutral there -- it removes 24 v_mov_b32 per staged task and costs the 16-wide data-gradient kernel a spill)
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra -c "$here/$s.hip" -o "$o" &
-    pids+=($!)
-  fi
-done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$here/libwslhip.so"
-echo "built $here/libwslhip.so"
+export LC_ALL=C
+SRC_SHA="$(cat $(ls "$here"/*.hip "$here"/*.h | sort) "$root/include/wsl_hip.h" | sha256sum | cut -d' ' -f1)"
+HDR_SHA="$(cat "$here/wsl_rt.h" "$here/wsl_debug.h" "$root/include/wsl_hip.h" | sha256sum | cut -d' ' -f1)"
 
-if [ "${1:-}" = "exp" ] || [ "${2:-}" = "exp" ]; then
-  xd="$root/tools/exp"
-  mkdir -p "$xd/build"
-  xobjs=()
-  pids=()
+# build_variant <object dir> <output .so> <compiler> <link flags> <extra header for the key> <compile flags...>
+build_variant() {
+  local odir="$1" out="$2" cxx="$3" link="$4" xhdr="$5"; shift 5
+  local flags=("$@") objs=() pids=() s o key extra xsha
+  mkdir -p "$odir"
   for s in "${srcs[@]}"; do
     [ -f "$here/$s.hip" ] || continue
-    o="$xd/build/$s.o"
-    xobjs+=("$o")
-    if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$here/wsl_debug.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
-      extra=""
-      [ "$s" = "wsl_conv5" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && extra="-fno-slp-vectorize"
-      "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DWSL_EXPERIMENTS $extra -c "$here/$s.hip" -o "$o" &
+    o="$odir/$s.o"; objs+=("$o"); extra=()
+    # the Winograd kernels are bound by their vector-instruction count: the SLP vectoriser packs the output transforms into
+    # v_pk_add_f32 and then pays more v_mov_b32 to un-interleave the results than it saved (-8 % vector instructions without)
+    # (wsl_convsp: measured neutral there -- it removes 24 v_mov_b32 per staged task and costs the 16-wide data-gradient kernel a spill)
+    [ "$s" = "wsl_conv5" ] && [ "${WSL_NO_SLP:-1}" = "1" ] && [ "$cxx" = "$HIPCC" ] && extra=(-fno-slp-vectorize)
+    [ "$s" = "wsl_api" ] && extra+=("-DWSL_SRC_SHA256=\"$SRC_SHA\"")
+    xsha=""; if [ -n "$xhdr" ]; then xsha="$(sha256sum < "$xhdr" | cut -d' ' -f1)"; fi
+    key="$(sha256sum < "$here/$s.hip" | cut -d' ' -f1) $HDR_SHA $xsha $cxx ${flags[*]} ${extra[*]:-}"
+    if [ ! -f "$o" ] || [ ! -f "$o.key" ] || [ "$(cat "$o.key")" != "$key" ]; then
+      rm -f "$o.key"
+      ( "$cxx" "${flags[@]}" "${extra[@]}" -c "$here/$s.hip" -o "$o" && printf '%s' "$key" > "$o.key" ) &
       pids+=($!)
     fi
   done
-  for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-  "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${xobjs[@]}" -o "$xd/libwslhip_exp.so"
+  local rc=0 p
+  for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
+  [ $rc = 0 ] || { echo "build of $out failed" >&2; exit 1; }
+  BUILT_OBJS=("${objs[@]}")
+}
+
+build_variant "$here/build" "$here/libwslhip.so" "$HIPCC" "" "" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${BUILT_OBJS[@]}" -o "$here/libwslhip.so"
+echo "built $here/libwslhip.so (sources sha256:$SRC_SHA)"
+
+if [ "${1:-}" = "exp" ] || [ "${2:-}" = "exp" ]; then
+  xd="$root/tools/exp"
+  build_variant "$xd/build" "$xd/libwslhip_exp.so" "$HIPCC" "" "" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DWSL_EXPERIMENTS
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${BUILT_OBJS[@]}" -o "$xd/libwslhip_exp.so"
   echo "built $xd/libwslhip_exp.so"
 fi
 
@@ -57,21 +65,11 @@ if [ "${1:-}" = "emul" ] || [ "${2:-}" = "emul" ]; then
   CXX="${EMUL_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
   em="$root/tests/emul"
   mkdir -p "$em/build"
-  eobjs=()
-  pids=()
-  for s in "${srcs[@]}"; do
-    [ -f "$here/$s.hip" ] || continue
-    o="$em/build/$s.o"
-    eobjs+=("$o")
-    if [ ! -f "$o" ] || [ "$here/$s.hip" -nt "$o" ] || [ "$here/wsl_rt.h" -nt "$o" ] || [ "$em/hip_emul.h" -nt "$o" ] || [ "$root/include/wsl_hip.h" -nt "$o" ]; then
-      "$CXX" -x c++ -std=c++17 -O2 -g -fPIC -ffp-contract=off -DWSL_HOST_EMUL -DWSL_EXPERIMENTS -I"$em" -Wall -Wno-unused-function \
-        -Wno-unknown-pragmas -Wno-pass-failed -c "$here/$s.hip" -o "$o" &
-      pids+=($!)
-    fi
-  done
   "$CXX" -std=c++17 -O2 -g -fPIC -c "$em/hip_emul.cpp" -o "$em/build/hip_emul.o" &
-  pids+=($!)
-  for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-  "$CXX" -shared -fPIC -pthread "${eobjs[@]}" "$em/build/hip_emul.o" -o "$em/libwslhip_emul.so"
+  epid=$!
+  build_variant "$em/build" "$em/libwslhip_emul.so" "$CXX" "" "$em/hip_emul.h" -x c++ -std=c++17 -O2 -g -fPIC -ffp-contract=off -DWSL_HOST_EMUL \
+    -DWSL_EXPERIMENTS -I"$em" -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-pass-failed
+  wait $epid
+  "$CXX" -shared -fPIC -pthread "${BUILT_OBJS[@]}" "$em/build/hip_emul.o" -o "$em/libwslhip_emul.so"
   echo "built $em/libwslhip_emul.so"
 fi

@@ -177,10 +177,17 @@ extern "C" int wsl_net_concurrent(int on) {
 
 extern "C" int wsl_version(void) { return 100; }
 extern "C" const char* wsl_last_error(void) { return wsl::g_err; }
+// WSL_SRC_SHA256: SHA-256 of the library's sources (csrc/*.hip, csrc/*.h sorted, include/wsl_hip.h), put on this file's command line by
+// build.sh -- the binary names the tree it was built from (bench.py and tests/test_abi.py compare it with the tree: VERDICT r5 item 4a)
+#ifndef WSL_SRC_SHA256
+#define WSL_SRC_SHA256 "unknown"
+#endif
 extern "C" const char* wsl_build_info(void) {
-#ifdef WSL_HOST_EMUL
-  return "HOST-EMULATION (tests only; not a product build)";
+#if defined(WSL_HOST_EMUL)
+  return "HOST-EMULATION (tests only; not a product build) sha256:" WSL_SRC_SHA256;
+#elif defined(WSL_EXPERIMENTS)
+  return "gfx950 hipcc EXPERIMENTS (tuning tools / route-forcing tests only; not a product build) sha256:" WSL_SRC_SHA256;
 #else
-  return "gfx950 hipcc";
+  return "gfx950 hipcc sha256:" WSL_SRC_SHA256;
 #endif
 }

@@ -224,47 +224,57 @@ struct FwdPlan {
 // 64-pixel-wide tiles only pay for <= 16 output channels; wider layers take 8x32 pixels x as many channels as one
 // workgroup can hold (halves the staging per MFMA); at 16x16 resolution the channel block shrinks until the launch
 // has >= 2 workgroups per CU (a 128-workgroup launch leaves half the chip idle).
-static int g_forced_plan[3] = {-1, 0, 0};   // th, tw, co_t; th < 0: environment not read yet, 0: none
 bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, int* tw, int* co_t);   // wsl_conv5.hip
-// Winograd F(2x2,3x3) for the 3x3 layers it fits (wsl_conv5.hip): env WSL_CONV_WINO / wsl_debug_conv_wino():
-// 0 off, 1 only layers with Co % 32 == 0, 2 also Co % 16 == 0 (default)
+// Winograd F(2x2,3x3) for the 3x3 layers it fits (wsl_conv5.hip): 0 off, 1 only layers with Co % 32 == 0, 2 also Co % 16 == 0 (the
+// product's fixed setting).
 #define WSL_WINO_DEFAULT 2
-static int g_wino = -1;
-static bool wino_enabled() {
-  if (g_wino < 0) {
-    g_wino = WSL_TUNE("WSL_CONV_WINO", WSL_WINO_DEFAULT);
-    if (g_wino < 0 || g_wino > 2) g_wino = WSL_WINO_DEFAULT;
+#ifdef WSL_EXPERIMENTS
+// Routing overrides of the EXPERIMENTS build only (tools/exp/libwslhip_exp.so and the test-only host emulator): the product library has
+// no routing state at all -- its plan of a launch is a pure function of the launch's shape.  Atomics: the tuning
+// tools set them from the host thread between launches.
+static std::atomic<int> g_forced_plan[3] = {{-1}, {0}, {0}};   // th, tw, co_t; th < 0: environment not read yet, 0: none
+static std::atomic<int> g_wino{-1};                            // env WSL_CONV_WINO / wsl_debug_conv_wino()
+static int wino_mode() {
+  int w = g_wino.load();
+  if (w < 0) {
+    w = WSL_TUNE("WSL_CONV_WINO", WSL_WINO_DEFAULT);
+    if (w < 0 || w > 2) w = WSL_WINO_DEFAULT;
+    g_wino.store(w);
   }
-  return g_wino != 0;
+  return w;
 }
+#else
+static constexpr int wino_mode() { return WSL_WINO_DEFAULT; }
+#endif
+static bool wino_enabled() { return wino_mode() != 0; }
 static FwdPlan fwd_plan(int N, int H, int W, int Co, int Ci, int ks) {
   FwdPlan f;
-  // tuning / test aid: WSL_CONV_PLAN=th,tw,co_t or wsl_debug_conv_plan() force one tile shape wherever it divides the layer
-  if (g_forced_plan[0] < 0) {
-    g_forced_plan[0] = 0;
 #ifdef WSL_EXPERIMENTS
+  // tuning / test aid (experiments build only): WSL_CONV_PLAN=th,tw,co_t or wsl_debug_conv_plan() force one tile shape wherever it divides the layer
+  if (g_forced_plan[0].load() < 0) {
     const char* e = getenv("WSL_CONV_PLAN");
     int th = 0, tw = 0, ct = 0;
-    if (e && sscanf(e, "%d,%d,%d", &th, &tw, &ct) == 3) g_forced_plan[0] = th, g_forced_plan[1] = tw, g_forced_plan[2] = ct;
-#endif
+    if (e && sscanf(e, "%d,%d,%d", &th, &tw, &ct) == 3 && th > 0) g_forced_plan[1] = tw, g_forced_plan[2] = ct, g_forced_plan[0] = th;
+    else g_forced_plan[0] = 0;
   }
-  if (g_forced_plan[0] > 0) {
+  if (g_forced_plan[0].load() > 0) {
     const int th = g_forced_plan[0], tw = g_forced_plan[1], ct = g_forced_plan[2];
     if (tw > 0 && W % tw == 0 && ct > 0 && Co % ct == 0) {
       f.th = th, f.tw = tw, f.co_t = ct, f.wino = false;
       return f;
     }
   }
+#endif
   f.wino = false;
   if (Co <= 16) {
     f.co_t = 16;
     if (W >= 64) f.th = 8, f.tw = 64; else if (W >= 32) f.th = 8, f.tw = 32; else f.th = 16, f.tw = 16;
     // a Winograd-shaped layer keeps the Winograd tile in the direct kernels too: one BatchNorm-partial count per layer
-    if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, g_wino == 2, &f.th, &f.tw, nullptr)) f.wino = true;
+    if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, wino_mode() == 2, &f.th, &f.tw, nullptr)) f.wino = true;
     return f;
   }
   if (W >= 32) f.th = 8, f.tw = 32; else f.th = 16, f.tw = 16;
-  if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, g_wino == 2, &f.th, &f.tw, nullptr)) f.wino = true;
+  if (wino_enabled() && wino_shape_ok(H, W, Ci, Co, ks, wino_mode() == 2, &f.th, &f.tw, nullptr)) f.wino = true;
   const int64_t tiles = (int64_t)N * cdiv(H, f.th) * cdiv(W, f.tw);
   const int64_t enough = 2 * (int64_t)device_cu_count();
   f.co_t = Co <= 32 ? 32 : 64;
@@ -486,7 +496,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_dw,
   }
 }
 
-int g_forced_wgrad_wgs = 0;   // wsl_debug_wgrad_workgroups(): small launches walk several tiles per workgroup in the tests (also wsl_convsp.hip)
+#ifdef WSL_EXPERIMENTS
+static std::atomic<int> g_forced_wgrad_wgs{0};   // wsl_debug_wgrad_workgroups(): small launches walk several tiles per workgroup in the tests
+int forced_wgrad_wgs() { return g_forced_wgrad_wgs.load(); }   // (declared in wsl_rt.h; the product's is a constexpr 0)
+#endif
 struct WgPlan {
   int th, tw, cb, ib, wk, nsplit, items, tiles_x, tiles_y, co_blocks, ci_blocks;
 };
@@ -506,7 +519,7 @@ static WgPlan wgrad_plan(int N, int H, int W, int Ci, int Co, bool v2 = false, b
   g.items = N * g.tiles_x * g.tiles_y;
   g.co_blocks = cdiv(Co, g.cb), g.ci_blocks = cdiv(Ci, g.ib);
   static const int wgs = WSL_TUNE("WSL_WGRAD_WGS", 768);   // 3 resident workgroups x 256 CUs
-  int want = (g_forced_wgrad_wgs > 0 ? g_forced_wgrad_wgs : wide ? 512 : wgs) / (g.co_blocks * g.ci_blocks);
+  int want = (forced_wgrad_wgs() > 0 ? forced_wgrad_wgs() : wide ? 512 : wgs) / (g.co_blocks * g.ci_blocks);
   if (want < 1) want = 1;
   g.nsplit = g.items < want ? g.items : want;
   return g;
@@ -576,8 +589,10 @@ int wgrad2_launch(const WslSrc& a, const WslSrc* b, const float* dy, int64_t dy_
 
 using namespace wsl;
 
+#ifdef WSL_EXPERIMENTS
+// (private header wsl_debug.h; experiments build and host emulator only)
 extern "C" int wsl_debug_conv_plan(int th, int tw, int co_t) {
-  g_forced_plan[0] = th > 0 ? th : 0, g_forced_plan[1] = tw, g_forced_plan[2] = co_t;
+  g_forced_plan[1] = tw, g_forced_plan[2] = co_t, g_forced_plan[0] = th > 0 ? th : 0;
   return WSL_OK;
 }
 
@@ -590,6 +605,7 @@ extern "C" int wsl_debug_conv_wino(int on) {
   g_wino = on < 0 ? -1 : (on > 2 ? 2 : on);
   return WSL_OK;
 }
+#endif
 
 extern "C" int wsl_conv2d_wino_ok(int N, int H, int W, int Ca, int Cb, int Co, int ks) {
   if (N <= 0 || Ca <= 0 || Cb < 0) return 0;
@@ -731,6 +747,8 @@ static int wgrad_stage1(const WslSrc* a, const WslSrc* b, const float* dy, int64
     return WSL_EWORKSPACE;
   }
   const int KK = ks * ks;
+  // (the plan actually launched, not only the sizing query: ADVICE r5)
+  WSL_REQUIRE(sizeof(float) * (size_t)g.nsplit * ((size_t)KK * Co * Ci + Co) <= ws_bytes, "conv2d_wgrad: %d splits do not fit the workspace", g.nsplit);
   p.dy = dy, p.dy_bs = dy_bs, p.N = N, p.Co = Co;
   p.part_dw = static_cast<float*>(ws);
   p.part_db = p.part_dw + (size_t)g.nsplit * KK * Co * Ci;

@@ -791,7 +791,7 @@ static int launch_conv2r(Conv2P& p, int wmode_for_prof, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_mfma2r_kernel");
@@ -848,7 +848,7 @@ static int launch_conv2l(Conv2P& p, int wmode_for_prof, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / CO_T);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_mfma2l_kernel");
@@ -878,7 +878,7 @@ static int launch_conv2(Conv2P& p, int wmode_for_prof, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Co, CO_T));
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci), stream);
+  void* tok = prof_begin(wmode_for_prof ? 1 : 0, 2.0 * px * p.Co * p.Ci * KS * KS, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co), stream);
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_mfma2_kernel");

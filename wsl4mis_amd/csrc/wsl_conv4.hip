@@ -258,7 +258,6 @@ int wgrad_small_launch(int kind, const WslSrc& a, const float* dy, int64_t dy_bs
 // products per instruction = 64 consecutive pixels of a row (4 per block) x the 4 classes, K = 1 (one (ci, tap) pair).
 // Lane l supplies the input of pixel l (A) and the weight of class l & 3 (B) and receives pixels 4*(l>>2)..+3 of class
 // l & 3 -- a float4 store.  The 144 weights of a lane's class live in registers for the whole (persistent) workgroup.
-extern int g_forced_wgrad_wgs;   // wsl_conv.hip
 struct ClsP {
   const float* x;        // [N,16,H,W] raw conv output of the last decoder block
   int64_t x_bs;
@@ -402,7 +401,7 @@ int conv_cls_launch(const WslSrc& a, const float* wp, const float* bias, float* 
     (void)WSL_SET_MAX_DYN_SMEM(conv_cls_kernel, ClsCfg::SMEM);
     attr_done = true;
   }
-  int wgs = g_forced_wgrad_wgs > 0 ? g_forced_wgrad_wgs : 2 * device_cu_count();   // (wsl_debug_wgrad_workgroups(): tests force a few)
+  int wgs = forced_wgrad_wgs() > 0 ? forced_wgrad_wgs() : 2 * device_cu_count();   // (wsl_debug_wgrad_workgroups(): tests force a few)
   if (wgs > p.items) wgs = p.items;
   const double px = (double)N * H * W;
   void* tok = prof_begin(0, 2.0 * px * 4 * 16 * 9, 4.0 * px * (16 + 4), stream);
@@ -605,7 +604,7 @@ static int launch_nk16(NkP& p, bool dgrad, void* stream) {
   int wgs = kNk16MinW * device_cu_count();
   if (wgs > p.items) wgs = p.items;
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(dgrad ? PF_CONV_DGRAD : PF_CONV_FWD, 2.0 * px * CI * 16 * 9, 4.0 * px * (16 + CI), stream);
+  void* tok = prof_begin(dgrad ? PF_CONV_DGRAD : PF_CONV_FWD, 2.0 * px * CI * 16 * 9, 4.0 * px * (16 + CI) + bn_epi_bytes(p.bn, px * 16), stream);
   WSL_LAUNCH(kern, dim3(wgs), dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
   return check_launch("conv_nk16_kernel");

@@ -441,8 +441,9 @@ struct Wino2RCfg : Wino2Cfg<TH, TW, NT> {
 
 // (ABL: compile-time phase ablations of the experiments build, env WSL_WINO2R_ABLATE -- 1 no MFMAs, 2 no DMA after the first
 //  chunk, 4 no epilogue, 8 no input-patch reads from LDS after the first chunk; wrong results by design; tools/abl_wino2r.sh)
-template <int TH, int TW, int NT, int ABL = 0>
+template <int TH, int TW, int NT WSL_ABL_TPARAM>
 __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r_kernel(WinoP p) {
+  WSL_ABL_CONST   // (product build: no ablation parameter, the arms below fold away)
   using C = Wino2RCfg<TH, TW, NT>;
   constexpr int KC = C::KC, CO_T = C::CO_T, MTW = C::MTW;
   WSL_DYN_SMEM(smem);
@@ -769,7 +770,7 @@ static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
+  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co), stream,
                          2.0 * px * p.Co * p.Ci * 4);   // issued: 16 instead of 36 multiply-adds per 2x2 tile
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
@@ -790,7 +791,7 @@ static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
+  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co), stream,
                          2.0 * px * p.Co * p.Ci * 4);   // issued: 16 instead of 36 multiply-adds per 2x2 tile
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
@@ -872,8 +873,9 @@ struct WgWinoCfg {
                     (NCI == 1 || NCI == 2) && (NW == 4 || NW == 8), "tile shape");
 };
 
-template <int TH, int TW, int NCO, int NCI, int NW, int ABL = 0>
+template <int TH, int TW, int NCO, int NCI, int NW WSL_ABL_TPARAM>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void wgrad_wino_kernel(WgWinoP p) {
+  WSL_ABL_CONST   // (product build: no ablation parameter, the arms below fold away)
   using C = WgWinoCfg<TH, TW, NCO, NCI, NW>;
   WSL_DYN_SMEM(smem);
   float* tiles = reinterpret_cast<float*>(smem);                    // NBUF x {dy tile, input tile}

@@ -817,7 +817,7 @@ static int launch_conv_sp(ConvSpP& p, int is_dgrad, void* stream) {
   dim3 grid(gx, co_blocks);
   const double px = (double)p.N * p.H * p.W;
   // issued = the three f16 passes over the tap-padded K (10 / 9)
-  void* tok = prof_begin(is_dgrad ? PF_SP_DGRAD : PF_SP_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci), stream,
+  void* tok = prof_begin(is_dgrad ? PF_SP_DGRAD : PF_SP_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co), stream,
                          2.0 * px * p.Co * p.Ci * 10 * 3);
   WSL_LAUNCH(kern, grid, dim3(kThreads), smem, stream, p);
   prof_end(tok, stream);
@@ -1075,7 +1075,6 @@ struct WgSpPlan {
   int th, tw, cb, nsplit, splits, items, tiles_x, tiles_y, co_blocks, ci_blocks;
   bool ok;
 };
-extern int g_forced_wgrad_wgs;   // wsl_conv.hip: wsl_debug_wgrad_workgroups()
 static WgSpPlan wgrad_sp_plan(int N, int H, int W, int Ca, int Cb, int Co) {
   WgSpPlan g{};
   const int Ci = Ca + Cb;
@@ -1086,7 +1085,7 @@ static WgSpPlan wgrad_sp_plan(int N, int H, int W, int Ca, int Cb, int Co) {
   g.cb = (Co % 32 == 0 && Ci % 32 == 0 && (Cb == 0 || Ca % 32 == 0)) ? 32 : 16;
   g.tiles_x = W / g.tw, g.tiles_y = H / g.th, g.items = N * g.tiles_x * g.tiles_y;
   g.co_blocks = Co / g.cb, g.ci_blocks = Ci / g.cb;
-  int want = (g_forced_wgrad_wgs > 0 ? g_forced_wgrad_wgs : 2 * device_cu_count()) / (g.co_blocks * g.ci_blocks);   // two persistent workgroups per CU
+  int want = (forced_wgrad_wgs() > 0 ? forced_wgrad_wgs() : 2 * device_cu_count()) / (g.co_blocks * g.ci_blocks);   // two persistent workgroups per CU
   if (want < 1) want = 1;
   g.nsplit = g.items < want ? g.items : want;
   g.splits = g.cb == 32 ? g.nsplit : 4 * g.nsplit;
@@ -1202,7 +1201,7 @@ extern "C" size_t wsl_sp_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int 
   if (!g.ok) return 0;
   // upper bound over both channel blockings (how Ci splits over two sources may lower the block to 16): 4 partials per
   // persistent workgroup, at most two workgroups per CU
-  const int want = g_forced_wgrad_wgs > 0 ? g_forced_wgrad_wgs : 2 * device_cu_count();
+  const int want = forced_wgrad_wgs() > 0 ? forced_wgrad_wgs() : 2 * device_cu_count();
   const size_t splits = (size_t)4 * (g.items < want ? g.items : want);
   return sizeof(float) * splits * ((size_t)9 * Co * Ci + Co);
 }

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void masks_kernel(MaskTable t, uint32_t k0, ui
     // Philox call -- the generator's integer multiplies are what this kernel is made of (68 -> ~36 us per step); the keep probability is
     // quantised to 1 / 65536 (0.95 -> 0.949997), far inside the sampling noise of any mask
     const int64_t n8 = (t.e[m].numel + 7) >> 3;
-    const uint32_t th16 = th >> 16;
+    // rounded to the nearest 1 / 65536 and able to reach 65536 (keep_prob 1.0 keeps everything, 0.0 nothing: ADVICE r5 -- flooring
+    // dropped one element in 65536 at keep_prob 1.0 and biased every keep rate down by up to 1.5e-5)
+    const uint32_t th16 = th == 0xFFFFFFFFu ? 0x10000u : (uint32_t)(((uint64_t)th + 0x8000u) >> 16);
     uint8_t* o = static_cast<uint8_t*>(t.e[m].out);
     for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < n8; q += (int64_t)gridDim.x * kThreads) {
       uint32_t r[4];
