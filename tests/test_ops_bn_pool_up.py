@@ -96,7 +96,8 @@ def test_bilinear_golden(be):
         assert rel_err(be.np(du), g[f"{tag}_dx"]) < 1e-5, tag
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (1, 2, 24, 32), (1, 2, 8, 128), (1, 1, 40, 64), (2, 2, 5, 7), (1, 2, 6, 12)])
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (1, 2, 24, 32), (1, 2, 8, 128), (1, 1, 40, 64), (2, 2, 5, 7), (1, 2, 6, 12),
+                                   (1, 2, 32, 64), (1, 1, 64, 32), (1, 2, 32, 16), (1, 1, 64, 128)])   # (h % 32 == 0: the 32-row transpose tiles)
 def test_bilinear_fast_and_fallback_shapes(be, shape):
     """power-of-two widths >= 16 take the float4 / LDS-tile kernels, anything else the reference kernels"""
     N, C, h, w = shape

