@@ -463,7 +463,12 @@ def main():
     if eng.dp:
         # self-diagnosing N > 1 line: what each rank saw, how long the main stream sat waiting for the
         # all-reduce stream, and whether the replicas are still bit-identical after the timed region
-        wait_ms = eng.comm_diag(False)
+        wait_ms = eng.comm_diag(False) / max(1, n_rep)          # (the events cover every timed region: per region)
+        bucket_us = eng.bucket_diag()
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if not emu else None
+        except Exception:                                       # noqa: BLE001
+            rccl = None
         p = eng.model.flat_params()
         digest = torch.stack([p.view(torch.int32).to(torch.int64).sum(), (p.view(torch.int32).to(torch.int64) * torch.arange(
             1, p.numel() + 1, device=dev, dtype=torch.int64) % 1000003).sum()])
@@ -481,6 +486,8 @@ def main():
                    "per_rank_ms_per_step_main_stream_blocked_on_allreduce": [round(r[1], 4) for r in rows_],
                    "replicas_bit_identical_after_timed_region": all(r[2] == rows_[0][2] and r[3] == rows_[0][3] for r in rows_),
                    "per_rank_last_loss": [round(r[4], 5) for r in rows_],
+                   "rccl_version": rccl, "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES"), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "allreduce_us_per_bucket_on_the_comm_stream_rank0": bucket_us,     # {elements: mean us}, HIP events on the comm stream
                    "allreduce": "flat fp32 gradient arena in 2 buckets (decoders, then encoder) on a side stream; bytes per step "
                                 f"{4 * eng.model.n_param}", "semantics": "DDP-equivalent (per-rank BN statistics and loss normalisation, gradients averaged)"}
 

@@ -839,12 +839,27 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
     set_error("conv2d_fwd: shape N=%d H=%d W=%d Ci=%d(+%d) Co=%d is not a Winograd shape", N, H, W, p.a.C, p.b.C, Co);
     return WSL_EINVAL;
   }
+#ifdef WSL_EXPERIMENTS
+  // WIDE tiles (round 6, measured and not kept: profiles/r6_wino2r_ablations.md section 5; experiments build only): the same number of
+  // pixels per workgroup as 8 x 64 / 8 x 32 -- so the same BatchNorm partial count as the plan the direct kernels and
+  // wsl_conv2d_stat_blocks() use -- but rows twice as long: 512- / 256-byte row segments instead of 256 / 128 (tools/probe_tile_loads.hip:
+  // the pure halo fetch of a 16-channel 256^2 tensor takes 86 us in 8 x 64 tiles and 72 in 4 x 128; in the kernels it buys nothing)
+  static const int wide16 = WSL_TUNE("WSL_WINO16_WIDE", 0), wide32 = WSL_TUNE("WSL_WINO32_WIDE", 0);   // (wide32: minimum image width)
+  const bool w16 = wide16 && co_t == 16 && th == 8 && tw == 64 && W % 128 == 0 && H % 4 == 0;
+  const bool w32 = wide32 && co_t == 32 && th == 8 && tw == 32 && W % 64 == 0 && H % 4 == 0 && W >= wide32;
+  if (w16) th = 4, tw = 128;
+  if (w32) th = 4, tw = 64;
+#endif
   p.tiles_x = W / tw, p.tiles_y = H / th;
   // every shape wino_shape_ok() admits has a kernel with the BatchNorm-backward statistics in its epilogue
   const bool narrow16 = co_t == 16 && th == 8 && tw == 32;   // 64 tiles x 16 channels: one accumulator set, 3 workgroups per CU
   const bool bn_ok = bn && bn->part;
   if (bn_ok) p.bn = *bn;
   if (bn_done) *bn_done = bn_ok ? 1 : 0;
+#ifdef WSL_EXPERIMENTS
+  if (w16) return launch_wino2<4, 128, 1>(p, is_dgrad, stream);
+  if (w32) return launch_wino2<4, 64, 2>(p, is_dgrad, stream);
+#endif
   if (tw == 64) return launch_wino2<8, 64, 1>(p, is_dgrad, stream);
   if (narrow16) return launch_wino2<8, 32, 1>(p, is_dgrad, stream);
   if (th == 8) return launch_wino2<8, 32, 2>(p, is_dgrad, stream);

@@ -115,7 +115,14 @@ class TrainEngine:
         ev.record(torch.cuda.current_stream())
         self.comm.wait_event(ev)
         with torch.cuda.stream(self.comm):
-            dist.all_reduce(flat)
+            if self._diag is not None:     # per-bucket all-reduce time: HIP events on the COMM stream (torch.cuda.Event times the stream it is recorded on)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(self.comm)
+                dist.all_reduce(flat)
+                b.record(self.comm)
+                self._diag_buckets.append((int(flat.numel()), a, b))
+            else:
+                dist.all_reduce(flat)
 
     # ------------------------------------------------------------------ one optimiser step
     def step(self, x, label_u8, beta=0.5, noise=None):
@@ -321,12 +328,24 @@ class TrainEngine:
         """on=True: start timing how long the main stream sits blocked on the all-reduce stream at the end of every backward;
         on=False: stop, return the total in ms (host sync on the recorded events)."""
         if on:
-            self._diag = []
+            self._diag, self._diag_buckets = [], []
             return 0.0
         pairs, self._diag = self._diag or [], None
         if pairs:
             pairs[-1][1].synchronize()
         return float(sum(a.elapsed_time(b) for a, b in pairs))
+
+    def bucket_diag(self):
+        """after comm_diag(False): {elements of the bucket: mean microseconds of its all-reduce on the comm stream} of the timed steps
+        (decoders' bucket first, then the encoder's) -- what explains a scaling line without a second run"""
+        recs, self._diag_buckets = getattr(self, "_diag_buckets", []), []
+        if not recs:
+            return {}
+        recs[-1][2].synchronize()
+        out = {}
+        for n, a, b in recs:
+            out.setdefault(n, []).append(a.elapsed_time(b) * 1e3)
+        return {str(n): round(sum(v) / len(v), 2) for n, v in out.items()}
 
     def optimizer_step(self):
         m = self.model
