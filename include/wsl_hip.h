@@ -176,6 +176,18 @@ int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const flo
                          const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
                          float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
                          int channel_major, void* ws, size_t ws_bytes, void* stream);
+/* Round 6: the same pair with the ACTIVATION + DROPOUT backward moved into the producer as well (autograd of ref: unet.py:18-29).  The
+ * data-gradient epilogue forms dz = g * keep * scale * leaky'(z) of every element for its sums; wsl_conv2d_dgrad_bn_d lets it WRITE dz where
+ * it would have written g.  *fused = 2: g holds dz, statistics in bn_part -- finish with wsl_bnact_bwd_finish_d_amax, whose pass reads dz
+ * and y only (12 instead of 13 bytes per element, no keep-mask unpacking, no select).  *fused = 1 / 0: exactly wsl_conv2d_dgrad_bn's
+ * meaning (g is the plain gradient: the kernel this launch dispatched to does not hold the consumer's y / keep bytes when it stores). */
+int wsl_conv2d_dgrad_bn_d(const WslSrc* dy, const float* w, float* g, int64_t g_bs, int N, int H, int W, int Co, int ks,
+                          int wmode, const float* bn_y, const float* bn_st, const uint8_t* bn_emask, float bn_emask_scale,
+                          float* bn_part, int* fused, void* stream);
+int wsl_bnact_bwd_finish_d_amax(const float* dz, int64_t dz_bs, const float* y, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta, int N, int C, int H,
+                                int W, const float* part, int nblk, int channel_major, void* ws, size_t ws_bytes, uint32_t* dy_amax,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------ split-precision conv path
  * (opt-in; ref semantics unchanged: networks/unet.py:13-29.)  The 3x3 convolutions on the f16 matrix cores

@@ -202,6 +202,28 @@ def test_dgrad_with_bn_backward_statistics_equals_the_two_pass_form(be, case):
                 N, Cg, H, W, be.ptr(part), nblk, 1, be.ptr(coef), 8 * Cg, be.stream)
         assert rel_err(be.np(dg), be.np(dg_ref)) < 2e-6 and rel_err(be.np(db), be.np(db_ref)) < 2e-6
         assert rel_err(be.np(dy), be.np(dy_ref)) < 2e-6
+    # --- round 6: the d form -- the epilogue writes dz = g * keep * scale * leaky'(z) in place of g where the dispatched kernel can
+    # (*fused == 2: the raw-source Winograd kernel), and wsl_bnact_bwd_finish_d_amax reads dz and y only.  Same dy, dgamma, dbeta.
+    g2, dy2 = be.zeros((N, Cg, H, W)), be.zeros((N, Cg, H, W))
+    dg2, db2, part2, coef2 = be.zeros((Cg,)), be.zeros((Cg,)), be.ws(nws), be.zeros((2 * Cg,))
+    fused2 = C_.c_int(-1)
+    be.call("wsl_conv2d_dgrad_bn_d", src, be.ptr(wp), be.ptr(g2), Cg * H * W, N, H, W, Cg, ks, wmode, be.ptr(d["y"]), be.ptr(d["st"]),
+            be.ptr(dm) if with_mask else None, es, be.ptr(part2), C_.byref(fused2), be.stream)
+    assert (fused2.value == 0) == (fused.value == 0), (fused.value, fused2.value)
+    assert fused2.value == (2 if wmode == 5 and fused.value else fused.value), (case, fused2.value)
+    if fused2.value == 2:
+        z = y * st[2 * Cg:3 * Cg][None, :, None, None] + st[3 * Cg:][None, :, None, None]
+        keep = (emask.astype(np.float32) * np.float32(es)) if with_mask else np.float32(1.0)
+        dz_ref = be.np(g_ref) * keep * np.where(z > 0, np.float32(1.0), np.float32(0.01))
+        assert rel_err(be.np(g2), dz_ref) < 1e-6
+        nblk = be.lib.wsl_conv2d_stat_blocks(N, H, W, Cdy, Cg, ks)
+        be.call("wsl_bnact_bwd_finish_d_amax", be.ptr(g2), Cg * H * W, be.ptr(d["y"]), be.ptr(d["mean"]), be.ptr(d["invstd"]),
+                be.ptr(d["gamma"]), be.ptr(d["beta"]), be.ptr(dy2), be.ptr(dg2), be.ptr(db2), N, Cg, H, W, be.ptr(part2), nblk, 1,
+                be.ptr(coef2), 8 * Cg, None, be.stream)
+        assert rel_err(be.np(dg2), be.np(dg_ref)) < 2e-6 and rel_err(be.np(db2), be.np(db_ref)) < 2e-6
+        assert rel_err(be.np(dy2), be.np(dy_ref)) < 2e-6
+    elif fused2.value == 1:
+        assert np.array_equal(be.np(g2), be.np(g_ref))
 
 
 @pytest.mark.parametrize("shape,pool", [((2, 3, 8, 12), True), ((1, 4, 7, 10), True), ((2, 2, 6, 6), False)])

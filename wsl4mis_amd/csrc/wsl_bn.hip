@@ -278,6 +278,7 @@ struct BnBwdP {
   const uint8_t* emask;
   float es;
   int C, HW, chunks;
+  int g_is_d = 0;   // g already holds d = g * keep * scale * leaky'(z) (written by wsl_conv2d_dgrad_bn_d): no keep-mask read, no select
 };
 
 __device__ __forceinline__ float bn_dz(const BnBwdP& p, int n, int c, int i, float sc, float sh, float mean, float invstd,
@@ -285,9 +286,10 @@ __device__ __forceinline__ float bn_dz(const BnBwdP& p, int n, int c, int i, flo
   const int64_t idx = ((int64_t)n * p.C + c) * p.HW + i;
   const float yv = p.y[idx];
   float d = p.g[n * p.g_bs + (int64_t)c * p.HW + i];
+  *xhat = (yv - mean) * invstd;
+  if (p.g_is_d) return d;
   if (p.emask) d = p.emask[idx] ? d * p.es : 0.f;
   const float z = fmaf(yv, sc, sh);           // same expression as the forward loader: identical sign decisions
-  *xhat = (yv - mean) * invstd;
   return z > 0.f ? d : WSL_LEAKY_SLOPE * d;
 }
 
@@ -322,6 +324,11 @@ __device__ __forceinline__ void bn_dz4(const BnBwdP& p, int n, int c, int i, flo
   const float4 gv = *reinterpret_cast<const float4*>(p.g + n * p.g_bs + (int64_t)c * p.HW + i);
   const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
   float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+  if (p.g_is_d) {   // (kernel argument: uniform)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xh[k] = (y4[k] - mean) * invstd, d[k] = g4[k];
+    return;
+  }
   if (p.emask) {
     const uint32_t m = *reinterpret_cast<const uint32_t*>(p.emask + idx);
 #pragma unroll
@@ -832,16 +839,17 @@ extern "C" size_t wsl_bnact_bwd_finish_ws_bytes(int N, int C, int H, int W, int 
   return sizeof(float) * (2 * (size_t)C + (with_amax ? (size_t)N * cdiv(H * W, kChunk) * C : 0));
 }
 
-extern "C" int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
-                                         const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
-                                         float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
-                                         int channel_major, void* ws, size_t ws_bytes, uint32_t* dy_amax, void* stream) {
+static int bnact_bwd_finish_impl(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                                 float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
+                                 int channel_major, void* ws, size_t ws_bytes, uint32_t* dy_amax, int g_is_d, void* stream) {
   WSL_REQUIRE(g && y && mean && invstd && gamma && beta && dy && ws && part, "bnact_bwd_finish: null argument");
   WSL_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && nblk > 0, "bnact_bwd_finish: bad shape");
   WSL_REQUIRE(ws_bytes >= wsl_bnact_bwd_finish_ws_bytes(N, C, H, W, dy_amax != nullptr),
               "bnact_bwd_finish: workspace too small (wsl_bnact_bwd_finish_ws_bytes)");
   BnBwdP p{g, g_bs, y, mean, invstd, gamma, beta, emask, emask_scale, C, H * W, cdiv(H * W, kChunk)};
-  ProfScope ps(PF_BN_BWD, 0.0, (double)N * C * H * W * (12.0 + (emask ? 1.0 : 0.0)), stream);     // the apply pass alone
+  p.g_is_d = g_is_d;
+  ProfScope ps(PF_BN_BWD, 0.0, (double)N * C * H * W * (12.0 + (emask && !g_is_d ? 1.0 : 0.0)), stream);     // the apply pass alone
   float* coef = static_cast<float*>(ws);
   dim3 grid(p.chunks, C, N);
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -855,6 +863,22 @@ extern "C" int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const flo
   else WSL_LAUNCH(bnact_bwd_apply_kernel, grid, dim3(kThreads), 0, stream, p, coef, dy, pmax);
   if (dy_amax) WSL_LAUNCH(amax_fold_kernel, dim3(WSL_SP_AMAX_SLOTS), dim3(kThreads), 0, stream, pmax, N * p.chunks * C, dy_amax);
   return check_launch("bnact_bwd_finish");
+}
+
+extern "C" int wsl_bnact_bwd_finish_amax(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, const uint8_t* emask, float emask_scale, float* dy,
+                                         float* dgamma, float* dbeta, int N, int C, int H, int W, const float* part, int nblk,
+                                         int channel_major, void* ws, size_t ws_bytes, uint32_t* dy_amax, void* stream) {
+  return bnact_bwd_finish_impl(g, g_bs, y, mean, invstd, gamma, beta, emask, emask_scale, dy, dgamma, dbeta, N, C, H, W, part, nblk,
+                               channel_major, ws, ws_bytes, dy_amax, 0, stream);
+}
+
+extern "C" int wsl_bnact_bwd_finish_d_amax(const float* d, int64_t d_bs, const float* y, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta, int N, int C,
+                                           int H, int W, const float* part, int nblk, int channel_major, void* ws, size_t ws_bytes,
+                                           uint32_t* dy_amax, void* stream) {
+  return bnact_bwd_finish_impl(d, d_bs, y, mean, invstd, gamma, beta, nullptr, 1.f, dy, dgamma, dbeta, N, C, H, W, part, nblk,
+                               channel_major, ws, ws_bytes, dy_amax, 1, stream);
 }
 
 extern "C" int wsl_bnact_bwd_finish(const float* g, int64_t g_bs, const float* y, const float* mean, const float* invstd,

@@ -690,17 +690,29 @@ extern "C" int wsl_conv2d_fwd(const WslSrc* a, const WslSrc* b, const float* w, 
   return conv2d_fwd_impl(a, b, w, bias, y, y_bs, N, H, W, Co, ks, wmode, stat_part, stat_cnt, stream, nullptr, nullptr);
 }
 
-extern "C" int wsl_conv2d_dgrad_bn(const WslSrc* dy, const float* w, float* g, int64_t g_bs, int N, int H, int W, int Co,
-                                   int ks, int wmode, const float* bn_y, const float* bn_st, const uint8_t* bn_emask,
-                                   float bn_emask_scale, float* bn_part, int* fused, void* stream) {
+static int dgrad_bn_impl(const WslSrc* dy, const float* w, float* g, int64_t g_bs, int N, int H, int W, int Co, int ks, int wmode,
+                         const float* bn_y, const float* bn_st, const uint8_t* bn_emask, float bn_emask_scale, float* bn_part, int* fused,
+                         bool allow_d, void* stream) {
   WSL_REQUIRE(bn_y && bn_st && bn_part && fused, "conv2d_dgrad_bn: null BatchNorm argument");
   WSL_REQUIRE(wmode == 1 || wmode == 3 || wmode == 5, "conv2d_dgrad_bn: wmode %d is not a data-gradient mode", wmode);
   BnBwdEpi e;
-  e.y = bn_y, e.st = bn_st, e.emask = bn_emask, e.es = bn_emask_scale, e.part = bn_part;
+  e.y = bn_y, e.st = bn_st, e.emask = bn_emask, e.es = bn_emask_scale, e.part = bn_part, e.store_d = allow_d;
   if (g_bs != (int64_t)Co * H * W || (W & 3) || (reinterpret_cast<uintptr_t>(bn_y) & 15) ||
       (bn_emask && (reinterpret_cast<uintptr_t>(bn_emask) & 3)))
     e.part = nullptr;        // the statistics address y through the dense index of g: same shape, float4-aligned rows
   return conv2d_fwd_impl(dy, nullptr, w, nullptr, g, g_bs, N, H, W, Co, ks, wmode, nullptr, nullptr, stream, &e, fused);
+}
+
+extern "C" int wsl_conv2d_dgrad_bn(const WslSrc* dy, const float* w, float* g, int64_t g_bs, int N, int H, int W, int Co,
+                                   int ks, int wmode, const float* bn_y, const float* bn_st, const uint8_t* bn_emask,
+                                   float bn_emask_scale, float* bn_part, int* fused, void* stream) {
+  return dgrad_bn_impl(dy, w, g, g_bs, N, H, W, Co, ks, wmode, bn_y, bn_st, bn_emask, bn_emask_scale, bn_part, fused, false, stream);
+}
+
+extern "C" int wsl_conv2d_dgrad_bn_d(const WslSrc* dy, const float* w, float* g, int64_t g_bs, int N, int H, int W, int Co,
+                                     int ks, int wmode, const float* bn_y, const float* bn_st, const uint8_t* bn_emask,
+                                     float bn_emask_scale, float* bn_part, int* fused, void* stream) {
+  return dgrad_bn_impl(dy, w, g, g_bs, N, H, W, Co, ks, wmode, bn_y, bn_st, bn_emask, bn_emask_scale, bn_part, fused, true, stream);
 }
 
 extern "C" size_t wsl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co, int ks) {

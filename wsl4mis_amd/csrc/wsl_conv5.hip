@@ -114,7 +114,9 @@ __device__ __forceinline__ int64_t wino2_corner(int n, int64_t bs_or_chw, int co
 
 // PRE: the caller has the BatchNorm-backward epilogue's y / keep-mask values in registers (loaded before its channel loop)
 // (EABL, experiments build only: 32 = the output stores are predicated off (same instructions otherwise), 64 = no statistics)
-template <typename C, int TH, int TW, int NT, bool PRE = false, int EABL = 0>
+// (SD: a data-gradient launch that writes d = g * keep * scale * leaky'(z) in place of g -- BnBwdEpi::store_d -- as its own instantiation:
+//  as a run-time branch the second store path cost the kernels 14-24 spilled registers)
+template <typename C, int TH, int TW, int NT, bool PRE = false, int EABL = 0, bool SD = false>
 __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C::NA], float* scratch, int n, int co0, int y0, int x0,
                                                int tile_id, int nb, int cby, const float4* ypre = nullptr,
                                                const uint32_t* mpre = nullptr) {
@@ -164,6 +166,8 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C:
         *reinterpret_cast<float4*>(ycorner + yb) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
         *reinterpret_cast<float4*>(ycorner + (ya + wb)) = make_float4(o[a][8], o[a][9], o[a][10], o[a][11]);
         *reinterpret_cast<float4*>(ycorner + (yb + wb)) = make_float4(o[a][12], o[a][13], o[a][14], o[a][15]);
+      } else if constexpr (SD) {
+        // (the BatchNorm-backward section below writes d = g * keep * scale * leaky'(z) in place of g: wsl_conv2d_dgrad_bn_d)
       } else if ((EABL & 32) == 0 || bs == 123.456f) {
         *reinterpret_cast<float4*>(ycorner + yo) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
         *reinterpret_cast<float4*>(ycorner + (yo + 16u)) = make_float4(o[a][4], o[a][5], o[a][6], o[a][7]);
@@ -187,7 +191,16 @@ __device__ __forceinline__ void wino2_epilogue(const WinoP& p, v4f (&acc)[16][C:
         const int tyy = tb / C::TTX, txb = tb - tyy * C::TTX;
         const int64_t base = ((int64_t)n * p.Co + co) * HW + (int64_t)(y0 + 2 * tyy) * W + x0 + 2 * txb;
         const int a = m * NT + j;
-        if constexpr (PRE) {
+        if constexpr (PRE && SD) {   // d goes where g would have gone; the consumer's apply pass then reads no keep mask
+          const uint32_t yo = 4u * wino2_out_lane_off<C, NT>(HW, W, a * 4), wb = 4u * (uint32_t)W;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float d[4];
+            bn_bwd_acc4v(p.bn, ypre[a * 4 + r], mpre[a * 4 + r], o[a][4 * r], o[a][4 * r + 1], o[a][4 * r + 2], o[a][4 * r + 3], mean,
+                         invstd, sc, sh, ba, d);
+            *reinterpret_cast<float4*>(ycorner + (yo + (r & 1) * 16u + (r >> 1) * wb)) = make_float4(d[0], d[1], d[2], d[3]);
+          }
+        } else if constexpr (PRE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             bn_bwd_acc4v(p.bn, ypre[a * 4 + r], mpre[a * 4 + r], o[a][4 * r], o[a][4 * r + 1], o[a][4 * r + 2], o[a][4 * r + 3], mean,
@@ -453,7 +466,7 @@ struct Wino2RCfg : Wino2Cfg<TH, TW, NT> {
 
 // (ABL: compile-time phase ablations of the experiments build, env WSL_WINO2R_ABLATE -- 1 no MFMAs, 2 no DMA after the first
 //  chunk, 4 no epilogue, 8 no input-patch reads from LDS after the first chunk; wrong results by design; tools/abl_wino2r.sh)
-template <int TH, int TW, int NT WSL_ABL_TPARAM>
+template <int TH, int TW, int NT, bool SD = false WSL_ABL_TPARAM>
 __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r_kernel(WinoP p) {
   WSL_ABL_CONST   // (product build: no ablation parameter, the arms below fold away)
   using C = Wino2RCfg<TH, TW, NT>;
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   // channel loop ahead of their use (this kernel has the 40 registers; the epilogue would otherwise sit out their latency)
   float4 ypre[4 * C::NA];
   uint32_t mpre[4 * C::NA];
-  const bool bn_epi = p.bn.part != nullptr;
+  const bool bn_epi = SD || p.bn.part != nullptr;   // (an SD launch always carries the BatchNorm-backward epilogue)
   if (bn_epi) {
     const int64_t corner = wino2_corner(n, (int64_t)Co * HW, co0, HW, y0, W, x0);                      // wave-uniform
     const char* const yc = reinterpret_cast<const char*>(p.bn.y + corner);
@@ -623,8 +636,12 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     if (t == 123.456f) p.y[0] = t;
     return;
   }
-  if (bn_epi) wino2_epilogue<C, TH, TW, NT, true, (ABL & 224)>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
-  else wino2_epilogue<C, TH, TW, NT, false, (ABL & 224)>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
+  if constexpr (SD) {
+    wino2_epilogue<C, TH, TW, NT, true, 0, true>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
+  } else {
+    if (bn_epi) wino2_epilogue<C, TH, TW, NT, true, (ABL & 224)>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby, ypre, mpre);
+    else wino2_epilogue<C, TH, TW, NT, false, (ABL & 224)>(p, acc, in_b, n, co0, y0, x0, tile_id, nb, cby);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ filter transform
@@ -769,30 +786,35 @@ static inline double wsrc_mask_bytes(const WinoP& p, double px) { return px * ((
 template <int TH, int TW, int NT>
 static int launch_wino2r(WinoP& p, int is_dgrad, void* stream) {
   using C = Wino2RCfg<TH, TW, NT>;
-  auto kern = conv_wino2r_kernel<TH, TW, NT>;
+  auto kern = (p.bn.part && p.bn.store_d) ? conv_wino2r_kernel<TH, TW, NT, true> : conv_wino2r_kernel<TH, TW, NT>;
 #ifdef WSL_EXPERIMENTS
-  {
+  if (!(p.bn.part && p.bn.store_d)) {
     static const int abl = WSL_TUNE("WSL_WINO2R_ABLATE", 0);
-    if (abl == 1) kern = conv_wino2r_kernel<TH, TW, NT, 1>;
-    if (abl == 2) kern = conv_wino2r_kernel<TH, TW, NT, 2>;
-    if (abl == 4) kern = conv_wino2r_kernel<TH, TW, NT, 4>;
-    if (abl == 6) kern = conv_wino2r_kernel<TH, TW, NT, 6>;     // channel loop only, no memory traffic
-    if (abl == 7) kern = conv_wino2r_kernel<TH, TW, NT, 7>;     // ... without MFMAs
-    if (abl == 14) kern = conv_wino2r_kernel<TH, TW, NT, 14>;   // ... without operand reads (transforms + MFMAs)
-    if (abl == 3) kern = conv_wino2r_kernel<TH, TW, NT, 3>;
-    if (abl == 128) kern = conv_wino2r_kernel<TH, TW, NT, 128>; // epilogue stores in the address pattern of a lane-transposed epilogue
-    if (abl == 32) kern = conv_wino2r_kernel<TH, TW, NT, 32>;   // epilogue without its global stores
-    if (abl == 64) kern = conv_wino2r_kernel<TH, TW, NT, 64>;   // epilogue without its statistics
-    if (abl == 96) kern = conv_wino2r_kernel<TH, TW, NT, 96>;   // epilogue = output transform only
-    if (abl == 16) kern = conv_wino2r_kernel<TH, TW, NT, 16>;   // half the input transforms per MFMA (NT = 4's upper bound)
-    if (abl == 20) kern = conv_wino2r_kernel<TH, TW, NT, 20>;   // ... and no epilogue
+    if (abl == 1) kern = conv_wino2r_kernel<TH, TW, NT, false, 1>;
+    if (abl == 2) kern = conv_wino2r_kernel<TH, TW, NT, false, 2>;
+    if (abl == 4) kern = conv_wino2r_kernel<TH, TW, NT, false, 4>;
+    if (abl == 6) kern = conv_wino2r_kernel<TH, TW, NT, false, 6>;     // channel loop only, no memory traffic
+    if (abl == 7) kern = conv_wino2r_kernel<TH, TW, NT, false, 7>;     // ... without MFMAs
+    if (abl == 14) kern = conv_wino2r_kernel<TH, TW, NT, false, 14>;   // ... without operand reads (transforms + MFMAs)
+    if (abl == 3) kern = conv_wino2r_kernel<TH, TW, NT, false, 3>;
+    if (abl == 128) kern = conv_wino2r_kernel<TH, TW, NT, false, 128>; // epilogue stores in the address pattern of a lane-transposed epilogue
+    if (abl == 32) kern = conv_wino2r_kernel<TH, TW, NT, false, 32>;   // epilogue without its global stores
+    if (abl == 64) kern = conv_wino2r_kernel<TH, TW, NT, false, 64>;   // epilogue without its statistics
+    if (abl == 96) kern = conv_wino2r_kernel<TH, TW, NT, false, 96>;   // epilogue = output transform only
+    if (abl == 16) kern = conv_wino2r_kernel<TH, TW, NT, false, 16>;   // half the input transforms per MFMA (NT = 4's upper bound)
+    if (abl == 20) kern = conv_wino2r_kernel<TH, TW, NT, false, 20>;   // ... and no epilogue
   }
 #endif
+#ifdef WSL_EXPERIMENTS
+  (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);   // (the ablation variants: whichever was picked)
+#else
   static bool attr_done = false;
   if (!attr_done) {
-    (void)WSL_SET_MAX_DYN_SMEM(kern, C::SMEM);
+    (void)WSL_SET_MAX_DYN_SMEM((conv_wino2r_kernel<TH, TW, NT>), C::SMEM);
+    (void)WSL_SET_MAX_DYN_SMEM((conv_wino2r_kernel<TH, TW, NT, true>), C::SMEM);
     attr_done = true;
   }
+#endif
   dim3 grid(p.tiles_x * p.tiles_y * p.N, p.Co / C::CO_T);
   const double px = (double)p.N * p.H * p.W;
   void* tok = prof_begin(is_dgrad ? PF_WINO_DGRAD : PF_WINO_FWD, 2.0 * px * p.Co * p.Ci * 9, 4.0 * px * (p.Co + p.Ci) + bn_epi_bytes(p.bn, px * p.Co) + wsrc_mask_bytes(p, px), stream,
@@ -855,7 +877,11 @@ int wino_fwd(const WslSrc& a, const WslSrc* b, const float* u, const float* bias
   const bool narrow16 = co_t == 16 && th == 8 && tw == 32;   // 64 tiles x 16 channels: one accumulator set, 3 workgroups per CU
   const bool bn_ok = bn && bn->part;
   if (bn_ok) p.bn = *bn;
-  if (bn_done) *bn_done = bn_ok ? 1 : 0;
+  // d instead of g (BnBwdEpi::store_d) is written by the raw-source kernel only: it has the consumer's y / keep bytes in registers when it stores
+  static const bool dma_on = (WSL_TUNE("WSL_WINO_DMA", 1) != 0);
+  const bool raw_src = !p.a.scale && !p.a.emask && !p.a.cmask && (p.b.C == 0 || (!p.b.scale && !p.b.emask && !p.b.cmask));
+  if (!bn_ok || !(raw_src && dma_on)) p.bn.store_d = false;
+  if (bn_done) *bn_done = bn_ok ? (p.bn.store_d ? 2 : 1) : 0;
 #ifdef WSL_EXPERIMENTS
   if (w16) return launch_wino2<4, 128, 1>(p, is_dgrad, stream);
   if (w32) return launch_wino2<4, 64, 2>(p, is_dgrad, stream);

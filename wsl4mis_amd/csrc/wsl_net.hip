@@ -341,6 +341,7 @@ static int conv_any(const Ctx& c, const ConvRef& cv, int dgrad, const WslSrc* a,
 struct GStats {
   int nblk = 0;            // 0: none, run the stand-alone reduction pass
   int channel_major = 0;
+  int g_is_d = 0;          // the producer wrote d = g * keep * scale * leaky'(z) in place of g (wsl_conv2d_dgrad_bn_d, *fused == 2)
 };
 
 // data-gradient convolution of layer `cv` (dy -> g, dense) that also emits the backward statistics of the BatchNorm whose raw
@@ -365,10 +366,11 @@ static int conv_dgrad_bn(const Ctx& c, const ConvRef& cv, const float* dy, float
     else w = c.ws + c.P.packd + cv.w, wmode = 3;
   }
   int fused = 0;
-  WSL_TRY(wsl_conv2d_dgrad_bn(&dys, w, g, g_bs, N, H, W, Cg, cv.ks, wmode, c.ws + y, c.ws + st, emask, es, c.ws + c.S().bn_ws,
-                              &fused, c.stream));
+  WSL_TRY(wsl_conv2d_dgrad_bn_d(&dys, w, g, g_bs, N, H, W, Cg, cv.ks, wmode, c.ws + y, c.ws + st, emask, es, c.ws + c.S().bn_ws,
+                                &fused, c.stream));
   gs->nblk = fused ? wsl_conv2d_stat_blocks(N, H, W, cv.Co, Cg, cv.ks) : 0;
   gs->channel_major = 1;
+  gs->g_is_d = fused == 2;
   return WSL_OK;
 }
 
@@ -379,6 +381,10 @@ static int bn_bwd(const Ctx& c, const float* g, int64_t g_bs, size_t y, size_t s
   const int C = bn.C;
   const float* s = c.ws + st;
   // (split path: the apply pass also leaves max |dy| in the layer's slot -- the operand scale of dy's two consumers)
+  if (gs.nblk && gs.g_is_d)   // g already is the gradient in front of the BatchNorm output: the apply pass reads it and y only
+    return wsl_bnact_bwd_finish_d_amax(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, dy, c.grads + bn.gamma,
+                                       c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, gs.nblk, gs.channel_major,
+                                       c.ws + c.S().bn_coef, P.bn_coef_bytes, sp_dymax(c, bn), c.stream);
   if (gs.nblk)
     return wsl_bnact_bwd_finish_amax(g, g_bs, c.ws + y, s, s + C, c.params + bn.gamma, c.params + bn.beta, emask, es, dy,
                                      c.grads + bn.gamma, c.grads + bn.beta, P.d.N, C, H, W, c.ws + c.S().bn_ws, gs.nblk,

@@ -365,6 +365,8 @@ struct BnBwdEpi {
   const uint8_t* emask = nullptr;  // keep mask of the nn.Dropout after the activation (or null)
   float es = 1.f;
   float* part = nullptr;           // [C][tiles][2]; null = no statistics
+  bool store_d = false;            // the launch may write d = g * (keep byte * scale) * leaky'(z) -- the gradient in front of the BatchNorm
+                                   // output, which the epilogue forms for its sums anyway -- instead of g (wsl_conv2d_dgrad_bn_d: round 6)
 };
 // algorithmic HBM bytes the BatchNorm-backward statistics epilogue adds to a data-gradient launch over `elems` output elements: one read
 // of the consumer layer's raw output y (4 B) and of its keep mask (1 B) per element -- counted in the launch's algorithmic bytes (the
@@ -379,8 +381,9 @@ struct BnBwdAcc {
 };
 // (yv, m: the four conv outputs and keep bytes at the gradient's position -- a caller with registers to spare loads them
 //  early, bn_bwd_acc4 loads them here)
+// (dout: where the caller wants d itself, the four values in element order)
 __device__ __forceinline__ void bn_bwd_acc4v(const BnBwdEpi& e, float4 yv, uint32_t m, float g0, float g1, float g2, float g3,
-                                             float mean, float invstd, float sc, float sh, BnBwdAcc& a) {
+                                             float mean, float invstd, float sc, float sh, BnBwdAcc& a, float* dout = nullptr) {
   const wsl_v2f y[2] = {{yv.x, yv.y}, {yv.z, yv.w}};
   wsl_v2f g[2] = {{g0, g1}, {g2, g3}};
   if (e.emask) {   // keep bytes are 0 or 1: (g * scale) * byte == the selected value
@@ -396,6 +399,7 @@ __device__ __forceinline__ void bn_bwd_acc4v(const BnBwdEpi& e, float4 yv, uint3
     const wsl_v2f d = {z[0] > 0.f ? g[h][0] : gl[0], z[1] > 0.f ? g[h][1] : gl[1]};
     a.s1 += d;
     a.s2 = __builtin_elementwise_fma(d, xh, a.s2);
+    if (dout) dout[2 * h] = d[0], dout[2 * h + 1] = d[1];
   }
 }
 __device__ __forceinline__ void bn_bwd_acc4(const BnBwdEpi& e, int64_t idx, float g0, float g1, float g2, float g3, float mean,
