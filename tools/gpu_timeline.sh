@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# round 6, call f: kernel TIMELINE of the default two-stream step (rocprofv3 --kernel-trace, timestamps kept): how much of a step has no
+# kernel TIMELINE of the default two-stream step (rocprofv3 --kernel-trace, timestamps kept): how much of a step has no
 # kernel running (dependency gaps), how much has two; analysed by tools/timeline_gaps.py
 set -u
 O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd /tmp; export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# round 5, bundle g: HBM traffic of EVERY kernel of the f32 step (FETCH_SIZE / WRITE_SIZE, separate passes, decoders serialised), per kernel name
+# HBM traffic of EVERY kernel of the f32 step (FETCH_SIZE / WRITE_SIZE, separate passes, decoders serialised), per kernel name
 O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-split-record --steps 2 --warmup 1 --serial-decoders --no-prof"
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do

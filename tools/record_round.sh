@@ -7,7 +7,7 @@ set -u
 O="$1"; R="${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p "$R/$O"; cd "$R"
 rm -f gpurun_out/labelmap_rates.jsonl gpurun_out/fullsize_error_budget.json
 (WSL_FP64_BUDGET=1 timeout 1500 python -m pytest tests -m gpu -q --tb=short -s 2>&1 | grep -v "^iteration" | tail -60) > "$O/pytest_gpu.log"
-cp gpurun_out/labelmap_rates.jsonl gpurun_out/fullsize_error_budget.json gpurun_out/fullsize_replayed_decisions*.json "$O"/ 2>/dev/null
+cp gpurun_out/labelmap_rates.jsonl gpurun_out/fullsize_error_budget*.json gpurun_out/fullsize_replayed_decisions*.json "$O"/ 2>/dev/null
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1) > "$O/smoke.log"
 (timeout 900 python bench.py 2>"$O/bench_stderr.log" | tail -1) > "$O/bench_default.json"
 (timeout 400 python bench.py --loss pce --no-cpu-baseline 2>/dev/null | tail -1) > "$O/bench_pce.json"
@@ -16,9 +16,11 @@ cp gpurun_out/labelmap_rates.jsonl gpurun_out/fullsize_error_budget.json gpurun_
 (timeout 400 python bench.py --loss mean_teacher --no-cpu-baseline 2>/dev/null | tail -1) > "$O/bench_mt.json"
 (timeout 300 python bench.py --net unet --loss pce --no-cpu-baseline 2>/dev/null | tail -1) > "$O/bench_unet_pce.json"
 (timeout 300 python bench.py --serial-decoders --no-cpu-baseline --no-split-record 2>/dev/null | tail -1) > "$O/bench_serial.json"
+(timeout 300 python bench.py --path modules --steps 20 --warmup 5 2>/dev/null | tail -1) > "$O/bench_modules.json"
+(timeout 300 python bench.py --force-dp --no-cpu-baseline --no-split-record 2>/dev/null | tail -1) > "$O/bench_forcedp.json"
 for l in pce_tv pce_ms pce_entropy; do (timeout 300 python bench.py --loss $l --no-cpu-baseline 2>/dev/null | tail -1) > "$O/bench_unet_$l.json"; done
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-split-record"
+B="python $R/bench.py --no-cpu-baseline --no-split-record --no-pmc-refresh --repeats 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_f32_serial" -- $B --steps 10 --warmup 3 --serial-decoders > "$R/$O/bench_serial_under_rocprof.log" 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_split_serial" -- $B --steps 10 --warmup 3 --serial-decoders --conv-precision split_f16x3 > "$R/$O/bench_split_serial_under_rocprof.log" 2>/dev/null
 # counters: separate passes, never combined with a trace domain
