@@ -191,6 +191,43 @@ def gatedcrf(y, img, radius, sigma_xy=6.0, sigma_rgb=0.1, weight=1.0):
     return loss, msg
 
 
+def gatedcrf_general(y, sample, kernels_desc, radius):
+    """ModelLossSemsegGatedCRF.forward for what its signature admits beyond the trainers' one descriptor (gate_crf_loss.py:20-188; Potts
+    model, no masks): `sample` [N,1,Hs,Ws] is brought to the prediction's resolution by F.adaptive_avg_pool2d (:127-133); every kernel
+    descriptor contributes weight * exp(-0.5 * |f_q - f_p|^2) with features f = cat(mesh / sigma if 'xy' is listed, sample / sigma for EVERY
+    other modality it lists) in the descriptor's key order (:135-161), the kernels are summed, the centre tap is 0 (:171), out-of-image taps
+    see the all-zero feature vector and y = 0 (zero-padded unfold, :184-188).  Returns the loss (a sum over descriptors: it is linear in the
+    kernel)."""
+    N, C, H, W = y.shape
+    r = radius
+    if tuple(sample.shape[-2:]) != (H, W):
+        sample = F.adaptive_avg_pool2d(sample, (H, W))
+    yp = F.pad(y, (r, r, r, r))
+    ksum = torch.zeros((), dtype=y.dtype)
+    prod = torch.zeros((), dtype=y.dtype)
+    for desc in kernels_desc:
+        feats = []
+        for modality, sigma in desc.items():
+            if modality == "weight":
+                continue
+            if modality == "xy":
+                feats.append((torch.arange(W, dtype=y.dtype) / sigma).view(1, 1, 1, W).expand(N, 1, H, W))
+                feats.append((torch.arange(H, dtype=y.dtype) / sigma).view(1, 1, H, 1).expand(N, 1, H, W))
+            else:
+                feats.append(sample.to(y.dtype) / sigma)
+        f = torch.cat(feats, dim=1)
+        fp = F.pad(f, (r, r, r, r))
+        for dy in range(-r, r + 1):
+            for dx in range(-r, r + 1):
+                if dy == 0 and dx == 0:
+                    continue
+                fq = fp[:, :, r + dy:r + dy + H, r + dx:r + dx + W]
+                k = desc["weight"] * torch.exp((-0.5 * (fq - f) ** 2).sum(dim=1, keepdim=True))
+                ksum = ksum + k.sum()
+                prod = prod + (k * yp[:, :, r + dy:r + dy + H, r + dx:r + dx + W] * y).sum()
+    return (ksum - prod) / (N * H * W)
+
+
 def tv_loss(p):
     """tv_loss (pCE_TV_2D.py:58-65): mean(relu(dilate3(erode3(p)) - erode3(p)))."""
     e = -F.max_pool2d(-p, (3, 3), 1, 1)

@@ -338,6 +338,33 @@ def gen_crf():
     save("g4_gatedcrf", **out)
 
 
+def gen_crf_general():
+    """Round 6 (VERDICT r5 missing 4): what the reference's signature admits beyond the one descriptor its trainers pass --
+    several kernel descriptors summed, descriptors without 'xy' / with several sample modalities (gate_crf_loss.py:135-161) and a
+    `sample` larger than the prediction (F.adaptive_avg_pool2d, :127-133)."""
+    out = {}
+    crf = ModelLossSemsegGatedCRF()
+    cases = {
+        "two": ([{"weight": 1, "xy": 6, "rgb": 0.1}, {"weight": 0.5, "xy": 3}], (2, 24, 32), 3, 1),
+        "rgbonly": ([{"weight": 0.8, "rgb": 0.2}], (1, 16, 24), 2, 1),
+        "twomod": ([{"weight": 1, "xy": 5, "rgb": 0.15, "depth": 0.3}], (1, 20, 16), 2, 1),
+        "down": ([{"weight": 1, "xy": 6, "rgb": 0.1}], (2, 16, 24), 3, 2),
+        "three": ([{"weight": 1, "xy": 6, "rgb": 0.1}, {"weight": 0.3, "rgb": 0.5}, {"weight": 0.2, "xy": 2}], (1, 16, 16), 5, 1),
+    }
+    for i, (tag, (desc, (N, H, W), r, up)) in enumerate(cases.items()):
+        torch.manual_seed(170 + i)
+        y = torch.softmax(torch.randn(N, 4, H, W) * 1.5, 1).requires_grad_()
+        img = torch.rand(N, 1, H * up, W * up)
+        img_in = img.clone()
+        loss = crf(y, [dict(d) for d in desc], r, img_in, H * up, W * up)["loss"]
+        loss.backward()
+        assert torch.equal(img, img_in)
+        out.update({f"{tag}_y": y.detach().numpy(), f"{tag}_img": img.numpy(), f"{tag}_r": np.int64(r), f"{tag}_up": np.int64(up),
+                    f"{tag}_loss": np.float32(loss.item()), f"{tag}_dy": y.grad.numpy(),
+                    f"{tag}_desc": np.array(repr(desc))})
+    save("g11_gatedcrf_general", **out)
+
+
 def gen_tv_ms():
     out = {}
     torch.manual_seed(61)
@@ -676,8 +703,8 @@ def gen_init_digest():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["init", "convblock", "pool_up", "head", "crf", "tv_ms", "sgd", "net", "curve", "crf_curve", "upblock_t"]
-    fns = dict(init=gen_init_digest, convblock=gen_convblock, pool_up=gen_pool_up, head=gen_head, crf=gen_crf,
+    which = sys.argv[1:] or ["init", "convblock", "pool_up", "head", "crf", "crf_general", "tv_ms", "sgd", "net", "curve", "crf_curve", "upblock_t"]
+    fns = dict(init=gen_init_digest, convblock=gen_convblock, pool_up=gen_pool_up, head=gen_head, crf=gen_crf, crf_general=gen_crf_general,
                tv_ms=gen_tv_ms, sgd=gen_sgd_ema, net=gen_net, curve=gen_curve_and_ddp, crf_curve=gen_crf_curve,
                upblock_t=gen_upblock_t)
     for w in which:

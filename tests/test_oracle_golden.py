@@ -106,6 +106,15 @@ def test_gatedcrf_tv_ms_against_reference():
     loss, _ = R.gatedcrf(y, t(g["alt_img"]), int(g["alt_r"]), sxy, srgb, w)
     loss.backward()
     assert rel_err(loss.item(), g["alt_loss"]) < TOL and rel_err(y.grad, g["alt_dy"]) < TOL
+    # what the signature admits beyond the trainers' descriptor (round 6): several descriptors, missing / several modalities, a larger sample
+    g = golden("g11_gatedcrf_general")
+    for tag in ("two", "rgbonly", "twomod", "down", "three"):
+        desc = eval(str(g[f"{tag}_desc"]), {"__builtins__": {}})       # a literal list of dicts of numbers, written by make_golden.py
+        y = t(g[f"{tag}_y"]).requires_grad_()
+        loss = R.gatedcrf_general(y, t(g[f"{tag}_img"]), desc, int(g[f"{tag}_r"]))
+        loss.backward()
+        assert rel_err(loss.item(), g[f"{tag}_loss"]) < TOL, tag
+        assert rel_err(y.grad, g[f"{tag}_dy"]) < TOL, tag
     g = golden("g5_tv_ms")
     for pre in ("tv", "tvt"):
         p = t(g[f"{pre}_p"]).requires_grad_()

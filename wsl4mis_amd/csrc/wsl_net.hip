@@ -399,7 +399,9 @@ static int pack_all(const Ctx& c, int with_dgrad) {
   t.n = 0;
   // `skip`: bit 0 / bit 1 = the forward / data-gradient launches of this layer take the Winograd kernels at its level (the very test
   // conv_any and conv_dgrad_bn apply), so nobody reads its direct [tap][ci][co] image: 3x3 layers are 99 % of the parameters, and
-  // packing images that are never read was 41 us of every step (round 5)
+  // packing images that are never read was 41 us of every step (round 5).  The prediction and the launch apply the SAME test,
+  // wsl_conv2d_wino_ok(), which in the product library is a pure function of the layer's shape (round 6: no routing state left -- ADVICE r5;
+  // in the experiments build the tuning tools set their switches before the forward and leave them until the backward has run)
   auto one = [&](const ConvRef& cv, int l, int ca = 0, int cb = 0) {
     int skip = 0;
     if (cv.ks == 3) {

@@ -1,7 +1,9 @@
 """Drop-in for utils/gate_crf_loss.py: ModelLossSemsegGatedCRF with the reference's forward signature
 (ref: utils/gate_crf_loss.py:20-124).  One stencil kernel computes the pairwise messages; nothing of the reference's
-[N,C,(2r+1)^2,H,W] unfolded tensors is ever materialised.  Options no trainer of the reference passes raise
-NotImplementedError (never silently ignored)."""
+[N,C,(2r+1)^2,H,W] unfolded tensors is ever materialised.  Round 6: any number of kernel descriptors (summed, ref :135-161), descriptors
+with or without 'xy' and with one or several sample modalities, and a `sample` larger than the prediction (adaptive average pooling,
+ref :127-133).  What stays unbuilt raises NotImplementedError (never silently ignored): masks, a compatibility matrix, custom downsamplers,
+kernel visualisation, a multi-channel `sample`."""
 import torch
 
 from .. import _lib
@@ -45,11 +47,37 @@ class ModelLossSemsegGatedCRF(torch.nn.Module):
                 raise NotImplementedError(f"ModelLossSemsegGatedCRF: `{name}` is not built (Potts model, no masks)")
         if out_kernels_vis:
             raise NotImplementedError("ModelLossSemsegGatedCRF: out_kernels_vis is not built")
-        if len(kernels_desc) != 1 or set(kernels_desc[0]) != {"weight", "xy", "rgb"}:
-            raise NotImplementedError("ModelLossSemsegGatedCRF: exactly one {'weight','xy','rgb'} kernel descriptor is "
-                                      f"built (the one every reference trainer passes), got {kernels_desc}")
-        if tuple(sample.shape) != (N, 1, height_pred, width_pred):
-            raise NotImplementedError("ModelLossSemsegGatedCRF: `sample` must be a single-channel image at prediction "
-                                      f"resolution [N,1,{height_pred},{width_pred}], got {tuple(sample.shape)}")
-        d = kernels_desc[0]
-        return {"loss": _CRF.apply(y_hat_softmax, sample, kernels_radius, d["weight"], d["xy"], d["rgb"])}
+        if len(kernels_desc) == 0:
+            raise ValueError("ModelLossSemsegGatedCRF: kernels_desc is empty")
+        if sample.dim() != 4 or sample.shape[0] != N:
+            raise AssertionError("ModelLossSemsegGatedCRF: `sample` must be an NCHW batch of the prediction's batch size")
+        if sample.shape[1] != 1:
+            raise NotImplementedError("ModelLossSemsegGatedCRF: a single-channel `sample` is built (every trainer of the reference passes the "
+                                      f"1-channel slice batch), got {tuple(sample.shape)}")
+        if tuple(sample.shape[-2:]) != (height_pred, width_pred):
+            # gate_crf_loss.py:127-133: F.adaptive_avg_pool2d of the modality to the prediction's resolution (round 6: VERDICT r5 missing 4)
+            sample = torch.nn.functional.adaptive_avg_pool2d(sample, (height_pred, width_pred))
+        # gate_crf_loss.py:135-161: the kernel of the loss is the SUM of the descriptors' kernels and the loss is linear in it -> one stencil
+        # pass per descriptor, the losses added (autograd adds the gradients).  A descriptor's features are the pixel mesh / sigma_xy (if it
+        # lists 'xy') and `sample` / sigma once per other modality it lists (the reference hands EVERY non-xy modality the same `sample`):
+        # k such modalities are one with 1 / sigma^2 = sum 1 / sigma_k^2.  A modality a descriptor does not list enters the stencil kernel
+        # with sigma = 1e18: every squared difference then is below 1e-30 and its factor exactly 1.0 in fp32.
+        total = None
+        for d in kernels_desc:
+            if "weight" not in d:
+                raise KeyError("weight")
+            inv2, sxy = 0.0, None
+            for modality, sigma in d.items():
+                if modality == "weight":
+                    continue
+                if modality == "xy":
+                    sxy = float(sigma)
+                else:
+                    inv2 += 1.0 / (float(sigma) * float(sigma))
+            if sxy is None and inv2 == 0.0:
+                raise RuntimeError("ModelLossSemsegGatedCRF: a kernel descriptor needs at least one modality besides 'weight' "
+                                   "(the reference's torch.cat of an empty feature list fails here)")
+            srgb = (1.0 / inv2) ** 0.5 if inv2 > 0.0 else 1e18
+            term = _CRF.apply(y_hat_softmax, sample, kernels_radius, d["weight"], sxy if sxy is not None else 1e18, srgb)
+            total = term if total is None else total + term
+        return {"loss": total}
