@@ -273,15 +273,17 @@ struct ClsP {
 struct ClsCfg {
   static constexpr int TH = 8, TW = 64, ROWP = TW + 8, ROWS = TH + 2, ROWP4 = ROWP / 4, POS = ROWS * ROWP4, KC = 8;
   static constexpr int PLANE = ROWS * ROWP;
-  static constexpr size_t SMEM = sizeof(float) * (KC * PLANE + 32);
+  // TWO staged halves (round 6): the 8-channel half being multiplied and the one being committed live in different buffers, so a tile costs
+  // two barriers instead of four (46 KB per workgroup, two workgroups per CU)
+  static constexpr size_t SMEM = sizeof(float) * (2 * KC * PLANE + 32);
   static_assert(POS <= 256, "one float4 position per thread");
 };
 
 __global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
   using C = ClsCfg;
   WSL_DYN_SMEM(smem);
-  float* in_t = reinterpret_cast<float*>(smem);
-  float2* tab = reinterpret_cast<float2*>(in_t + C::KC * C::PLANE);   // [16] {scale, shift}
+  float* in_b = reinterpret_cast<float*>(smem);                      // two staged halves [2][KC][PLANE]
+  float2* tab = reinterpret_cast<float2*>(in_b + 2 * C::KC * C::PLANE);   // [16] {scale, shift}
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, W = p.W, HW = H * W;
   const bool has_scale = p.scale != nullptr;
@@ -306,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
   const int it1 = interleaved ? p.items : (int)((int64_t)(bx + 1) * p.items / nwg);
   const int step = interleaved ? nwg : 1;
 
-  float4 pre[C::KC];
+  float4 pre[C::KC];   // (BOTH halves of the next tile in flight during a whole tile's matrix phase -- 64 registers, 242 in all -- measured
+                       //  113.4 us against 104.5 for this form and 107.7 for the four-barrier single buffer: round 6, tools/gpu_kernel_ab.sh)
   bool pok = false;
   auto tile_of = [&](int item, int& n, int& y0, int& x0) {
     int q = item;
@@ -326,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
     for (int i = 0; i < C::KC; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + (int64_t)i * HW + off);
   };
   auto commit = [&](int ch) __attribute__((always_inline)) {
+    float* in_t = in_b + ch * (C::KC * C::PLANE);
     if (owner) {
 #pragma unroll
       for (int i = 0; i < C::KC; ++i) {
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
   // one 8-channel half of the reduction: rows 2*wave and 2*wave+1 of the tile, pixel = lane
   auto mfma_half = [&](auto ch_tag) __attribute__((always_inline)) {
     constexpr int CH = decltype(ch_tag)::value;   // std::integral_constant
+    const float* in_t = in_b + CH * (C::KC * C::PLANE);
 #pragma unroll
     for (int cc = 0; cc < C::KC; ++cc)
 #pragma unroll
@@ -364,16 +369,14 @@ __global__ __launch_bounds__(256, 2) void conv_cls_kernel(ClsP p) {
   __syncthreads();   // table visible
   for (int item = it0; item < it1; item += step) {
     acc[0] = v4f{bias, bias, bias, bias}, acc[1] = acc[0];
-    commit(0);
-    __syncthreads();
+    commit(0);                     // (buffer 0 is free: every wave passed barrier B of the previous tile after its first half)
     issue(item, 1);
+    __syncthreads();               // A: half 0 staged; every wave is done with buffer 1 (second half of the previous tile)
     mfma_half(std::integral_constant<int, 0>{});
-    __syncthreads();
     commit(1);
-    __syncthreads();
     if (item + step < it1) issue(item + step, 0);
+    __syncthreads();               // B: half 1 staged; every wave is done with buffer 0
     mfma_half(std::integral_constant<int, 1>{});
-    __syncthreads();
     int n, y0, x0;
     tile_of(item, n, y0, x0);
     float* yb = p.y + n * p.y_bs + (int64_t)(lane & 3) * HW + (int64_t)(y0 + wave * 2) * W + x0 + (lane >> 2) * 4;
