@@ -357,6 +357,7 @@ static int conv_dgrad_bn(const Ctx& c, const ConvRef& cv, const float* dy, float
                                    c.ws + st, emask, es, c.ws + c.S().bn_ws, &fused, c.stream));
     gs->nblk = fused ? wsl_sp_conv2d_stat_blocks(N, H, W, cv.Co, Cg) : 0;
     gs->channel_major = 1;
+    gs->g_is_d = 0;          // (the split kernels write the plain gradient)
     return WSL_OK;
   }
   const float* w = c.params + cv.w;
