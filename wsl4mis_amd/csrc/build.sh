@@ -61,6 +61,16 @@ if [ "${1:-}" = "exp" ] || [ "${2:-}" = "exp" ]; then
   echo "built $xd/libwslhip_exp.so"
 fi
 
+# ./build.sh expvar   with WSL_EXP_TAG=<tag> WSL_EXP_FLAGS="-DWSL_X=1 ...": a tagged experiments build with extra compile flags
+#                     (tools/exp/libwslhip_exp_<tag>.so; the tuning tools pick it with WSL_EXP_LIB=<tag>) -- same-box A/B of source variants
+if [ "${1:-}" = "expvar" ]; then
+  xd="$root/tools/exp"; tag="${WSL_EXP_TAG:?WSL_EXP_TAG}"
+  # shellcheck disable=SC2086
+  build_variant "$xd/build_$tag" "$xd/libwslhip_exp_$tag.so" "$HIPCC" "" "" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DWSL_EXPERIMENTS ${WSL_EXP_FLAGS:-}
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${BUILT_OBJS[@]}" -o "$xd/libwslhip_exp_$tag.so"
+  echo "built $xd/libwslhip_exp_$tag.so"
+fi
+
 if [ "${1:-}" = "emul" ] || [ "${2:-}" = "emul" ]; then
   CXX="${EMUL_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
   em="$root/tests/emul"

@@ -528,6 +528,25 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
     for (int i = 0; i < C::NWL; ++i) WSL_LDS_DMA16_UNTRACKED_SO(wb + i * (4 * kThreads), (uint32_t)tid * 16u, wdst + i * (4 * kThreads));
   };
 
+  // (experiments build, -DWSL_WINO_V=bits via `build.sh expvar`: 1 = the next chunk's DMA pieces are spread over the matrix loop instead of
+  //  issued as one burst at its head, 2 = no scheduling fences in the matrix loop, 4 = s_setprio 1 around the matrix loop)
+#ifndef WSL_WINO_V
+#define WSL_WINO_V 0
+#endif
+  auto issue_piece = [&](int c0, int bsel, int k) __attribute__((always_inline)) {
+    if (k < C::NLD) {
+      const bool ina = c0 < p.a.C;
+      const int chb = ina ? c0 : c0 - p.a.C;
+      const float* xb = (ina ? xa_n : xb_n) + (int64_t)chb * HW;
+      float* dst = in_b + bsel * C::IN_FLOATS + wslot;
+      if (pvalid) WSL_LDS_DMA16_UNTRACKED_SO(xb + k * gstride, (uint32_t)toff * 4u, dst + k * (C::G * C::PLANE));
+    } else {
+      const int i = k - C::NLD;
+      const float* wb = p.u + (int64_t)cby * C::W_FLOATS + (c0 / KC) * w_cstride;
+      float* wdst = w_b + bsel * C::W_FLOATS + wave * 256;
+      WSL_LDS_DMA16_UNTRACKED_SO(wb + i * (4 * kThreads), (uint32_t)tid * 16u, wdst + i * (4 * kThreads));
+    }
+  };
   issue(0, 0);
   // data-gradient launches with the BatchNorm-backward statistics epilogue: its y / keep-mask reads are issued HERE, a whole
   // channel loop ahead of their use (this kernel has the 40 registers; the epilogue would otherwise sit out their latency)
@@ -559,9 +578,8 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
   // one chunk; FIRST: the accumulators start from the MFMA's zero C operand (no 128-register clear)
   auto chunk = [&](int c0, int bsel, auto first_tag) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    if constexpr ((ABL & 2) == 0) {
-      if (c0 + KC < Ci) issue(c0 + KC, bsel ^ 1);   // the next chunk streams into the other buffers during this one's compute
-    }
+    const bool more = (ABL & 2) == 0 && c0 + KC < Ci;
+    if ((WSL_WINO_V & 1) == 0 && more) issue(c0 + KC, bsel ^ 1);   // the next chunk streams into the other buffers during this one's compute
     const float* in_t = in_b + bsel * C::IN_FLOATS;
     const float* w_t = w_b + bsel * C::W_FLOATS;
     wsl_v2f rlo[MTW][4], rhi[MTW][4];   // the 4 x 4 patches, one row per pair of register pairs
@@ -607,9 +625,18 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
       };
 #pragma unroll
       for (int xi = 0; xi < BD; ++xi) loadb(xi, xi % BR);
+#if (WSL_WINO_V & 4)
+      if (kg == 0) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) {
         if (xi + BD < 16) loadb(xi + BD, (xi + BD) % BR);
+        if ((WSL_WINO_V & 1) != 0 && more) {   // one DMA piece every few transform positions (compile-time slots after unrolling)
+          constexpr int NP = C::NLD + C::NWL;
+#pragma unroll
+          for (int k = 0; k < NP; ++k)
+            if (kg * 16 + xi == (k * 32) / NP) issue_piece(c0 + KC, bsel ^ 1, k);
+        }
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -619,9 +646,14 @@ __global__ __launch_bounds__(256, (Wino2Cfg<TH, TW, NT>::MINW)) void conv_wino2r
             if constexpr ((ABL & 1) != 0) acc[xi][m * NT + j][0] = cin[0] + wino_pick(va[m], vb[m], xi) * bv[xi % BR][j];
             else acc[xi][m * NT + j] = WSL_MFMA16(wino_pick(va[m], vb[m], xi), bv[xi % BR][j], cin);
           }
+#if !(WSL_WINO_V & 2)
         WSL_SCHED_BARRIER();
+#endif
       }
     }
+#if (WSL_WINO_V & 4)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     WSL_WAIT_ALL();    // the next chunk's DMA has landed
     __syncthreads();   // ... and every wave is done with this chunk's buffers
   };
