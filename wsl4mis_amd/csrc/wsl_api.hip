@@ -60,7 +60,14 @@ static SideCtx* side_ctx(void* main) {
   for (auto& c : g_sides)
     if (c.dev == dev && c.main == (hipStream_t)main) return &c;
   SideCtx c{dev, (hipStream_t)main, nullptr, nullptr, nullptr};
-  if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess ||
+  // (experiments build: WSL_SIDE_PRIO = 1 / -1 creates the side stream at the highest / lowest stream priority -- an asymmetry between the
+  //  two decoder streams, whose kernel sequences are identical and otherwise run in lock-step; measured: profiles/r6_side_stream_priority.md)
+  static const int side_prio = WSL_TUNE("WSL_SIDE_PRIO", 0);
+  int plo = 0, phi = 0;
+  hipError_t made = hipErrorUnknown;
+  if (side_prio != 0 && hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess)
+    made = hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, side_prio > 0 ? phi : plo);
+  if ((made != hipSuccess && hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) ||
       hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess)
     return nullptr;
