@@ -896,10 +896,12 @@ struct WgradSpP {
 
 template <int TH, int TW, int CB>
 struct WgradSpCfg {
-  // (a pitch / plane offset that halves the transpose reads' bank conflicts in the model of tools/lds_tr_conflicts.py measured no faster:
-  //  profiles/r3_wgrad_sp_lds_conflicts.md, profiles/r4_conv_sp_rework_ab.log)
-  using In = SpImg<TH + 2, (TW + 8) / 4, CB / 8, (TW + 8) / 4>;
-  using Dy = SpImg<TH, TW / 4, CB / 8, TW / 4>;
+  // Round 6: at 32-pixel rows the images take a pixel pitch of 12 quads and planes 16 bytes off a multiple of 256 -- the two octets of a
+  // transpose read and the four pixels of a quad then fall on different bank groups (tools/lds_tr_conflicts.py: 6.0 -> 3.0 LDS clocks per
+  // read; measured: bank-conflict share of LDS-active cycles 0.524 -> 0.289, 118.4 -> 115.3 us per launch, the split step unchanged within
+  // 0.1 %; 51 -> 66 KB per workgroup, still two per CU).  16-pixel rows keep the compact images (the padded ones would cost a workgroup per CU).
+  using In = SpImg<TH + 2, (TW + 8) / 4, CB / 8, (TW == 32 ? 12 : (TW + 8) / 4), (TW == 32 ? 16 : 0)>;
+  using Dy = SpImg<TH, TW / 4, CB / 8, (TW == 32 ? 12 : TW / 4), (TW == 32 ? 16 : 0)>;
   static constexpr int KS = TH * TW / 32, KROWS = 32 / TW;      // K-steps per tile; tile rows per K-step
   static constexpr size_t SMEM = In::BYTES + Dy::BYTES;
   static_assert(TW == 16 || TW == 32, "a K-step is one row of 32 pixels or two rows of 16");
